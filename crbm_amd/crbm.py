@@ -1,0 +1,456 @@
+"""`CRBM` -- the reference's Python surface (secomo/convRBM.py:25-726) over the
+HIP C-ABI (include/crbm_amd.h).
+
+Same constructor signature, same validation and messages, same methods
+(`fit`, `freeEnergy`, `motifHitProbs`, `getPFMs`, `saveModel`, `loadModel`) and
+the `motifs` / `bias` / `c` objects with `get_value()` / `set_value()`; plus
+`trainModel` (alias of `fit`, the name BASELINE.json's north_star uses).
+Every tensor operation the reference hands to Theano runs in the HIP library;
+this file only holds host logic (argument checks, batching, printing, pickles).
+"""
+import ctypes
+import os
+import time
+import warnings
+
+import joblib
+import numpy as np
+import scipy.stats
+
+from . import _lib
+from ._lib import CrbmConfig, as_f32, fptr
+
+
+class _DeviceShared(object):
+    """Stand-in for a `theano.shared` variable (convRBM.py:133,149,152):
+    `get_value()` / `set_value()` on a parameter that lives on the GPU."""
+
+    def __init__(self, model, name, shape):
+        self._model = model
+        self.name = name
+        self._shape = shape
+
+    def get_value(self, borrow=False):
+        return self._model._get_param(self.name).copy()
+
+    def set_value(self, value, borrow=False):
+        value = as_f32(value)
+        if value.shape != self._shape:
+            raise ValueError("%s: expected shape %s, got %s" % (self.name, self._shape, value.shape))
+        self._model._set_param(self.name, value)
+
+    def __repr__(self):
+        return self.name
+
+
+class CRBM(object):
+    """Convolutional RBM for DNA motifs; API of secomo.CRBM (convRBM.py:25-67).
+
+    Parameters follow convRBM.py:68-71.  Keyword-only extras (not in the
+    reference): ``fantasy_hidden_len`` (the reference hard-codes the hidden
+    length of the persistent chains to 200, convRBM.py:168), ``seed``
+    (reference: wall clock, convRBM.py:155) and ``device``.
+    """
+
+    def __init__(self, num_motifs, motif_length, epochs=100, input_dims=4,
+                 doublestranded=True, batchsize=20, learning_rate=0.1,
+                 momentum=0.95, pooling=1, cd_k=5,
+                 rho=0.01, lambda_rate=0.1, **extra):
+        # sanity checks: convRBM.py:72-108 (same order, same messages)
+        if num_motifs <= 0:
+            raise Exception("Number of motifs must be positive.")
+        if motif_length <= 0:
+            raise Exception("Motif length must be positive.")
+        if epochs < 0:
+            raise Exception("Epochs must be non-negative.")
+        if input_dims <= 0:
+            raise Exception("input_dims must be positive.")
+        elif input_dims != 4:
+            warnings.warn("input_dims != 4 was not comprehensively "
+                          "tested yet. Be careful when interpreting the results.",
+                          UserWarning)
+        if batchsize <= 0:
+            raise Exception("batchsize must be positive.")
+        if learning_rate <= 0.0:
+            raise Exception("learning_rate must be positive.")
+        if not (momentum >= 0.0 and momentum < 1.):
+            raise Exception("momentum must be between zero and one.")
+        if pooling <= 0:
+            raise Exception("pooling must be positive.")
+        if cd_k <= 0:
+            raise Exception("cd_k must be positive.")
+        if not (rho >= 0.0 and rho < 1.):
+            raise Exception("rho must be between zero and one.")
+        if lambda_rate < 0.:
+            raise Exception("lambda_rate must be non-negative.")
+
+        fantasy_hidden_len = int(extra.pop("fantasy_hidden_len", 200))
+        seed = extra.pop("seed", None)
+        device = extra.pop("device", None)
+        if extra:
+            raise TypeError("unexpected keyword arguments: %s" % sorted(extra))
+
+        # convRBM.py:111-123
+        self.num_motifs = num_motifs
+        self.motif_length = motif_length
+        self.input_dims = input_dims
+        self.doublestranded = doublestranded
+        self.batchsize = batchsize
+        self.learning_rate = learning_rate
+        self.momentum = momentum
+        self.rho = rho
+        self.lambda_rate = lambda_rate
+        self.pooling = pooling
+        self.cd_k = cd_k
+        self.epochs = epochs
+        self.spmethod = 'entropy'
+        self.fantasy_hidden_len = fantasy_hidden_len
+        self.seed = int(time.time()) if seed is None else int(seed)      # :155
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        self.device = device
+
+        # convRBM.py:127-131: N(0,1) filters from NumPy's global RNG
+        W = np.random.randn(num_motifs, 1, input_dims, motif_length).astype(np.float32)
+        # convRBM.py:136-140
+        if not rho:
+            rho = 1. / (self.num_motifs * self.motif_length)
+            if self.doublestranded:
+                rho = rho / 2.
+            self.rho = rho
+        # convRBM.py:143-149 (floatX=float32; NumPy 2 would promote, so cast)
+        b = (np.zeros((1, num_motifs)) +
+             scipy.stats.norm.ppf(self.rho, 0, np.sqrt(motif_length))).astype(np.float32)
+        c = np.zeros((1, input_dims), dtype=np.float32)                  # :151
+        self._host = {"motifs": W, "bias": b, "c": c}
+        self._handle = None
+        self._comm_ready = False
+        self.motifs = _DeviceShared(self, "motifs", W.shape)
+        self.bias = _DeviceShared(self, "bias", b.shape)
+        self.c = _DeviceShared(self, "c", c.shape)
+        # data-parallel state (set by crbm_amd.dist.attach)
+        self.world_size = 1
+        self.rank = 0
+
+    # ------------------------------------------------------------------ device
+    def _h(self):
+        """The device handle; created on first use.  Replaces the Theano
+        compile step (convRBM.py:175, :453-515).  No CPU fallback."""
+        if self._handle is not None:
+            return self._handle
+        if self.input_dims != 4:
+            raise Exception("the HIP kernels require input_dims == 4")
+        if self.pooling != 1:
+            raise Exception("the HIP kernels require pooling == 1")
+        lib = _lib.load()
+        if self.batchsize % self.world_size != 0:
+            raise Exception("batchsize must be divisible by the number of GPUs")
+        cfg = CrbmConfig(
+            num_motifs=self.num_motifs, motif_length=self.motif_length, input_dims=self.input_dims,
+            doublestranded=1 if self.doublestranded else 0,
+            batchsize=self.batchsize // self.world_size, cd_k=self.cd_k, pooling=self.pooling,
+            fantasy_hidden_len=self.fantasy_hidden_len, learning_rate=self.learning_rate,
+            momentum=self.momentum, rho=self.rho, lambda_rate=self.lambda_rate,
+            seed=self.seed & 0xFFFFFFFFFFFFFFFF, device=self.device, reserved=0)
+        handle = ctypes.c_void_p()
+        rc = lib.crbm_create(ctypes.byref(cfg), ctypes.byref(handle))
+        if rc != 0:
+            raise Exception("crbm_create failed (%d): %s" % (rc, lib.crbm_last_error(None).decode()))
+        self._handle = handle
+        self._lib = lib
+        self._call("crbm_set_params", fptr(self._host["motifs"]), fptr(self._host["bias"]),
+                                        fptr(self._host["c"]))
+        self._call("crbm_set_shard", self.rank * (self.batchsize // self.world_size))
+        return handle
+
+    def _call(self, name, *args):
+        h = self._h()
+        self._check(getattr(self._lib, name)(h, *args))
+
+    def _check(self, rc):
+        if rc != 0:
+            raise Exception("HIP CRBM call failed (%d): %s"
+                            % (rc, self._lib.crbm_last_error(self._handle).decode()))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_handle", None) is not None:
+                self._lib.crbm_destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+    def _get_param(self, name):
+        if self._handle is None:
+            return self._host[name]
+        W = np.empty((self.num_motifs, 1, 4, self.motif_length), dtype=np.float32)
+        b = np.empty((1, self.num_motifs), dtype=np.float32)
+        c = np.empty((1, 4), dtype=np.float32)
+        self._check(self._lib.crbm_get_params(self._handle, fptr(W), fptr(b), fptr(c)))
+        return {"motifs": W, "bias": b, "c": c}[name]
+
+    def _set_param(self, name, value):
+        if self._handle is None:
+            self._host[name] = value
+            return
+        cur = {n: self._get_param(n) for n in ("motifs", "bias", "c")}
+        cur[name] = value
+        self._check(self._lib.crbm_set_params(self._handle, fptr(cur["motifs"]), fptr(cur["bias"]),
+                                              fptr(cur["c"])))
+
+    @staticmethod
+    def _data(data):
+        data = as_f32(data)
+        if data.ndim != 4 or data.shape[1] != 1 or data.shape[2] != 4:
+            raise Exception("expected a one-hot array of shape (n,1,4,L), got %s" % (data.shape,))
+        return data
+
+    # ------------------------------------------------------------- persistence
+    def saveModel(self, filename):
+        """convRBM.py:177-204 -- same pickle tuple."""
+        numpyParams = (self.motifs.get_value(), self.bias.get_value(), self.c.get_value())
+        hyperparams = (self.num_motifs, self.motif_length, self.input_dims, self.doublestranded,
+                       self.batchsize, self.learning_rate, self.momentum, self.rho, self.lambda_rate,
+                       self.pooling, self.cd_k, self.epochs, self.spmethod)
+        joblib.dump((numpyParams, hyperparams), filename, protocol=2)
+
+    @classmethod
+    def loadModel(cls, filename):
+        """convRBM.py:206-236 -- velocities and chains restart from zero."""
+        numpyParams, hyperparams = joblib.load(filename)
+        (num_motifs, motif_length, input_dims, doublestranded, batchsize, learning_rate,
+         momentum, rho, lambda_rate, pooling, cd_k, epochs, spmethod) = hyperparams
+        obj = cls(num_motifs, motif_length, epochs=epochs, input_dims=input_dims,
+                  doublestranded=doublestranded, batchsize=batchsize, learning_rate=learning_rate,
+                  momentum=momentum, pooling=pooling, cd_k=cd_k, rho=rho, lambda_rate=lambda_rate)
+        motifs, bias, c = numpyParams
+        obj.motifs.set_value(motifs)
+        obj.bias.set_value(bias)
+        obj.c.set_value(c)
+        return obj
+
+    # ------------------------------------------- graph builders as plain calls
+    def _hgv(self, data, flip, want, rng_step=0):
+        data = self._data(data)
+        n, L = data.shape[0], data.shape[3]
+        shape = (n, self.num_motifs, 1, L - self.motif_length + 1)
+        outs = [np.empty(shape, dtype=np.float32) if w else None for w in want]
+        self._call("crbm_h_given_v", fptr(data), n, L, 1 if flip else 0,
+                                             rng_step, fptr(outs[0]), fptr(outs[1]), fptr(outs[2]))
+        return outs
+
+    def _bottomUpActivity(self, data, flip_motif=False):
+        """convRBM.py:238-243."""
+        return self._hgv(data, flip_motif, (True, False, False))[0]
+
+    def _bottomUpProbabilityOfData(self, data, flip_motif=False):
+        """_bottomUpProbability(_bottomUpActivity(data)) (convRBM.py:245-257)."""
+        return self._hgv(data, flip_motif, (False, True, False))[1]
+
+    def _computeHgivenV(self, data, flip_motif=False, rng_step=0):
+        """convRBM.py:269-275 -> [probability, sample]."""
+        o = self._hgv(data, flip_motif, (False, True, True), rng_step)
+        return [o[1], o[2]]
+
+    def _vgh(self, h, hprime, want, rng_step=0):
+        h = as_f32(h)
+        hp = None if hprime is None else as_f32(hprime)
+        if h.ndim != 4 or h.shape[1] != self.num_motifs or h.shape[2] != 1:
+            raise Exception("expected hidden array of shape (n,K,1,Lh), got %s" % (h.shape,))
+        if hp is not None and hp.shape != h.shape:
+            raise Exception("h and hprime must have the same shape")
+        n, Lh = h.shape[0], h.shape[3]
+        shape = (n, 1, 4, Lh + self.motif_length - 1)
+        outs = [np.empty(shape, dtype=np.float32) if w else None for w in want]
+        self._call("crbm_v_given_h", fptr(h), fptr(hp), n, Lh, rng_step,
+                                             fptr(outs[0]), fptr(outs[1]), fptr(outs[2]))
+        return outs
+
+    def _topDownActivity(self, h, hprime=None):
+        """convRBM.py:277-292."""
+        return self._vgh(h, hprime, (True, False, False))[0]
+
+    def _topDownProbabilityOfHidden(self, h, hprime=None):
+        """_topDownProbability(_topDownActivity(h, hprime)) (convRBM.py:294-299)."""
+        return self._vgh(h, hprime, (False, True, False))[1]
+
+    def _computeVgivenH(self, H_sample, H_sample_prime=None, rng_step=0):
+        """convRBM.py:317-325 -> [probability, sample]."""
+        o = self._vgh(H_sample, H_sample_prime, (False, True, True), rng_step)
+        return [o[1], o[2]]
+
+    # ------------------------------------------------------------ evaluation
+    def _evaluateData(self, data):
+        """convRBM.py:517-522 -> [mean free energy, mean of a sampled H]."""
+        data = self._data(data)
+        mfe, nmh = ctypes.c_float(), ctypes.c_float()
+        self._call("crbm_eval_data", fptr(data), data.shape[0], data.shape[3],
+                                             ctypes.byref(mfe), ctypes.byref(nmh))
+        return [mfe.value, nmh.value]
+
+    def _evaluateParams(self):
+        """convRBM.py:528-533 -> [rms(W), IC, median IC]."""
+        a, b, c = ctypes.c_float(), ctypes.c_float(), ctypes.c_float()
+        self._call("crbm_eval_params", ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
+        return [a.value, b.value, c.value]
+
+    def _trainingFct(self, data):
+        """convRBM.py:524-526: one PCD-k update on a mini-batch."""
+        data = self._data(data)
+        self._call("crbm_train_step", fptr(data), data.shape[0], data.shape[3])
+
+    def motifHitProbs(self, data):
+        """convRBM.py:535-547 -> (n,K,1,L-M+1)."""
+        data = self._data(data)
+        n, L = data.shape[0], data.shape[3]
+        out = np.empty((n, self.num_motifs, 1, L - self.motif_length + 1), dtype=np.float32)
+        self._call("crbm_hit_probs", fptr(data), n, L, fptr(out))
+        return out
+
+    def freeEnergy(self, data, permotif=False):
+        """convRBM.py:549-568 -> (n,) or (n,K)."""
+        data = self._data(data)
+        n, L = data.shape[0], data.shape[3]
+        if permotif:
+            out = np.empty((n, self.num_motifs), dtype=np.float32)
+            self._call("crbm_free_energy_per_motif", fptr(data), n, L, fptr(out))
+        else:
+            out = np.empty((n,), dtype=np.float32)
+            self._call("crbm_free_energy", fptr(data), n, L, fptr(out))
+        return out
+
+    def getPFMs(self):
+        """convRBM.py:640-655 (host NumPy there too)."""
+        def softmax_(x):
+            x_exp = np.exp(x)
+            y = np.zeros(x.shape)
+            for i in range(x.shape[1]):
+                y[:, i] = x_exp[:, i] / np.sum(x_exp[:, i])
+            return y
+        return [softmax_(m[0, :, :]) for m in self.motifs.get_value()]
+
+    # --------------------------------------------------------------- training
+    def gibbsSteps(self, k=1):
+        """Advance the persistent chains by k Gibbs steps (convRBM.py:397-408)
+        with the parameters frozen."""
+        self._call("crbm_gibbs_steps", int(k))
+
+    def fit(self, training_data, test_data=None):
+        """convRBM.py:570-634: epochs x sequential, unshuffled mini-batches;
+        one status line per epoch.  The training set is uploaded once (packed
+        2-bit) and the batch loop only passes row bounds."""
+        # convRBM.py:586-599: truncate so that (L-M+1) % pooling == 0
+        nseq = int((training_data.shape[3] - self.motif_length + 1) / self.pooling) * \
+            self.pooling + self.motif_length - 1
+        training_data = training_data[:, :, :, :nseq]
+        if test_data is not None:
+            nseq = int((test_data.shape[3] - self.motif_length + 1) / self.pooling) * \
+                self.pooling + self.motif_length - 1
+            test_data = test_data[:, :, :, :nseq]
+        else:
+            test_data = training_data
+
+        print(("BatchSize: " + str(self.batchsize)))
+        print("Start training the model...")
+        starttime = time.time()
+        h = self._h()
+        lib = self._lib
+        train = self._data(training_data)
+        test = self._data(test_data)
+        if self.epochs > 0:
+            self._call("crbm_dataset_upload", fptr(train), train.shape[0], train.shape[3])
+        for epoch in range(self.epochs):
+            for [start, end] in self._iterateBatchIndices(train.shape[0], self.batchsize):
+                lo, hi = self._shard_rows(start, end)
+                self._call("crbm_train_step_resident", lo, hi)
+            meanfe = 0.0
+            meannmh = 0.0
+            nb = 0
+            for [start, end] in self._iterateBatchIndices(test.shape[0], self.batchsize):
+                [mfe_, nmh_] = self._evaluateData(test[start:end, :, :, :])
+                meanfe = meanfe + mfe_
+                meannmh = meannmh + nmh_
+                nb = nb + 1
+            [twn_, ic_, medic_] = self._evaluateParams()
+            if self.rank == 0:
+                print(("Epoch {:d}: ".format(epoch) +
+                       "FE={:1.3f} ".format(meanfe / nb) +
+                       "NumH={:1.4f} ".format(meannmh / nb) +
+                       "WNorm={:2.2f} ".format(float(twn_)) +
+                       "IC={:1.3f} medIC={:1.3f}".format(float(ic_), float(medic_))))
+        print(("Training finished after: {:5.2f} seconds!".format(time.time() - starttime)))
+
+    # the name BASELINE.json's north_star uses for the same entry point
+    trainModel = fit
+
+    def _shard_rows(self, start, end):
+        """Rows of mini-batch [start,end) this rank owns (contiguous, balanced)."""
+        if self.world_size == 1:
+            return start, end
+        n = end - start
+        lo = start + (n * self.rank) // self.world_size
+        hi = start + (n * (self.rank + 1)) // self.world_size
+        return lo, hi
+
+    def _iterateBatchIndices(self, totalsize, nbatchsize):
+        """convRBM.py:722-726."""
+        return [[i, i + nbatchsize] if i + nbatchsize <= totalsize
+                else [i, totalsize] for i in range(totalsize)[0::nbatchsize]]
+
+    def __repr__(self):
+        # convRBM.py:704-720 (no line breaks between hyper-parameters there either)
+        st = "Parameters:\n\n"
+        st += "Number of motifs: {}\n".format(self.num_motifs)
+        st += "Motif length: {}\n".format(self.motif_length)
+        st += "\n"
+        st += "Hyper-parameters:\n\n"
+        st += "input dims: {:d}".format(self.input_dims)
+        st += "doublestranded: {}".format(self.doublestranded)
+        st += "batchsize: {:d}".format(self.batchsize)
+        st += "learning rate: {:1.3f}".format(self.learning_rate)
+        st += "momentum: {:1.3f}".format(self.momentum)
+        st += "rho: {:1.4f}".format(self.rho)
+        st += "lambda: {:1.3f}".format(self.lambda_rate)
+        st += "pooling: {:d}".format(self.pooling)
+        st += "cd_k: {:d}".format(self.cd_k)
+        st += "epochs: {:d}".format(self.epochs)
+        return st
+
+    # ------------------------------------------- state the reference never saves
+    def get_velocities(self):
+        vW = np.empty((self.num_motifs, 1, 4, self.motif_length), dtype=np.float32)
+        vb = np.empty((1, self.num_motifs), dtype=np.float32)
+        vc = np.empty((1, 4), dtype=np.float32)
+        self._call("crbm_get_velocities", fptr(vW), fptr(vb), fptr(vc))
+        return vW, vb, vc
+
+    def set_velocities(self, vW, vb, vc):
+        self._call("crbm_set_velocities", fptr(as_f32(vW)), fptr(as_f32(vb)),
+                                                  fptr(as_f32(vc)))
+
+    def get_fantasy(self):
+        """(fantasy_h, fantasy_h_prime or None), dense float32 (convRBM.py:168-173)."""
+        h = self._h()
+        nb = self.batchsize // self.world_size
+        shape = (nb, self.num_motifs, 1, self.fantasy_hidden_len)
+        a = np.empty(shape, dtype=np.float32)
+        b = np.empty(shape, dtype=np.float32) if self.doublestranded else None
+        self._call("crbm_get_fantasy", fptr(a), fptr(b))
+        return a, b
+
+    def set_fantasy(self, hid, hid_prime=None):
+        h = self._h()
+        self._call("crbm_set_fantasy", fptr(as_f32(hid)),
+                                               fptr(None if hid_prime is None else as_f32(hid_prime)))
+
+    def get_fantasy_visible(self):
+        h = self._h()
+        nb = self.batchsize // self.world_size
+        v = np.empty((nb, 1, 4, self.fantasy_hidden_len + self.motif_length - 1), dtype=np.float32)
+        self._call("crbm_get_fantasy_visible", fptr(v))
+        return v
+
+    def set_rng(self, seed=None, gibbs_step=0, eval_step=0):
+        if seed is not None:
+            self.seed = int(seed)
+        self._call("crbm_set_rng", self.seed & 0xFFFFFFFFFFFFFFFF, gibbs_step, eval_step)

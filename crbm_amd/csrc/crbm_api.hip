@@ -1,0 +1,956 @@
+// Host side of the C-ABI declared in include/crbm_amd.h: owns device memory,
+// the HIP stream and (optionally) the RCCL communicator of one GPU, and turns
+// each entry point into kernel launches.  No torch, no Python types.
+#define CRBM_DEFINE_MISC_KERNELS
+#include "crbm_kernels.h"
+#include "../../include/crbm_amd.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace crbm;
+
+namespace crbm {
+#define CRBM_DECL_TABLE(n) const KernelTable* kernel_table_nq##n();
+CRBM_DECL_TABLE(1) CRBM_DECL_TABLE(2) CRBM_DECL_TABLE(3) CRBM_DECL_TABLE(4) CRBM_DECL_TABLE(5)
+CRBM_DECL_TABLE(6) CRBM_DECL_TABLE(8) CRBM_DECL_TABLE(10) CRBM_DECL_TABLE(13) CRBM_DECL_TABLE(16)
+const KernelTable* kernel_table(int nq) {
+  switch (nq) {
+    case 1: return kernel_table_nq1();
+    case 2: return kernel_table_nq2();
+    case 3: return kernel_table_nq3();
+    case 4: return kernel_table_nq4();
+    case 5: return kernel_table_nq5();
+    case 6: return kernel_table_nq6();
+    case 8: return kernel_table_nq8();
+    case 10: return kernel_table_nq10();
+    case 13: return kernel_table_nq13();
+    case 16: return kernel_table_nq16();
+    default: return nullptr;
+  }
+}
+}  // namespace crbm
+
+namespace {
+
+std::string g_create_error;
+
+// ---- RCCL, loaded on demand so that the library itself has no link-time
+// dependency on it (single-GPU users never touch it) --------------------------
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  std::string error;
+};
+RcclApi g_rccl;
+
+bool load_rccl() {
+  if (g_rccl.lib) return true;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"};
+  for (const char* n : names) {
+    g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (g_rccl.lib) break;
+  }
+  if (!g_rccl.lib) {
+    g_rccl.error = std::string("cannot dlopen librccl: ") + dlerror();
+    return false;
+  }
+#define CRBM_SYM(field, name)                                                    \
+  g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(g_rccl.lib, name)); \
+  if (!g_rccl.field) {                                                           \
+    g_rccl.error = std::string("librccl lacks ") + name;                         \
+    dlclose(g_rccl.lib);                                                         \
+    g_rccl.lib = nullptr;                                                        \
+    return false;                                                                \
+  }
+  CRBM_SYM(GetUniqueId, "ncclGetUniqueId")
+  CRBM_SYM(CommInitRank, "ncclCommInitRank")
+  CRBM_SYM(CommDestroy, "ncclCommDestroy")
+  CRBM_SYM(AllReduce, "ncclAllReduce")
+  CRBM_SYM(GetErrorString, "ncclGetErrorString")
+#undef CRBM_SYM
+  return true;
+}
+
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t cap = 0;   // elements
+  hipError_t ensure(size_t n) {
+    if (n <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = n + n / 8 + 64;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), want * sizeof(T));
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+}  // namespace
+
+struct crbm_handle {
+  crbm_config cfg;
+  int K = 0, M = 0, ds = 0, NQ = 0, NW = 0, G = 0, KP = 0, KAM = 0;
+  int Lf = 0, Lv = 0, B = 0;
+  int device = 0, num_cu = 256;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  const KernelTable* kt = nullptr;
+  // parameters and optimiser state
+  float *dW = nullptr, *db = nullptr, *dc = nullptr, *dvW = nullptr, *dvb = nullptr, *dvc = nullptr;
+  // persistent chains: K-bit masks per hidden position, letters of the last visible sample
+  uint32_t *d_hm = nullptr, *d_hmp = nullptr, *d_vf = nullptr;
+  uint32_t* d_flags = nullptr;
+  unsigned long long* d_ones = nullptr;
+  DevBuf<float> stage, stage2, out_a, out_b, out_c;
+  DevBuf<uint32_t> letters, dataset, masks_tmp;
+  DevBuf<float> partials;
+  float* d_sums = nullptr;
+  int dataset_n = 0, dataset_L = 0;
+  // sampler
+  uint64_t seed = 0;
+  uint32_t gibbs_step = 0, eval_step = 0, chain_offset = 0;
+  // launch geometry
+  GibbsLayout gl;
+  int gibbs_threads = 256, gibbs_grid = 0;
+  int stats_threads = 256, stats_rows = 0;
+  SumsLayout sl;
+  // data parallel
+  ncclComm_t comm = nullptr;
+  int nranks = 1, rank = 0;
+  std::string err;
+};
+
+namespace {
+
+int fail(crbm_handle* h, int code, const std::string& msg) {
+  if (h) h->err = msg; else g_create_error = msg;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                         \
+  do {                                                                                       \
+    hipError_t e__ = (expr);                                                                 \
+    if (e__ != hipSuccess)                                                                   \
+      return fail(h, CRBM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));      \
+  } while (0)
+
+#define ARGCHK(cond, msg)                                 \
+  do {                                                    \
+    if (!(cond)) return fail(h, CRBM_ERR_INVALID, msg);   \
+  } while (0)
+
+ModelView model_view(const crbm_handle* h) {
+  ModelView mv;
+  mv.W = h->dW; mv.b = h->db; mv.c = h->dc;
+  mv.K = h->K; mv.M = h->M; mv.G = h->G;
+  mv.ngroups = (h->M + h->G - 1) / h->G;
+  mv.rows = pow4(h->G);
+  mv.ds = h->ds;
+  return mv;
+}
+
+RngView rng_view(const crbm_handle* h, uint32_t step, uint32_t seq_offset) {
+  RngView r;
+  r.seed_lo = (uint32_t)(h->seed & 0xffffffffu);
+  r.seed_hi = (uint32_t)(h->seed >> 32);
+  r.step = step;
+  r.seq_offset = seq_offset;
+  return r;
+}
+
+int tab_bytes(const crbm_handle* h) { return gather_table_floats(h->M, h->G, h->KP) * 4; }
+
+int grid_for(long items, int threads, int cap) {
+  long g = (items + threads - 1) / threads;
+  return (int)std::max<long>(1, std::min<long>(g, cap));
+}
+
+// sequences per tile so that a tile has ~target items and ts*len*mult < 2^20
+int tile_seqs(int len, int target) { return std::max(1, std::min(target / std::max(1, len), (1 << 20) / std::max(1, len))); }
+
+int check_flags(crbm_handle* h) {
+  uint32_t flags = 0;
+  HIPCHK(hipMemcpyAsync(&flags, h->d_flags, sizeof(flags), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (flags) {
+    HIPCHK(hipMemsetAsync(h->d_flags, 0, sizeof(uint32_t), h->stream));
+    if (flags & 1u) return fail(h, CRBM_ERR_NOT_ONEHOT, "visible data is not exactly one-hot");
+    return fail(h, CRBM_ERR_NOT_BINARY, "hidden state is not exactly 0/1");
+  }
+  return CRBM_OK;
+}
+
+// host one-hot (n,1,4,L) -> packed letters on the device
+int encode_host(crbm_handle* h, const float* v, int n, int L, uint32_t* d_letters) {
+  const size_t count = (size_t)n * 4 * L;
+  HIPCHK(h->stage.ensure(count));
+  HIPCHK(hipMemcpyAsync(h->stage.p, v, count * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  EncodeArgs a;
+  a.v = h->stage.p; a.letters = d_letters; a.flags = h->d_flags;
+  a.n = n; a.L = L; a.LW = letter_words(L);
+  const int grid = grid_for((long)n * a.LW, 256, h->num_cu * 8);
+  hipLaunchKernelGGL(encode_onehot_kernel, dim3(grid), dim3(256), 0, h->stream, a);
+  HIPCHK(hipGetLastError());
+  return check_flags(h);
+}
+
+int launch_hgv(crbm_handle* h, const uint32_t* d_letters, int n, int L, int mode, float* act, float* prob,
+               float* sample, unsigned long long* ones, uint32_t kind, uint32_t step, uint32_t seq_offset) {
+  HgvArgs a;
+  a.mv = model_view(h);
+  a.letters = d_letters;
+  a.n = n; a.L = L; a.Lh = L - h->M + 1; a.LW = letter_words(L);
+  a.TS = tile_seqs(a.Lh, 4096);
+  a.divLh = make_fastdiv((uint32_t)a.Lh);
+  a.mode = mode;
+  a.act = act; a.prob = prob; a.sample = sample; a.ones = ones;
+  a.rng = rng_view(h, step, seq_offset);
+  a.kind = kind;
+  LaunchCfg c;
+  const int ntiles = (n + a.TS - 1) / a.TS;
+  c.gx = (uint32_t)std::max(1, std::min(ntiles, h->num_cu * 8));
+  c.gy = 1; c.block = 256;
+  c.lds = (uint32_t)((mode == 2 ? 2 : 1) * tab_bytes(h));
+  c.stream = h->stream;
+  h->kt->hgv(a, c);
+  HIPCHK(hipGetLastError());
+  return CRBM_OK;
+}
+
+int launch_gibbs(crbm_handle* h, int steps) {
+  GibbsArgs a;
+  a.mv = model_view(h);
+  a.hm = h->d_hm; a.hmp = h->ds ? h->d_hmp : nullptr; a.vout = h->d_vf;
+  a.nchains = h->B; a.Lf = h->Lf; a.Lv = h->gl.Lv; a.Lhp = h->gl.Lhp; a.LWs = h->gl.LWs; a.S = h->gl.S;
+  a.divLv = make_fastdiv((uint32_t)a.Lv);
+  a.divLf = make_fastdiv((uint32_t)a.Lf);
+  a.divRow = make_fastdiv((uint32_t)(a.Lhp * h->gl.NW));
+  a.steps = steps;
+  a.rng = rng_view(h, h->gibbs_step, h->chain_offset);
+  LaunchCfg c;
+  c.gx = (uint32_t)h->gibbs_grid; c.gy = 1; c.block = (uint32_t)h->gibbs_threads;
+  c.lds = (uint32_t)h->gl.lds_bytes; c.stream = h->stream;
+  h->kt->gibbs(a, c);
+  HIPCHK(hipGetLastError());
+  h->gibbs_step += (uint32_t)steps;
+  return CRBM_OK;
+}
+
+// raw statistic sums of (letters, n, L) -> sums half (data or model)
+int launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool data_half) {
+  const int want_sp = data_half ? 1 : 0;
+  const StatsLayout st = stats_layout(h->K, h->M, h->ds, h->NQ, h->G, want_sp, h->stats_threads);
+  StatsArgs a;
+  a.mv = model_view(h);
+  a.letters = d_letters;
+  a.n = n; a.L = L; a.Lh = L - h->M + 1; a.LW = letter_words(L);
+  a.TS = tile_seqs(std::max(a.Lh, L), 8192);
+  a.divLh = make_fastdiv((uint32_t)a.Lh);
+  a.divL = make_fastdiv((uint32_t)L);
+  a.want_sparsity = want_sp;
+  a.ntk = st.ntk; a.ntj = st.ntj; a.ntiles = st.ntiles;
+  a.row = st.row;
+  a.off_vh0 = st.off_vh[0]; a.off_vh1 = st.off_vh[1]; a.off_h0 = st.off_h[0]; a.off_h1 = st.off_h[1];
+  a.off_sw = st.off_sw; a.off_sb = st.off_sb; a.off_v = st.off_v;
+  const int nseqtiles = (n + a.TS - 1) / a.TS;
+  const int rows = std::max(1, std::min(nseqtiles, h->stats_rows));
+  HIPCHK(h->partials.ensure((size_t)rows * st.row));
+  a.partials = h->partials.p;
+  HIPCHK(hipMemsetAsync(h->partials.p, 0, (size_t)rows * st.row * sizeof(float), h->stream));
+  LaunchCfg c;
+  c.gx = (uint32_t)rows; c.gy = (uint32_t)st.grid_y; c.block = (uint32_t)h->stats_threads;
+  c.lds = (uint32_t)st.lds_bytes; c.stream = h->stream;
+  h->kt->stats(a, c);
+  HIPCHK(hipGetLastError());
+  ReduceArgs r;
+  r.partials = h->partials.p;
+  r.nrows = rows; r.row = st.row;
+  if (data_half) {
+    r.sums = h->d_sums + h->sl.data_off;
+    r.skip_begin = st.row; r.skip_len = 0;
+  } else {
+    r.sums = h->d_sums + h->sl.model_off;
+    r.skip_begin = h->sl.model_skip_begin; r.skip_len = h->sl.model_skip_len;
+  }
+  r.n_value = (float)n;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((st.row + 255) / 256), dim3(256), 0, h->stream, r);
+  HIPCHK(hipGetLastError());
+  return CRBM_OK;
+}
+
+int launch_update(crbm_handle* h, int L_data) {
+  UpdateArgs u;
+  u.sums = h->d_sums;
+  u.W = h->dW; u.b = h->db; u.c = h->dc; u.vW = h->dvW; u.vb = h->dvb; u.vc = h->dvc;
+  u.K = h->K; u.M = h->M; u.ds = h->ds;
+  u.L_data = L_data; u.Lf = h->Lf;
+  u.data_off = h->sl.data_off; u.n_d = h->sl.n_d; u.model_off = h->sl.model_off; u.n_m = h->sl.n_m;
+  u.lr = h->cfg.learning_rate; u.momentum = h->cfg.momentum; u.rho = h->cfg.rho; u.lambda_rate = h->cfg.lambda_rate;
+  hipLaunchKernelGGL(apply_update_kernel, dim3(1), dim3(256), 0, h->stream, u);
+  HIPCHK(hipGetLastError());
+  return CRBM_OK;
+}
+
+// data statistics + k Gibbs steps + model statistics -> d_sums (local)
+int train_local_dev(crbm_handle* h, const uint32_t* d_letters, int n, int L) {
+  int rc = CRBM_OK;
+  if (n > 0) {
+    rc = launch_stats(h, d_letters, n, L, true);
+  } else {   // a rank may own no rows of a short last mini-batch: contribute zeros
+    HIPCHK(hipMemsetAsync(h->d_sums + h->sl.data_off, 0, (size_t)(h->sl.n_d + 1 - h->sl.data_off) * sizeof(float), h->stream));
+  }
+  if (rc) return rc;
+  rc = launch_gibbs(h, h->cfg.cd_k);
+  if (rc) return rc;
+  return launch_stats(h, h->d_vf, h->B, h->Lv, false);
+}
+
+int train_core(crbm_handle* h, const uint32_t* d_letters, int n, int L) {
+  int rc = train_local_dev(h, d_letters, n, L);
+  if (rc) return rc;
+  if (h->comm) {
+    ncclResult_t r = g_rccl.AllReduce(h->d_sums, h->d_sums, (size_t)h->sl.count, ncclFloat, ncclSum, h->comm, h->stream);
+    if (r != ncclSuccess) return fail(h, CRBM_ERR_RCCL, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r));
+  }
+  return launch_update(h, L);
+}
+
+int check_data_shape(crbm_handle* h, int n, int L) {
+  ARGCHK(n >= 1, "n must be positive");
+  ARGCHK(L >= h->M, "sequence length must be >= motif_length");
+  ARGCHK((long)L * 4 < (1 << 20), "sequence too long");
+  return CRBM_OK;
+}
+
+int copy_out(crbm_handle* h, float* host, const float* dev, size_t count) {
+  HIPCHK(hipMemcpyAsync(host, dev, count * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  return CRBM_OK;
+}
+
+}  // namespace
+
+// =============================================================================
+extern "C" {
+
+int crbm_abi_version(void) { return CRBM_AMD_ABI_VERSION; }
+
+int crbm_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char* crbm_last_error(const crbm_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int crbm_create(const crbm_config* cfg, crbm_handle** out) {
+  crbm_handle* h = nullptr;   // fail() routes to the create-error slot
+  if (!cfg || !out) return fail(h, CRBM_ERR_INVALID, "null argument");
+  *out = nullptr;
+  ARGCHK(cfg->num_motifs >= 1, "Number of motifs must be positive.");
+  ARGCHK(cfg->num_motifs <= 64, "num_motifs > 64 is not supported by the HIP kernels");
+  ARGCHK(cfg->motif_length >= 1, "Motif length must be positive.");
+  ARGCHK(cfg->motif_length <= 32, "motif_length > 32 is not supported by the HIP kernels");
+  ARGCHK(cfg->input_dims == 4, "the HIP kernels require input_dims == 4 (DNA one-hot)");
+  ARGCHK(cfg->pooling == 1, "the HIP kernels require pooling == 1");
+  ARGCHK(cfg->batchsize >= 1, "batchsize must be positive.");
+  ARGCHK(cfg->cd_k >= 1, "cd_k must be positive.");
+  ARGCHK(cfg->fantasy_hidden_len >= 1 && cfg->fantasy_hidden_len <= 65536, "fantasy_hidden_len out of range");
+  ARGCHK(cfg->rho > 0.f && cfg->rho < 1.f, "rho must be in (0,1)");
+  ARGCHK(cfg->learning_rate > 0.f, "learning_rate must be positive.");
+  ARGCHK(cfg->momentum >= 0.f && cfg->momentum < 1.f, "momentum must be between zero and one.");
+  ARGCHK(cfg->lambda_rate >= 0.f, "lambda_rate must be non-negative.");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(h, CRBM_ERR_NO_GPU, "no HIP device visible (this library has no CPU path)");
+  ARGCHK(cfg->device >= 0 && cfg->device < ndev, "device ordinal out of range");
+
+  crbm_handle* hh = new crbm_handle();
+  hh->cfg = *cfg;
+  hh->K = cfg->num_motifs; hh->M = cfg->motif_length; hh->ds = cfg->doublestranded ? 1 : 0;
+  hh->NQ = instantiated_nq(nq_for(hh->K));
+  hh->KP = 4 * hh->NQ;
+  hh->NW = mask_words_for_nq(hh->NQ);
+  hh->KAM = hh->K * 4 * hh->M;
+  hh->Lf = cfg->fantasy_hidden_len; hh->Lv = hh->Lf + hh->M - 1; hh->B = cfg->batchsize;
+  hh->seed = cfg->seed;
+  hh->device = cfg->device;
+  hh->kt = kernel_table(hh->NQ);
+  hh->sl = sums_layout(hh->K, hh->M);
+  auto bail = [&](int code) { crbm_destroy(hh); return code; };
+  if (!hh->kt) { g_create_error = "no kernel specialisation"; delete hh; return CRBM_ERR_INVALID; }
+  hipError_t e;
+#define TRY(expr)                                                                                 \
+  if ((e = (expr)) != hipSuccess) {                                                               \
+    g_create_error = std::string(#expr) + ": " + hipGetErrorString(e);                            \
+    return bail(CRBM_ERR_HIP);                                                                    \
+  }
+  TRY(hipSetDevice(hh->device));
+  hipDeviceProp_t prop;
+  TRY(hipGetDeviceProperties(&prop, hh->device));
+  hh->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  TRY(hipStreamCreateWithFlags(&hh->stream, hipStreamNonBlocking));
+  TRY(hipEventCreate(&hh->ev0));
+  TRY(hipEventCreate(&hh->ev1));
+  const size_t kam = (size_t)hh->KAM, k = (size_t)hh->K;
+  TRY(hipMalloc((void**)&hh->dW, kam * 4)); TRY(hipMalloc((void**)&hh->dvW, kam * 4));
+  TRY(hipMalloc((void**)&hh->db, k * 4));   TRY(hipMalloc((void**)&hh->dvb, k * 4));
+  TRY(hipMalloc((void**)&hh->dc, 16));      TRY(hipMalloc((void**)&hh->dvc, 16));
+  TRY(hipMemset(hh->dW, 0, kam * 4)); TRY(hipMemset(hh->dvW, 0, kam * 4));
+  TRY(hipMemset(hh->db, 0, k * 4));   TRY(hipMemset(hh->dvb, 0, k * 4));
+  TRY(hipMemset(hh->dc, 0, 16));      TRY(hipMemset(hh->dvc, 0, 16));
+  const size_t mwords = (size_t)hh->B * hh->Lf * hh->NW;
+  TRY(hipMalloc((void**)&hh->d_hm, mwords * 4)); TRY(hipMemset(hh->d_hm, 0, mwords * 4));
+  TRY(hipMalloc((void**)&hh->d_hmp, mwords * 4)); TRY(hipMemset(hh->d_hmp, 0, mwords * 4));
+  const size_t vwords = (size_t)hh->B * letter_words(hh->Lv);
+  TRY(hipMalloc((void**)&hh->d_vf, vwords * 4)); TRY(hipMemset(hh->d_vf, 0, vwords * 4));
+  TRY(hipMalloc((void**)&hh->d_flags, 16)); TRY(hipMemset(hh->d_flags, 0, 16));
+  TRY(hipMalloc((void**)&hh->d_ones, 16)); TRY(hipMemset(hh->d_ones, 0, 16));
+  TRY(hipMalloc((void**)&hh->d_sums, (size_t)hh->sl.count * 4)); TRY(hipMemset(hh->d_sums, 0, (size_t)hh->sl.count * 4));
+#undef TRY
+  // gather-table group size
+  const int budget = env_int("CRBM_TABLE_BUDGET", 40 * 1024);
+  hh->G = env_int("CRBM_GROUP", 0);
+  if (hh->G < 1 || hh->G > 4) hh->G = choose_group(hh->M, hh->KP, hh->ds, budget);
+  // Gibbs launch geometry: chains per tile so that a tile keeps the block busy
+  // for several passes while several blocks still fit one CU's 160 KB LDS
+  hh->gibbs_threads = env_int("CRBM_GIBBS_THREADS", 256);
+  int S = env_int("CRBM_GIBBS_S", 0);
+  if (S < 1) {
+    S = std::max(1, std::min(16, (4 * hh->gibbs_threads) / hh->Lv));
+    while (S > 1 && gibbs_layout(hh->K, hh->M, hh->ds, hh->NQ, hh->G, hh->Lf, S).lds_bytes > 64 * 1024) --S;
+  }
+  S = std::min(S, hh->B);
+  hh->gl = gibbs_layout(hh->K, hh->M, hh->ds, hh->NQ, hh->G, hh->Lf, S);
+  if (hh->gl.lds_bytes > 160 * 1024 || (long)S * hh->gl.Lhp * hh->gl.NW >= (1 << 20)) {
+    g_create_error = "model too large for the LDS-resident Gibbs kernel";
+    crbm_destroy(hh);
+    return CRBM_ERR_INVALID;
+  }
+  const int ntiles = (hh->B + S - 1) / S;
+  const int per_cu = std::max(1, std::min(8, (160 * 1024) / std::max(1, hh->gl.lds_bytes)));
+  hh->gibbs_grid = env_int("CRBM_GIBBS_GRID", 0);
+  if (hh->gibbs_grid < 1) hh->gibbs_grid = std::min(ntiles, hh->num_cu * per_cu);
+  hh->stats_threads = 256;
+  hh->stats_rows = env_int("CRBM_STATS_ROWS", 2 * hh->num_cu);
+  *out = hh;
+  return CRBM_OK;
+}
+
+int crbm_destroy(crbm_handle* h) {
+  if (!h) return CRBM_OK;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+  void* ptrs[] = {h->dW, h->db, h->dc, h->dvW, h->dvb, h->dvc, h->d_hm, h->d_hmp, h->d_vf, h->d_flags, h->d_ones, h->d_sums};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  h->stage.release(); h->stage2.release(); h->out_a.release(); h->out_b.release(); h->out_c.release();
+  h->letters.release(); h->dataset.release(); h->masks_tmp.release(); h->partials.release();
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return CRBM_OK;
+}
+
+#define ENTER()                                               \
+  if (!h) return CRBM_ERR_INVALID;                            \
+  h->err.clear();                                             \
+  HIPCHK(hipSetDevice(h->device))
+
+int crbm_set_params(crbm_handle* h, const float* W, const float* b, const float* c) {
+  ENTER();
+  ARGCHK(W && b && c, "null argument");
+  HIPCHK(hipMemcpyAsync(h->dW, W, (size_t)h->KAM * 4, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->db, b, (size_t)h->K * 4, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->dc, c, 16, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return CRBM_OK;
+}
+
+int crbm_get_params(crbm_handle* h, float* W, float* b, float* c) {
+  ENTER();
+  ARGCHK(W && b && c, "null argument");
+  HIPCHK(hipMemcpyAsync(W, h->dW, (size_t)h->KAM * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(b, h->db, (size_t)h->K * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(c, h->dc, 16, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return CRBM_OK;
+}
+
+int crbm_set_velocities(crbm_handle* h, const float* vW, const float* vb, const float* vc) {
+  ENTER();
+  ARGCHK(vW && vb && vc, "null argument");
+  HIPCHK(hipMemcpyAsync(h->dvW, vW, (size_t)h->KAM * 4, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->dvb, vb, (size_t)h->K * 4, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->dvc, vc, 16, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return CRBM_OK;
+}
+
+int crbm_get_velocities(crbm_handle* h, float* vW, float* vb, float* vc) {
+  ENTER();
+  ARGCHK(vW && vb && vc, "null argument");
+  HIPCHK(hipMemcpyAsync(vW, h->dvW, (size_t)h->KAM * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(vb, h->dvb, (size_t)h->K * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(vc, h->dvc, 16, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return CRBM_OK;
+}
+
+int crbm_set_fantasy(crbm_handle* h, const float* hid, const float* hid_prime) {
+  ENTER();
+  ARGCHK(hid, "null argument");
+  ARGCHK(!h->ds || hid_prime, "doublestranded model needs hid_prime");
+  const size_t count = (size_t)h->B * h->K * h->Lf;
+  HIPCHK(h->stage.ensure(count));
+  const float* src[2] = {hid, hid_prime};
+  uint32_t* dst[2] = {h->d_hm, h->d_hmp};
+  for (int sidx = 0; sidx < 1 + h->ds; ++sidx) {
+    HIPCHK(hipMemcpyAsync(h->stage.p, src[sidx], count * 4, hipMemcpyHostToDevice, h->stream));
+    HiddenPackArgs a;
+    a.dense = h->stage.p; a.masks = dst[sidx]; a.flags = h->d_flags;
+    a.n = h->B; a.K = h->K; a.Lh = h->Lf; a.NW = h->NW;
+    hipLaunchKernelGGL(pack_hidden_kernel, dim3(grid_for((long)h->B * h->Lf, 256, h->num_cu * 8)), dim3(256), 0, h->stream, a);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));   // staging buffer is reused
+  }
+  return check_flags(h);
+}
+
+int crbm_get_fantasy(crbm_handle* h, float* hid, float* hid_prime) {
+  ENTER();
+  ARGCHK(hid, "null argument");
+  const size_t count = (size_t)h->B * h->K * h->Lf;
+  HIPCHK(h->stage.ensure(count));
+  float* dsth[2] = {hid, hid_prime};
+  uint32_t* src[2] = {h->d_hm, h->d_hmp};
+  for (int sidx = 0; sidx < 1 + h->ds; ++sidx) {
+    if (!dsth[sidx]) continue;
+    HiddenPackArgs a;
+    a.dense = h->stage.p; a.masks = src[sidx]; a.flags = h->d_flags;
+    a.n = h->B; a.K = h->K; a.Lh = h->Lf; a.NW = h->NW;
+    hipLaunchKernelGGL(unpack_hidden_kernel, dim3(grid_for((long)h->B * h->Lf, 256, h->num_cu * 8)), dim3(256), 0, h->stream, a);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(dsth[sidx], h->stage.p, count * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  return CRBM_OK;
+}
+
+int crbm_get_fantasy_visible(crbm_handle* h, float* v) {
+  ENTER();
+  ARGCHK(v, "null argument");
+  const size_t count = (size_t)h->B * 4 * h->Lv;
+  HIPCHK(h->stage.ensure(count));
+  DecodeArgs a;
+  a.letters = h->d_vf; a.v = h->stage.p; a.n = h->B; a.L = h->Lv; a.LW = letter_words(h->Lv);
+  hipLaunchKernelGGL(decode_onehot_kernel, dim3(grid_for((long)h->B * h->Lv, 256, h->num_cu * 8)), dim3(256), 0, h->stream, a);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(v, h->stage.p, count * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return CRBM_OK;
+}
+
+int crbm_set_rng(crbm_handle* h, uint64_t seed, uint32_t gibbs_step, uint32_t eval_step) {
+  if (!h) return CRBM_ERR_INVALID;
+  h->seed = seed; h->gibbs_step = gibbs_step; h->eval_step = eval_step;
+  return CRBM_OK;
+}
+
+int crbm_get_rng(crbm_handle* h, uint64_t* seed, uint32_t* gibbs_step, uint32_t* eval_step) {
+  if (!h) return CRBM_ERR_INVALID;
+  if (seed) *seed = h->seed;
+  if (gibbs_step) *gibbs_step = h->gibbs_step;
+  if (eval_step) *eval_step = h->eval_step;
+  return CRBM_OK;
+}
+
+int crbm_set_shard(crbm_handle* h, uint32_t chain_offset) {
+  if (!h) return CRBM_ERR_INVALID;
+  h->chain_offset = chain_offset;
+  return CRBM_OK;
+}
+
+// ---- training ----------------------------------------------------------------
+int crbm_train_step(crbm_handle* h, const float* D, int32_t n, int32_t L) {
+  ENTER();
+  ARGCHK(D, "null argument");
+  int rc = check_data_shape(h, n, L);
+  if (rc) return rc;
+  HIPCHK(h->letters.ensure((size_t)n * letter_words(L)));
+  rc = encode_host(h, D, n, L, h->letters.p);
+  if (rc) return rc;
+  rc = train_core(h, h->letters.p, n, L);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return CRBM_OK;
+}
+
+int crbm_dataset_upload(crbm_handle* h, const float* data, int32_t n, int32_t L) {
+  ENTER();
+  ARGCHK(data, "null argument");
+  int rc = check_data_shape(h, n, L);
+  if (rc) return rc;
+  const int LW = letter_words(L);
+  HIPCHK(h->dataset.ensure((size_t)n * LW));
+  // stream the fp32 array through the staging buffer in slabs of <= 64 MiB
+  const int slab = std::max(1, (int)std::min<long>(n, (64L << 20) / ((long)4 * L * 4)));
+  for (int start = 0; start < n; start += slab) {
+    const int cnt = std::min(slab, n - start);
+    rc = encode_host(h, data + (size_t)start * 4 * L, cnt, L, h->dataset.p + (size_t)start * LW);
+    if (rc) return rc;
+  }
+  h->dataset_n = n; h->dataset_L = L;
+  return CRBM_OK;
+}
+
+int crbm_train_step_resident(crbm_handle* h, int32_t start, int32_t end) {
+  ENTER();
+  ARGCHK(h->dataset_n > 0, "no resident data set (call crbm_dataset_upload)");
+  ARGCHK(start >= 0 && end >= start && end <= h->dataset_n, "row range out of bounds");
+  ARGCHK(end > start || h->comm, "empty row range");
+  const int LW = letter_words(h->dataset_L);
+  int rc = train_core(h, h->dataset.p + (size_t)start * LW, end - start, h->dataset_L);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return CRBM_OK;
+}
+
+int crbm_gibbs_steps_async(crbm_handle* h, int32_t k) {
+  ENTER();
+  ARGCHK(k >= 1, "k must be positive");
+  return launch_gibbs(h, k);
+}
+
+int crbm_sync(crbm_handle* h) {
+  ENTER();
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return CRBM_OK;
+}
+
+int crbm_gibbs_steps(crbm_handle* h, int32_t k) {
+  int rc = crbm_gibbs_steps_async(h, k);
+  if (rc) return rc;
+  return crbm_sync(h);
+}
+
+int crbm_time_gibbs(crbm_handle* h, int32_t k, int32_t launches, float* total_ms) {
+  ENTER();
+  ARGCHK(k >= 1 && launches >= 1 && total_ms, "bad argument");
+  HIPCHK(hipEventRecord(h->ev0, h->stream));
+  for (int i = 0; i < launches; ++i) {
+    int rc = launch_gibbs(h, k);
+    if (rc) return rc;
+  }
+  HIPCHK(hipEventRecord(h->ev1, h->stream));
+  HIPCHK(hipEventSynchronize(h->ev1));
+  HIPCHK(hipEventElapsedTime(total_ms, h->ev0, h->ev1));
+  return CRBM_OK;
+}
+
+int crbm_time_train(crbm_handle* h, int32_t start, int32_t end, int32_t launches, float* total_ms) {
+  ENTER();
+  ARGCHK(h->dataset_n > 0, "no resident data set (call crbm_dataset_upload)");
+  ARGCHK(start >= 0 && end > start && end <= h->dataset_n && launches >= 1 && total_ms, "bad argument");
+  const int LW = letter_words(h->dataset_L);
+  HIPCHK(hipEventRecord(h->ev0, h->stream));
+  for (int i = 0; i < launches; ++i) {
+    int rc = train_core(h, h->dataset.p + (size_t)start * LW, end - start, h->dataset_L);
+    if (rc) return rc;
+  }
+  HIPCHK(hipEventRecord(h->ev1, h->stream));
+  HIPCHK(hipEventSynchronize(h->ev1));
+  HIPCHK(hipEventElapsedTime(total_ms, h->ev0, h->ev1));
+  return CRBM_OK;
+}
+
+// ---- stand-alone passes ------------------------------------------------------
+int crbm_h_given_v(crbm_handle* h, const float* v, int32_t n, int32_t L, int32_t flip, uint32_t rng_step,
+                   float* act, float* prob, float* sample) {
+  ENTER();
+  ARGCHK(v, "null argument");
+  int rc = check_data_shape(h, n, L);
+  if (rc) return rc;
+  const int Lh = L - h->M + 1;
+  const size_t count = (size_t)n * h->K * Lh;
+  HIPCHK(h->letters.ensure((size_t)n * letter_words(L)));
+  rc = encode_host(h, v, n, L, h->letters.p);
+  if (rc) return rc;
+  if (act) HIPCHK(h->out_a.ensure(count));
+  if (prob) HIPCHK(h->out_b.ensure(count));
+  if (sample) HIPCHK(h->out_c.ensure(count));
+  rc = launch_hgv(h, h->letters.p, n, L, flip ? 1 : 0, act ? h->out_a.p : nullptr, prob ? h->out_b.p : nullptr,
+                  sample ? h->out_c.p : nullptr, nullptr, KIND_API_H, rng_step, h->chain_offset);
+  if (rc) return rc;
+  if (act && (rc = copy_out(h, act, h->out_a.p, count))) return rc;
+  if (prob && (rc = copy_out(h, prob, h->out_b.p, count))) return rc;
+  if (sample && (rc = copy_out(h, sample, h->out_c.p, count))) return rc;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return CRBM_OK;
+}
+
+int crbm_v_given_h(crbm_handle* h, const float* hid, const float* hid_prime, int32_t n, int32_t Lh,
+                   uint32_t rng_step, float* act, float* prob, float* sample) {
+  ENTER();
+  ARGCHK(hid, "null argument");
+  ARGCHK(n >= 1 && Lh >= 1, "bad shape");
+  const int L = Lh + h->M - 1;
+  ARGCHK((long)L * 4 < (1 << 20), "sequence too long");
+  const size_t hcount = (size_t)n * h->K * Lh, vcount = (size_t)n * 4 * L;
+  HIPCHK(h->stage.ensure(hcount));
+  HIPCHK(hipMemcpyAsync(h->stage.p, hid, hcount * 4, hipMemcpyHostToDevice, h->stream));
+  if (hid_prime) {
+    HIPCHK(h->stage2.ensure(hcount));
+    HIPCHK(hipMemcpyAsync(h->stage2.p, hid_prime, hcount * 4, hipMemcpyHostToDevice, h->stream));
+  }
+  if (act) HIPCHK(h->out_a.ensure(vcount));
+  if (prob) HIPCHK(h->out_b.ensure(vcount));
+  if (sample) HIPCHK(h->out_c.ensure(vcount));
+  VghArgs a;
+  a.mv = model_view(h);
+  a.hid = h->stage.p; a.hidp = hid_prime ? h->stage2.p : nullptr;
+  a.n = n; a.Lh = Lh; a.L = L;
+  a.TS = tile_seqs(L, 4096);
+  a.divL = make_fastdiv((uint32_t)L);
+  a.act = act ? h->out_a.p : nullptr; a.prob = prob ? h->out_b.p : nullptr; a.sample = sample ? h->out_c.p : nullptr;
+  a.rng = rng_view(h, rng_step, h->chain_offset);
+  a.kind = KIND_API_V;
+  const int ntiles = (n + a.TS - 1) / a.TS;
+  hipLaunchKernelGGL(vgh_dense_kernel, dim3(std::max(1, std::min(ntiles, h->num_cu * 8))), dim3(256),
+                     (size_t)h->M * h->K * 16, h->stream, a);
+  HIPCHK(hipGetLastError());
+  int rc;
+  if (act && (rc = copy_out(h, act, h->out_a.p, vcount))) return rc;
+  if (prob && (rc = copy_out(h, prob, h->out_b.p, vcount))) return rc;
+  if (sample && (rc = copy_out(h, sample, h->out_c.p, vcount))) return rc;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return CRBM_OK;
+}
+
+// ---- evaluation --------------------------------------------------------------
+int crbm_hit_probs(crbm_handle* h, const float* v, int32_t n, int32_t L, float* out) {
+  ENTER();
+  ARGCHK(v && out, "null argument");
+  int rc = check_data_shape(h, n, L);
+  if (rc) return rc;
+  const size_t count = (size_t)n * h->K * (L - h->M + 1);
+  HIPCHK(h->letters.ensure((size_t)n * letter_words(L)));
+  rc = encode_host(h, v, n, L, h->letters.p);
+  if (rc) return rc;
+  HIPCHK(h->out_b.ensure(count));
+  // convRBM.py:507-514: doublestranded -> sigma(x); single-stranded -> sigma(x + x')
+  rc = launch_hgv(h, h->letters.p, n, L, h->ds ? 0 : 2, nullptr, h->out_b.p, nullptr, nullptr, KIND_API_H, 0, 0);
+  if (rc) return rc;
+  rc = copy_out(h, out, h->out_b.p, count);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return CRBM_OK;
+}
+
+static int free_energy_common(crbm_handle* h, const float* v, int n, int L, float* fe, float* fem) {
+  int rc = check_data_shape(h, n, L);
+  if (rc) return rc;
+  HIPCHK(h->letters.ensure((size_t)n * letter_words(L)));
+  rc = encode_host(h, v, n, L, h->letters.p);
+  if (rc) return rc;
+  HIPCHK(h->out_a.ensure((size_t)n));
+  HIPCHK(h->out_b.ensure((size_t)n * h->K));
+  FeArgs a;
+  a.mv = model_view(h);
+  a.letters = h->letters.p;
+  a.n = n; a.L = L; a.Lh = L - h->M + 1; a.LW = letter_words(L);
+  a.fe = h->out_a.p; a.fem = h->out_b.p;
+  LaunchCfg c;
+  c.block = 256;
+  c.gx = (uint32_t)std::max(1, std::min((n + 3) / 4, h->num_cu * 8));
+  c.gy = 1;
+  c.lds = (uint32_t)((1 + h->ds) * tab_bytes(h));
+  c.stream = h->stream;
+  h->kt->free_energy(a, c);
+  HIPCHK(hipGetLastError());
+  if (fe && (rc = copy_out(h, fe, h->out_a.p, (size_t)n))) return rc;
+  if (fem && (rc = copy_out(h, fem, h->out_b.p, (size_t)n * h->K))) return rc;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return CRBM_OK;
+}
+
+int crbm_free_energy(crbm_handle* h, const float* v, int32_t n, int32_t L, float* out) {
+  ENTER();
+  ARGCHK(v && out, "null argument");
+  return free_energy_common(h, v, n, L, out, nullptr);
+}
+
+int crbm_free_energy_per_motif(crbm_handle* h, const float* v, int32_t n, int32_t L, float* out) {
+  ENTER();
+  ARGCHK(v && out, "null argument");
+  return free_energy_common(h, v, n, L, nullptr, out);
+}
+
+int crbm_eval_data(crbm_handle* h, const float* v, int32_t n, int32_t L, float* mfe, float* nmh) {
+  ENTER();
+  ARGCHK(v && mfe && nmh, "null argument");
+  std::vector<float> fe((size_t)std::max(n, 1));
+  int rc = free_energy_common(h, v, n, L, fe.data(), nullptr);
+  if (rc) return rc;
+  double tot = 0.0;
+  for (int i = 0; i < n; ++i) tot += fe[i];
+  *mfe = (float)(tot / n);                       // convRBM.py:636-638
+  // mean of a fresh forward-strand sample (convRBM.py:469-472); letters are still resident
+  HIPCHK(hipMemsetAsync(h->d_ones, 0, sizeof(unsigned long long), h->stream));
+  rc = launch_hgv(h, h->letters.p, n, L, 0, nullptr, nullptr, nullptr, h->d_ones, KIND_EVAL_H, h->eval_step, 0);
+  if (rc) return rc;
+  h->eval_step += 1;
+  unsigned long long ones = 0;
+  HIPCHK(hipMemcpyAsync(&ones, h->d_ones, sizeof(ones), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  *nmh = (float)((double)ones / ((double)n * h->K * (L - h->M + 1)));
+  return CRBM_OK;
+}
+
+int crbm_eval_params(crbm_handle* h, float* twn, float* ic, float* medic) {
+  ENTER();
+  ARGCHK(twn && ic && medic, "null argument");
+  const int K = h->K, M = h->M;
+  std::vector<float> W((size_t)h->KAM);
+  HIPCHK(hipMemcpyAsync(W.data(), h->dW, W.size() * 4, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  // convRBM.py:475-485 on 4*K*M numbers: host arithmetic in double
+  double sq = 0.0, entsum = 0.0, medsum = 0.0;
+  std::vector<double> ent((size_t)M);
+  for (int k = 0; k < K; ++k) {
+    for (int j = 0; j < M; ++j) {
+      double w[4], mx = -1e300, z = 0.0, e = 0.0;
+      for (int a = 0; a < 4; ++a) {
+        w[a] = W[(size_t)(k * 4 + a) * M + j];
+        sq += w[a] * w[a];
+        mx = std::max(mx, w[a]);
+      }
+      for (int a = 0; a < 4; ++a) z += std::exp(w[a] - mx);
+      for (int a = 0; a < 4; ++a) {
+        const double p = std::exp(w[a] - mx) / z;
+        if (p > 0.0) e -= p * std::log2(p);
+      }
+      ent[j] = e;
+      entsum += e;
+    }
+    std::sort(ent.begin(), ent.end());
+    medsum += ent[(size_t)(M / 2)];
+  }
+  *twn = (float)std::sqrt(sq / (double)h->KAM);
+  *ic = (float)(2.0 - entsum / ((double)K * M));
+  *medic = (float)(2.0 - medsum / (double)K);
+  return CRBM_OK;
+}
+
+// ---- data parallel -------------------------------------------------------------
+int crbm_comm_unique_id(uint8_t id[CRBM_UNIQUE_ID_BYTES]) {
+  if (!id) return CRBM_ERR_INVALID;
+  if (!load_rccl()) { g_create_error = g_rccl.error; return CRBM_ERR_RCCL; }
+  ncclUniqueId uid;
+  static_assert(sizeof(uid) == CRBM_UNIQUE_ID_BYTES, "ncclUniqueId size");
+  ncclResult_t r = g_rccl.GetUniqueId(&uid);
+  if (r != ncclSuccess) { g_create_error = std::string("ncclGetUniqueId: ") + g_rccl.GetErrorString(r); return CRBM_ERR_RCCL; }
+  memcpy(id, &uid, sizeof(uid));
+  return CRBM_OK;
+}
+
+int crbm_comm_init(crbm_handle* h, const uint8_t id[CRBM_UNIQUE_ID_BYTES], int32_t nranks, int32_t rank) {
+  ENTER();
+  ARGCHK(id && nranks >= 1 && rank >= 0 && rank < nranks, "bad argument");
+  if (!load_rccl()) return fail(h, CRBM_ERR_RCCL, g_rccl.error);
+  if (h->comm) { g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
+  ncclUniqueId uid;
+  memcpy(&uid, id, sizeof(uid));
+  ncclResult_t r = g_rccl.CommInitRank(&h->comm, nranks, uid, rank);
+  if (r != ncclSuccess) {
+    h->comm = nullptr;
+    return fail(h, CRBM_ERR_RCCL, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r));
+  }
+  h->nranks = nranks; h->rank = rank;
+  return CRBM_OK;
+}
+
+int crbm_comm_destroy(crbm_handle* h) {
+  ENTER();
+  if (h->comm) {
+    HIPCHK(hipStreamSynchronize(h->stream));
+    g_rccl.CommDestroy(h->comm);
+    h->comm = nullptr;
+  }
+  h->nranks = 1; h->rank = 0;
+  return CRBM_OK;
+}
+
+int crbm_sums_count(const crbm_handle* h) { return h ? h->sl.count : 0; }
+
+int crbm_train_local(crbm_handle* h, const float* D, int32_t n, int32_t L, float* sums_out) {
+  ENTER();
+  ARGCHK(D && sums_out, "null argument");
+  int rc = check_data_shape(h, n, L);
+  if (rc) return rc;
+  HIPCHK(h->letters.ensure((size_t)n * letter_words(L)));
+  rc = encode_host(h, D, n, L, h->letters.p);
+  if (rc) return rc;
+  rc = train_local_dev(h, h->letters.p, n, L);
+  if (rc) return rc;
+  rc = copy_out(h, sums_out, h->d_sums, (size_t)h->sl.count);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return CRBM_OK;
+}
+
+int crbm_train_apply(crbm_handle* h, const float* sums_in, int32_t L_data) {
+  ENTER();
+  ARGCHK(sums_in && L_data >= h->M, "bad argument");
+  HIPCHK(hipMemcpyAsync(h->d_sums, sums_in, (size_t)h->sl.count * 4, hipMemcpyHostToDevice, h->stream));
+  int rc = launch_update(h, L_data);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return CRBM_OK;
+}
+
+int crbm_get_launch_info(const crbm_handle* h, crbm_launch_info* out) {
+  if (!h || !out) return CRBM_ERR_INVALID;
+  const StatsLayout st = stats_layout(h->K, h->M, h->ds, h->NQ, h->G, 1, h->stats_threads);
+  out->nq = h->NQ; out->group = h->G;
+  out->gibbs_grid = h->gibbs_grid; out->gibbs_block = h->gibbs_threads;
+  out->gibbs_seqs_per_tile = h->gl.S; out->gibbs_lds_bytes = h->gl.lds_bytes;
+  out->stats_grid_x = h->stats_rows; out->stats_grid_y = st.grid_y;
+  out->stats_block = h->stats_threads; out->stats_lds_bytes = st.lds_bytes;
+  return CRBM_OK;
+}
+
+int64_t crbm_gibbs_state_bytes(const crbm_handle* h) {
+  if (!h) return 0;
+  const int64_t masks = (int64_t)h->B * h->Lf * h->NW * 4 * (1 + h->ds);
+  const int64_t vout = (int64_t)h->B * letter_words(h->Lv) * 4;
+  return 2 * masks + vout;   // masks read + written, last visible sample written
+}
+
+}  // extern "C"

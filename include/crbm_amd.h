@@ -1,0 +1,180 @@
+/*
+ * crbm_amd.h -- C-ABI of the MI355X-native CRBM training hot path.
+ *
+ * This is the drop-in boundary for the path that the reference
+ * (schulter/crbm, secomo/convRBM.py) hands to Theano.  The reference has no
+ * FFI layer: its inner boundary is the set of compiled-function handles made
+ * in CRBM._compileTheanoFunctions (convRBM.py:453-515).  Every entry point
+ * below replaces one of those handles (or the shared-variable accessors next
+ * to them) one for one; the file:line it replaces is cited per function.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; all array arguments are HOST pointers to
+ *     C-contiguous float32 unless the name ends in _dev;
+ *   - tensors use the reference's layouts: visible (n,1,4,L), hidden
+ *     (n,K,1,Lh), filters (K,1,4,M), bias (1,K), c (1,4);
+ *   - every function returns 0 on success, a negative crbm_status otherwise,
+ *     and never throws; crbm_last_error() returns the message;
+ *   - calls are synchronous w.r.t. the host unless the name ends in _async;
+ *   - one handle owns one GPU (one process per GPU); a handle is not
+ *     thread-safe; the library owns all device memory, the caller owns every
+ *     host buffer it passes and may free it on return.
+ *
+ * Visible data must be exactly one-hot (reference sequences.py:28-31 builds
+ * it that way); anything else returns CRBM_ERR_NOT_ONEHOT.
+ */
+#ifndef CRBM_AMD_H
+#define CRBM_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRBM_AMD_ABI_VERSION 1
+
+typedef enum crbm_status {
+  CRBM_OK = 0,
+  CRBM_ERR_INVALID = -1,      /* bad argument / unsupported configuration */
+  CRBM_ERR_HIP = -2,          /* a HIP runtime call failed                 */
+  CRBM_ERR_NOT_ONEHOT = -3,   /* visible data is not exactly one-hot      */
+  CRBM_ERR_NOT_BINARY = -4,   /* hidden state is not exactly 0/1          */
+  CRBM_ERR_RCCL = -5,         /* an RCCL call failed / RCCL not loadable   */
+  CRBM_ERR_NO_GPU = -6        /* no usable HIP device                      */
+} crbm_status;
+
+/* Hyper-parameters: the reference constructor's arguments
+ * (convRBM.py:68-71) plus what Theano kept implicit. */
+typedef struct crbm_config {
+  int32_t num_motifs;          /* K                                   :111 */
+  int32_t motif_length;        /* M  (1..32)                          :112 */
+  int32_t input_dims;          /* A, must be 4                        :113 */
+  int32_t doublestranded;      /* 0/1                                 :114 */
+  int32_t batchsize;           /* number of persistent fantasy chains :115 */
+  int32_t cd_k;                /* Gibbs steps per update              :121 */
+  int32_t pooling;             /* must be 1                           :120 */
+  int32_t fantasy_hidden_len;  /* hidden length of the fantasy chains;
+                                  the reference hard-codes 200        :168 */
+  float learning_rate;         /*                                     :116 */
+  float momentum;              /*                                     :117 */
+  float rho;                   /* resolved target frequency (>0)  :136-140 */
+  float lambda_rate;           /*                                     :119 */
+  uint64_t seed;               /* Philox key (reference: wall clock   :155) */
+  int32_t device;              /* HIP device ordinal                       */
+  int32_t reserved;
+} crbm_config;
+
+typedef struct crbm_handle crbm_handle;
+
+/* ---- lifetime ------------------------------------------------------------
+ * crbm_create replaces CRBM.__init__'s shared-variable setup + the Theano
+ * compile step (convRBM.py:127-175): allocates W,b,c, velocities (zero),
+ * fantasy chains (zero), picks kernel specialisations.  W is zero until
+ * crbm_set_params. */
+int crbm_create(const crbm_config* cfg, crbm_handle** out);
+int crbm_destroy(crbm_handle* h);
+/* Message of the last failed call on h (h may be NULL: last crbm_create). */
+const char* crbm_last_error(const crbm_handle* h);
+int crbm_abi_version(void);
+/* Number of visible HIP devices (does not initialise a context). */
+int crbm_device_count(void);
+
+/* ---- shared-variable accessors (theano.shared get_value/set_value;
+ * convRBM.py:133,149,152,158-173, used at :186-188,:233-235) --------------- */
+int crbm_set_params(crbm_handle* h, const float* W, const float* b, const float* c);
+int crbm_get_params(crbm_handle* h, float* W, float* b, float* c);
+int crbm_set_velocities(crbm_handle* h, const float* vW, const float* vb, const float* vc);
+int crbm_get_velocities(crbm_handle* h, float* vW, float* vb, float* vc);
+/* fantasy_h / fantasy_h_prime, dense (batchsize,K,1,fantasy_hidden_len);
+ * h_prime is ignored / may be NULL when single-stranded. */
+int crbm_set_fantasy(crbm_handle* h, const float* hid, const float* hid_prime);
+int crbm_get_fantasy(crbm_handle* h, float* hid, float* hid_prime);
+/* Visible sample of the last Gibbs step, dense (batchsize,1,4,Lf+M-1). */
+int crbm_get_fantasy_visible(crbm_handle* h, float* v);
+/* Sampler state: key, Gibbs-step counter, evaluation counter, and the global
+ * index of this rank's first chain / first data row (data-parallel runs). */
+int crbm_set_rng(crbm_handle* h, uint64_t seed, uint32_t gibbs_step, uint32_t eval_step);
+int crbm_get_rng(crbm_handle* h, uint64_t* seed, uint32_t* gibbs_step, uint32_t* eval_step);
+int crbm_set_shard(crbm_handle* h, uint32_t chain_offset);
+
+/* ---- training ------------------------------------------------------------
+ * theano_trainingFct([D]) (convRBM.py:459-464, graph :373-438): one PCD-k
+ * SGD+momentum update on mini-batch D (n,1,4,L); mutates W,b,c, velocities,
+ * fantasy chains.  n may differ from batchsize (short last slice). */
+int crbm_train_step(crbm_handle* h, const float* D, int32_t n, int32_t L);
+/* Same, on rows [start,end) of a data set made resident with
+ * crbm_dataset_upload (fit() uploads once, convRBM.py:612-615 then only
+ * passes slice bounds). */
+int crbm_dataset_upload(crbm_handle* h, const float* data, int32_t n, int32_t L);
+int crbm_train_step_resident(crbm_handle* h, int32_t start, int32_t end);
+/* The persistent chain alone (convRBM.py:397-408): k Gibbs steps on all
+ * fantasy chains, parameters frozen.  Benchmark entry. */
+int crbm_gibbs_steps(crbm_handle* h, int32_t k);
+int crbm_gibbs_steps_async(crbm_handle* h, int32_t k);
+int crbm_sync(crbm_handle* h);
+/* Times `launches` back-to-back launches of k Gibbs steps each with HIP
+ * events on the library's stream; returns the total in milliseconds. */
+int crbm_time_gibbs(crbm_handle* h, int32_t k, int32_t launches, float* total_ms);
+/* Same for full training steps on resident rows [start,end). */
+int crbm_time_train(crbm_handle* h, int32_t start, int32_t end, int32_t launches, float* total_ms);
+
+/* ---- stand-alone passes (the graph builders the reference tests compile
+ * directly, tests/testcrbm.py:165-171,:226-229) ---------------------------- */
+/* _computeHgivenV(data, flip) (convRBM.py:269-275): any of act/prob/sample
+ * may be NULL; each is (n,K,1,L-M+1).  Samples use Philox word 3 = rng_step. */
+int crbm_h_given_v(crbm_handle* h, const float* v, int32_t n, int32_t L, int32_t flip,
+                   uint32_t rng_step, float* act, float* prob, float* sample);
+/* _computeVgivenH(h, hprime) (convRBM.py:317-325): hid (n,K,1,Lh) (any
+ * finite values), hid_prime NULL or same shape; outputs (n,1,4,Lh+M-1),
+ * each may be NULL. */
+int crbm_v_given_h(crbm_handle* h, const float* hid, const float* hid_prime, int32_t n,
+                   int32_t Lh, uint32_t rng_step, float* act, float* prob, float* sample);
+
+/* ---- evaluation ------------------------------------------------------------
+ * theano_getHitProbs (convRBM.py:507-514) -> (n,K,1,L-M+1). */
+int crbm_hit_probs(crbm_handle* h, const float* v, int32_t n, int32_t L, float* out);
+/* theano_freeEnergy (:501, graph :657-676) -> (n,) */
+int crbm_free_energy(crbm_handle* h, const float* v, int32_t n, int32_t L, float* out);
+/* theano_fePerMotif (:504, graph :678-697) -> (n,K) */
+int crbm_free_energy_per_motif(crbm_handle* h, const float* v, int32_t n, int32_t L, float* out);
+/* theano_evaluateData (:487-491) -> mean free energy, mean of a sampled H */
+int crbm_eval_data(crbm_handle* h, const float* v, int32_t n, int32_t L, float* mfe, float* nmh);
+/* theano_evaluateParams (:494-499) -> rms(W), IC, median IC */
+int crbm_eval_params(crbm_handle* h, float* twn, float* ic, float* medic);
+
+/* ---- data-parallel (new: the reference is single-device) -----------------
+ * One process per GPU.  Rank 0 calls crbm_comm_unique_id and distributes the
+ * 128 bytes by any host channel; every rank then calls crbm_comm_init.  After
+ * that crbm_train_step* all-reduces (ncclSum, float32) one packed buffer of
+ * raw statistic sums per step over RCCL/xGMI and every rank applies the same
+ * update.  Layout of the packed buffer (floats), KAM = K*4*M:
+ *   [vh_d KAM][vh_d' KAM][h_d K][h_d' K][sw KAM][sb K][v_d 4][n_d 1]
+ *   [vh_m KAM][vh_m' KAM][h_m K][h_m' K][v_m 4][n_m 1]
+ * (the primed blocks are present, zero-filled, also when single-stranded). */
+#define CRBM_UNIQUE_ID_BYTES 128
+int crbm_comm_unique_id(uint8_t id[CRBM_UNIQUE_ID_BYTES]);
+int crbm_comm_init(crbm_handle* h, const uint8_t id[CRBM_UNIQUE_ID_BYTES], int32_t nranks, int32_t rank);
+int crbm_comm_destroy(crbm_handle* h);
+int crbm_sums_count(const crbm_handle* h);
+/* Split form of crbm_train_step for hosts that reduce the sums themselves:
+ * local phase -> sums in `sums_out` (host, crbm_sums_count floats);
+ * the caller reduces; apply consumes the reduced sums. */
+int crbm_train_local(crbm_handle* h, const float* D, int32_t n, int32_t L, float* sums_out);
+int crbm_train_apply(crbm_handle* h, const float* sums_in, int32_t L_data);
+
+/* ---- introspection used by bench/profiling ------------------------------- */
+typedef struct crbm_launch_info {
+  int32_t nq;            /* float4 quads of motifs the kernels are specialised for */
+  int32_t group;         /* letters per gather-table group (G)                    */
+  int32_t gibbs_grid, gibbs_block, gibbs_seqs_per_tile, gibbs_lds_bytes;
+  int32_t stats_grid_x, stats_grid_y, stats_block, stats_lds_bytes;
+} crbm_launch_info;
+int crbm_get_launch_info(const crbm_handle* h, crbm_launch_info* out);
+/* Actual bytes of chain state one Gibbs launch reads+writes in HBM. */
+int64_t crbm_gibbs_state_bytes(const crbm_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRBM_AMD_H */
