@@ -593,7 +593,7 @@ __global__ void __launch_bounds__(256) stats_kernel(StatsArgs a) {
   if (mv.ds) build_gather_table(Tr, mv, KP, true);
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = nthr >> 6;
-  // accumulator tile of this wave: (strand, kind, kt, jt)
+  // accumulator tile of this wave: (class, kt, jt)
   const int tile_id = blockIdx.y * nwaves + wave;
   const bool active = tile_id < a.ntiles;
   int t_jt = 0, t_kt = 0, t_kind = 0, t_strand = 0;
@@ -601,9 +601,9 @@ __global__ void __launch_bounds__(256) stats_kernel(StatsArgs a) {
     int t = tile_id;
     t_jt = t % a.ntj; t /= a.ntj;
     t_kt = t % a.ntk; t /= a.ntk;
-    const int nkind = 1 + a.want_sparsity;
-    t_kind = t % nkind; t /= nkind;
-    t_strand = t;
+    // accumulator classes: 0 = vh (forward strand), 1 = vh' (ds only), last = sw (forward, P(1-P))
+    t_kind = (a.want_sparsity && t == mv.ds + 1) ? 1 : 0;
+    t_strand = (!t_kind && t == 1) ? 1 : 0;
   }
   float acc[4][JC][KC];
 #pragma unroll

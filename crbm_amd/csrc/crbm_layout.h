@@ -98,7 +98,7 @@ inline GibbsLayout gibbs_layout(int K, int M, int ds, int NQ, int G, int Lf, int
 inline int stats_nqc(int NQ) { return NQ < 4 ? NQ : 4; }
 inline int stats_jc(int NQ) { return stats_nqc(NQ) <= 3 ? 4 : 3; }
 struct StatsLayout {
-  int ntk, ntj, ntiles;   // k-tiles, j-tiles, total (strand x kind x k x j)
+  int ntk, ntj, ntiles;   // k-tiles, j-tiles, total (class x k x j)
   int grid_y;
   int row;                // floats per partial row: 3*KAM + 3K + 4
   int off_vh[2], off_h[2], off_sw, off_sb, off_v;
@@ -109,7 +109,7 @@ inline StatsLayout stats_layout(int K, int M, int ds, int NQ, int G, int want_sp
   int KAM = K * 4 * M;
   s.ntk = (NQ + stats_nqc(NQ) - 1) / stats_nqc(NQ);
   s.ntj = (M + stats_jc(NQ) - 1) / stats_jc(NQ);
-  s.ntiles = (1 + ds) * (1 + want_sparsity) * s.ntk * s.ntj;
+  s.ntiles = (1 + ds + want_sparsity) * s.ntk * s.ntj;   // classes: vh, vh' (ds), sw
   int waves = threads / 64;
   s.grid_y = (s.ntiles + waves - 1) / waves;
   s.off_vh[0] = 0;

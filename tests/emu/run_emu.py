@@ -1,0 +1,291 @@
+"""TEST INFRASTRUCTURE: drives the CPU-thread emulation of the HIP kernels
+(libcrbm_emu.so, built from tests/emu/emu_main.cpp with ASan+UBSan) and checks
+every kernel against the float64 oracle.  Run by tests/test_emu.py in a
+subprocess with the sanitizer runtime preloaded."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from oracle.crbm_oracle import (OracleCRBM, synthetic_onehot, hidden_uniforms, visible_uniforms,  # noqa: E402
+                                KIND_API_H, KIND_API_V, letters_of)
+
+lib = ctypes.CDLL(os.path.join(HERE, os.environ.get("CRBM_EMU_LIB", "libcrbm_emu.so")))
+F = ctypes.POINTER(ctypes.c_float)
+U = ctypes.POINTER(ctypes.c_uint32)
+
+
+def fp(a):
+    return None if a is None else a.ctypes.data_as(F)
+
+
+def up(a):
+    return None if a is None else a.ctypes.data_as(U)
+
+
+def f32(x):
+    return np.ascontiguousarray(x, dtype=np.float32)
+
+
+def model_arrays(o):
+    return f32(o.W.reshape(o.num_motifs, 4, o.motif_length)), f32(o.b.ravel()), f32(o.c.ravel())
+
+
+def encode(data):
+    n, L = data.shape[0], data.shape[3]
+    LW = lib.emu_letter_words(L)
+    letters = np.zeros((n, LW), dtype=np.uint32)
+    flags = np.zeros(4, dtype=np.uint32)
+    lib.emu_encode(fp(f32(data)), up(letters), up(flags), n, L, 3)
+    return letters, int(flags[0])
+
+
+def pack_hidden(h, NW):
+    n, K, _, Lh = h.shape
+    masks = np.zeros((n, Lh, NW), dtype=np.uint32)
+    flags = np.zeros(4, dtype=np.uint32)
+    d = f32(h)
+    lib.emu_pack_hidden(fp(d), up(masks), up(flags), n, K, Lh, NW, 0)
+    return masks, int(flags[0])
+
+
+def unpack_hidden(masks, K):
+    n, Lh, NW = masks.shape
+    d = np.zeros((n, K, 1, Lh), dtype=np.float32)
+    flags = np.zeros(4, dtype=np.uint32)
+    lib.emu_pack_hidden(fp(d), up(np.ascontiguousarray(masks)), up(flags), n, K, Lh, NW, 1)
+    return d
+
+
+def check_samples(name, got, prob, u):
+    """identical up to ties: a mismatch needs |p-u| < 1e-6."""
+    want = (prob > u).astype(np.float32)
+    bad = got != want
+    if bad.any():
+        assert np.all(np.abs(prob - u)[bad] < 1e-6), "%s: sample mismatch away from a tie" % name
+    return int(bad.sum())
+
+
+def make_oracle(K, M, ds, seed=0, batch=4, Lf=20, cd_k=2, wscale=1.0, **kw):
+    rng = np.random.default_rng(100 + K * 31 + M)
+    o = OracleCRBM(K, M, doublestranded=ds, batchsize=batch, cd_k=cd_k, fantasy_hidden_len=Lf, seed=seed,
+                   W=rng.standard_normal((K, 1, 4, M)) * wscale, **kw)
+    o.c = f32(rng.standard_normal((1, 4)) * 0.2).astype(np.float64)
+    o.b = f32(o.b + 6.0 + rng.standard_normal((1, K)) * 0.5).astype(np.float64)   # livelier hidden units
+    return o
+
+
+ALL_CASES = [  # K, M, ds, nq, G
+    (10, 5, False, 3, 2),
+    (10, 15, True, 3, 3),
+    (2, 5, True, 1, 4),
+    (3, 4, False, 1, 1),
+    (20, 15, True, 5, 2),
+    (50, 25, False, 13, 2),
+    (7, 32, True, 2, 3),
+]
+# One OS thread per GPU thread makes barrier-heavy kernels slow on 8 cores: the
+# default run keeps the CPU suite to a few minutes, CRBM_EMU_FULL=1 runs all.
+FULL = os.environ.get("CRBM_EMU_FULL", "0") == "1"
+CASES = ALL_CASES if FULL else [ALL_CASES[1], ALL_CASES[2], ALL_CASES[3]]
+GIBBS_CASES = ALL_CASES if FULL else [ALL_CASES[1], ALL_CASES[3], ALL_CASES[5], ALL_CASES[6]]
+
+
+def test_encode_pack():
+    d = synthetic_onehot(5, 37, seed=1)
+    letters, flag = encode(d)
+    assert flag == 0
+    LW = lib.emu_letter_words(37)
+    ref = letters_of(d)
+    for n in range(5):
+        for p in range(37):
+            assert (int(letters[n, p >> 4]) >> (2 * (p & 15))) & 3 == ref[n, p]
+    assert np.all(letters[:, LW - 2:] == 0)
+    back = np.zeros_like(d)
+    lib.emu_decode(up(letters), fp(back), 5, 37, 2)
+    assert np.array_equal(back, d)
+    bad = d.copy(); bad[2, 0, :, 5] = 0
+    assert encode(bad)[1] == 1
+    bad = d.copy(); bad[1, 0, :, 7] = 0.5
+    assert encode(bad)[1] == 1
+    rng = np.random.default_rng(2)
+    for K, NW in ((10, 1), (40, 2)):
+        h = rng.binomial(1, 0.3, size=(3, K, 1, 9)).astype(np.float32)
+        m, fl = pack_hidden(h, NW)
+        assert fl == 0
+        assert np.array_equal(unpack_hidden(m, K), h)
+        h2 = h.copy(); h2[0, 0, 0, 0] = 0.25
+        assert pack_hidden(h2, NW)[1] == 2
+    print("encode/pack ok")
+
+
+def test_hgv():
+    for (K, M, ds, nq, G) in CASES:
+        o = make_oracle(K, M, ds)
+        W, b, c = model_arrays(o)
+        n, L = 5, M + 27
+        d = synthetic_onehot(n, L, seed=K)
+        letters, _ = encode(d)
+        Lh = L - M + 1
+        for mode in (0, 1, 2):
+            act = np.zeros((n, K, 1, Lh), dtype=np.float32)
+            prob = np.zeros_like(act)
+            smp = np.zeros_like(act)
+            ones = ctypes.c_ulonglong(0)
+            rc = lib.emu_hgv(nq, fp(W), fp(b), fp(c), K, M, G, int(ds), up(letters), n, L, mode, fp(act), fp(prob),
+                             fp(smp), ctypes.byref(ones), ctypes.c_uint64(77), 5, 3, KIND_API_H, 2, 2, 128)
+            assert rc == 0
+            if mode == 2:
+                ref = o._bottomUpActivity(d) + o._bottomUpActivity(d, True)
+            else:
+                ref = o._bottomUpActivity(d, mode == 1)
+            np.testing.assert_allclose(act, ref, rtol=1e-5, atol=1e-5)
+            p = 1 / (1 + np.exp(-ref))
+            np.testing.assert_allclose(prob, p, rtol=1e-5, atol=1e-6)
+            u = hidden_uniforms(77, 5, np.arange(n) + 3, K, Lh, 1 if mode == 1 else 0, KIND_API_H)
+            ties = check_samples("hgv", smp, prob.astype(np.float64), u)
+            assert ones.value == int(smp.sum())
+        print("hgv ok", (K, M, ds, nq, G), "ties", ties)
+
+
+def test_vgh():
+    for (K, M, ds, nq, G) in CASES[:5]:
+        o = make_oracle(K, M, ds)
+        W, b, c = model_arrays(o)
+        rng = np.random.default_rng(K)
+        n, Lh = 4, 23
+        h = rng.binomial(1, 0.15, size=(n, K, 1, Lh)).astype(np.float32)
+        hp = rng.binomial(1, 0.15, size=(n, K, 1, Lh)).astype(np.float32) if ds else None
+        if K == 3:
+            h = rng.standard_normal(h.shape).astype(np.float32)      # any finite values
+        L = Lh + M - 1
+        act = np.zeros((n, 1, 4, L), dtype=np.float32)
+        prob = np.zeros_like(act)
+        smp = np.zeros_like(act)
+        lib.emu_vgh(fp(W), fp(b), fp(c), K, M, fp(h), fp(hp), n, Lh, fp(act), fp(prob), fp(smp),
+                    ctypes.c_uint64(9), 2, 1, 2, 3, 64)
+        ref = o._topDownActivity(h, hp)
+        np.testing.assert_allclose(act, ref, rtol=1e-5, atol=1e-5)
+        pref = o._topDownProbability(ref)
+        np.testing.assert_allclose(prob, pref, rtol=1e-5, atol=1e-6)
+        u = visible_uniforms(9, 2, np.arange(n) + 1, L, KIND_API_V)
+        sref = o._topDownSample(pref, u)
+        bad = (smp != sref).any(axis=2)[:, 0]
+        if bad.any():
+            cum = np.cumsum(pref[:, 0], axis=1)
+            gap = np.min(np.abs(cum - u[:, None, :]), axis=1)
+            assert np.all(gap[bad] < 1e-6)
+        np.testing.assert_array_equal(smp.sum(axis=2), 1.0)
+        print("vgh ok", (K, M, ds))
+
+
+def run_gibbs(o, nq, G, S, steps, grid, threads):
+    K, M, ds = o.num_motifs, o.motif_length, o.doublestranded
+    W, b, c = model_arrays(o)
+    NW = 1 if nq <= 8 else 2
+    hm, _ = pack_hidden(f32(o.fantasy_h), NW)
+    hmp = pack_hidden(f32(o.fantasy_h_prime), NW)[0] if ds else np.zeros_like(hm)
+    B, Lf = o.fantasy_h.shape[0], o.fantasy_h.shape[3]
+    Lv = Lf + M - 1
+    vout = np.zeros((B, lib.emu_letter_words(Lv)), dtype=np.uint32)
+    rc = lib.emu_gibbs(nq, fp(W), fp(b), fp(c), K, M, G, int(ds), up(hm), up(hmp), up(vout), B, Lf, S, steps,
+                       ctypes.c_uint64(o.seed), o.gibbs_step, o.seq_offset, grid, threads)
+    assert rc == 0
+    v = np.zeros((B, 1, 4, Lv), dtype=np.float32)
+    lib.emu_decode(up(vout), fp(v), B, Lv, 2)
+    return unpack_hidden(hm, K), (unpack_hidden(hmp, K) if ds else None), v, vout
+
+
+def test_gibbs():
+    for (K, M, ds, nq, G) in GIBBS_CASES:
+        for (B, Lf, S, steps, grid, threads) in ((5, 21, 2, 3, 2, 128), (3, 40, 4, 1, 1, 64)):
+            o = make_oracle(K, M, ds, seed=11, batch=B, Lf=Lf, wscale=1.5)
+            o.seq_offset = 6
+            rng = np.random.default_rng(5)
+            o.fantasy_h = rng.binomial(1, 0.1, size=o.fantasy_h.shape).astype(np.float64)
+            if ds:
+                o.fantasy_h_prime = rng.binomial(1, 0.1, size=o.fantasy_h.shape).astype(np.float64)
+            h, hp, v, _ = run_gibbs(o, nq, G, S, steps, grid, threads)
+            o.gibbs_steps(steps)
+            mism = int((h != o.fantasy_h).sum()) + (int((hp != o.fantasy_h_prime).sum()) if ds else 0)
+            mism_v = int((v != o.last_v_model).sum())
+            assert mism == 0 and mism_v == 0, ("gibbs mismatch", (K, M, ds), mism, mism_v)
+            assert o.fantasy_h.sum() > 0
+        print("gibbs ok", (K, M, ds, nq, G))
+
+
+def test_train_step():
+    for (K, M, ds, nq, G) in (ALL_CASES[:6] if FULL else CASES[:2]):
+        B, Lf, n, L = 4, 18, 5, M + 20
+        o = make_oracle(K, M, ds, seed=3, batch=B, Lf=Lf, cd_k=2, rho=0.05)
+        o.vW = f32(np.random.default_rng(1).standard_normal(o.W.shape) * 0.01).astype(np.float64)
+        D = synthetic_onehot(n, L, seed=21)
+        W, b, c = model_arrays(o)
+        vW, vb, vc = f32(o.vW.reshape(K, 4, M)), f32(o.vb.ravel()), f32(o.vc.ravel())
+        lay = (ctypes.c_int * 7)()
+        lib.emu_sums_layout(K, M, lay)
+        data_off, n_d, model_off, n_m, count, skipb, skipl = list(lay)
+        sums = np.zeros(count, dtype=np.float32)
+        letters, _ = encode(D)
+        rows, threads = 2, 128
+        row = 3 * K * 4 * M + 3 * K + 4
+        partials = np.zeros(rows * row, dtype=np.float32)
+        r = lib.emu_stats(nq, fp(W), fp(b), fp(c), K, M, G, int(ds), up(letters), n, L, 1, 2, rows, threads,
+                          fp(partials), fp(sums[data_off:]), -1, 0)
+        assert r == row
+        _, _, v, vout = run_gibbs(o, nq, G, 2, o.cd_k, 2, threads)
+        Lv = Lf + M - 1
+        r = lib.emu_stats(nq, fp(W), fp(b), fp(c), K, M, G, int(ds), up(vout), B, Lv, 0, 3, rows, threads,
+                          fp(partials), fp(sums[model_off:]), skipb, skipl)
+        assert sums[n_d] == n and sums[n_m] == B
+        # raw sums against the oracle's
+        P_m, P_mp, v_m = o.gibbs_steps(o.cd_k)
+        assert np.array_equal(v, v_m)
+        o.gibbs_step -= o.cd_k
+        s = o.local_sums(D, P_m, P_mp, v_m)
+        KAM = K * 4 * M
+        np.testing.assert_allclose(sums[0:KAM], s['vh_d'].ravel(), rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(sums[2 * KAM:2 * KAM + K], s['h_d'], rtol=2e-5)
+        np.testing.assert_allclose(sums[2 * KAM + 2 * K:3 * KAM + 2 * K], s['sw'].ravel(), rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(sums[3 * KAM + 2 * K:3 * KAM + 3 * K], s['sb'], rtol=2e-5)
+        np.testing.assert_allclose(sums[3 * KAM + 3 * K:3 * KAM + 3 * K + 4], s['v_d'])
+        np.testing.assert_allclose(sums[model_off:model_off + KAM], s['vh_m'].ravel(), rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(sums[n_m - 4:n_m], s['v_m'])
+        if ds:
+            np.testing.assert_allclose(sums[KAM:2 * KAM], s['vh_dp'].ravel(), rtol=2e-5, atol=1e-6)
+            np.testing.assert_allclose(sums[model_off + 2 * KAM + K:model_off + 2 * KAM + 2 * K], s['h_mp'], rtol=2e-5)
+        lib.emu_update(fp(sums), fp(W), fp(b), fp(c), fp(vW), fp(vb), fp(vc), K, M, int(ds), L, Lf,
+                       ctypes.c_float(o.learning_rate), ctypes.c_float(o.momentum), ctypes.c_float(o.rho),
+                       ctypes.c_float(o.lambda_rate))
+        o.finalize_from_sums(s, L, Lf)
+        np.testing.assert_allclose(W.reshape(o.W.shape), o.W, rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(b, o.b.ravel(), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(c, o.c.ravel(), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(vW.reshape(o.W.shape), o.vW, rtol=1e-4, atol=1e-7)
+        print("train step ok", (K, M, ds, nq, G))
+
+
+def test_free_energy():
+    for (K, M, ds, nq, G) in CASES:
+        o = make_oracle(K, M, ds)
+        W, b, c = model_arrays(o)
+        n, L = 7, M + 70
+        d = synthetic_onehot(n, L, seed=K + 1)
+        letters, _ = encode(d)
+        fe = np.zeros(n, dtype=np.float32)
+        fem = np.zeros((n, K), dtype=np.float32)
+        lib.emu_free_energy(nq, fp(W), fp(b), fp(c), K, M, G, int(ds), up(letters), n, L, fp(fe), fp(fem), 2, 128)
+        np.testing.assert_allclose(fe, o.freeEnergy(d), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(fem, o.freeEnergy(d, True), rtol=1e-5, atol=1e-5)
+        print("free energy ok", (K, M, ds))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["encode_pack", "hgv", "vgh", "gibbs", "train_step", "free_energy"]
+    for w in which:
+        globals()["test_" + w]()
+    print("EMU ALL OK")

@@ -1,0 +1,69 @@
+// TEST INFRASTRUCTURE: a minimal "HIP on CPU threads" shim so that the kernel
+// header crbm_amd/csrc/crbm_kernels.h can be compiled with g++ and run under
+// AddressSanitizer / UBSan (GPU sanitizers are not available on this pool).
+// One OS thread per GPU thread, pthread barriers for __syncthreads() and for
+// wave-level shuffles.  Never shipped, never used by the product path.
+#pragma once
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {}
+};
+struct float4 {
+  float x, y, z, w;
+};
+static inline float4 make_float4(float a, float b, float c, float d) { return float4{a, b, c, d}; }
+typedef void* hipStream_t;
+
+namespace emu {
+struct BlockCtx {
+  pthread_barrier_t bar;
+  pthread_barrier_t* wave_bar;   // one per wave
+  float* wave_scratch;           // 64 floats per wave
+  unsigned char* smem;
+};
+extern thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
+extern thread_local BlockCtx* t_ctx;
+}  // namespace emu
+
+#define threadIdx emu::t_threadIdx
+#define blockIdx emu::t_blockIdx
+#define blockDim emu::t_blockDim
+#define gridDim emu::t_gridDim
+
+#define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<type*>(emu::t_ctx->smem);
+
+static inline void __syncthreads() { pthread_barrier_wait(&emu::t_ctx->bar); }
+
+static inline float __shfl_down(float v, int off, int width = 64) {
+  const unsigned lane = emu::t_threadIdx.x & 63u, wave = emu::t_threadIdx.x >> 6;
+  float* s = emu::t_ctx->wave_scratch + wave * 64;
+  s[lane] = v;
+  pthread_barrier_wait(&emu::t_ctx->wave_bar[wave]);
+  const float r = (lane + (unsigned)off < (unsigned)width) ? s[lane + off] : v;
+  pthread_barrier_wait(&emu::t_ctx->wave_bar[wave]);
+  return r;
+}
+
+static inline uint32_t atomicOr(uint32_t* p, uint32_t v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) {
+  return __atomic_fetch_add(p, v, __ATOMIC_RELAXED);
+}
+static inline int __ffs(uint32_t v) { return __builtin_ffs((int)v); }
+static inline uint32_t __umulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+#define __expf(x) expf(x)
+static inline float __fdividef(float a, float b) { return a / b; }
+using std::max;
+using std::min;

@@ -1,0 +1,134 @@
+"""world_size-2 CPU tests of the data-parallel path (gloo; no GPU).
+
+What is rank-dependent in the HIP path is host logic: which rows and chains a
+rank owns, the Philox sequence offset, the packed raw-sum layout, and that the
+update is formed from GLOBAL sums.  Here each rank computes its local raw sums
+with the oracle (standing in for the kernels), gloo all-reduces them, and the
+result must equal the single-process step on the whole batch."""
+import multiprocessing as mp
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from oracle.crbm_oracle import OracleCRBM, synthetic_onehot
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make(ds, B):
+    return OracleCRBM(6, 7, doublestranded=ds, batchsize=B, cd_k=2, fantasy_hidden_len=25, seed=9,
+                      W=np.random.default_rng(3).standard_normal((6, 1, 4, 7)))
+
+
+def _rank_main(rank, world, port, ds, q):
+    import torch
+    import torch.distributed as dist
+    from crbm_amd.dist import shard_range
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    B, n, L = 8, 11, 40
+    D = synthetic_onehot(n, L, seed=4)
+    o = _make(ds, B)
+    for b in o._iterateBatchIndices(n, 8):                 # two mini-batches, the second short (3 rows)
+        lo, hi = shard_range(b[1] - b[0], rank, world)
+        rows = D[b[0] + lo:b[0] + hi]
+        clo, chi = shard_range(B, rank, world)
+        local = _make(ds, chi - clo)
+        local.W, local.b, local.c = o.W, o.b, o.c
+        local.fantasy_h = o.fantasy_h[clo:chi]
+        local.fantasy_h_prime = o.fantasy_h_prime[clo:chi] if ds else None
+        local.seq_offset, local.gibbs_step = clo, o.gibbs_step
+        P_m, P_mp, v_m = local.gibbs_steps(local.cd_k)
+        if len(rows):
+            s = local.local_sums(rows, P_m, P_mp, v_m)
+        else:                                              # a rank may own no data rows
+            s = local.local_sums(D[:1], P_m, P_mp, v_m)
+            for k in ("vh_d", "h_d", "sw", "sb", "v_d", "vh_dp", "h_dp"):
+                if k in s:
+                    s[k] = np.zeros_like(s[k])
+            s["n_d"] = 0.0
+        keys = sorted(s)
+        flat = torch.from_numpy(np.concatenate([np.ravel(np.asarray(s[k], dtype=np.float64)) for k in keys]))
+        dist.all_reduce(flat)                              # sum
+        pos = 0
+        for k in keys:
+            size = int(np.size(s[k]))
+            s[k] = flat[pos:pos + size].numpy().reshape(np.shape(s[k])) if np.ndim(s[k]) else float(flat[pos])
+            pos += size
+        o.finalize_from_sums(s, L, 25)
+        # gather the chains back so that the next step starts from the global state
+        hs = [torch.zeros(1)] * world
+        parts = [None] * world
+        dist.all_gather_object(parts, (local.fantasy_h, local.fantasy_h_prime))
+        o.fantasy_h = np.concatenate([p[0] for p in parts])
+        if ds:
+            o.fantasy_h_prime = np.concatenate([p[1] for p in parts])
+        o.gibbs_step += o.cd_k
+    if rank == 0:
+        q.put((o.W, o.b, o.c, o.fantasy_h))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("ds", [False, True])
+def test_two_rank_step_equals_single_process(ds):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, ds, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    W, b, c, fh = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = _make(ds, 8)
+    D = synthetic_onehot(11, 40, seed=4)
+    for lo, hi in ref._iterateBatchIndices(11, 8):
+        ref.train_step(D[lo:hi])
+    np.testing.assert_allclose(W, ref.W, rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(b, ref.b, rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(c, ref.c, rtol=1e-10, atol=1e-13)
+    np.testing.assert_array_equal(fh, ref.fantasy_h)
+
+
+def _id_rank(rank, port, q):
+    from crbm_amd import dist
+    uid = dist.exchange_unique_id(rank, 2, addr="127.0.0.1", port=port,
+                                  make_id=lambda: bytes(range(128)))
+    q.put((rank, uid))
+
+
+def test_unique_id_exchange_over_tcp():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_id_rank, args=(r, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=60) for _ in range(2))
+    for p in procs:
+        p.join(timeout=30)
+    assert got[0] == got[1] == bytes(range(128))
+
+
+def test_shard_ranges_and_model_sharding():
+    from crbm_amd import CRBM
+    from crbm_amd.dist import shard_range
+    assert [shard_range(11, r, 4) for r in range(4)] == [(0, 2), (2, 5), (5, 8), (8, 11)]
+    assert [shard_range(3, r, 8) for r in range(8)].count((0, 0)) >= 1      # empty shards exist
+    m = CRBM(4, 5, batchsize=16)
+    m.rank, m.world_size = 3, 8
+    assert m._shard_rows(40, 48) == (43, 44)
+    covered = []
+    for r in range(8):
+        m.rank = r
+        lo, hi = m._shard_rows(100, 120)
+        covered += list(range(lo, hi))
+    assert covered == list(range(100, 120))

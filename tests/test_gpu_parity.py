@@ -1,0 +1,316 @@
+"""GPU parity tests: the HIP path (through the C-ABI, via crbm_amd.CRBM) against
+the float64 oracle on the same seeded inputs.  Shapes and checks mirror the
+reference's tests/testcrbm.py (lines cited per test).  Tolerance for floating
+point outputs: 1e-4 relative (BASELINE.json north_star); samples must be
+identical given the shared Philox stream, except at |p - u| < 1e-6 ties.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle.crbm_oracle import (OracleCRBM, synthetic_onehot, hidden_uniforms, visible_uniforms,
+                                KIND_API_H, KIND_API_V)
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+
+
+def make_pair(K, M, ds=True, batchsize=8, cd_k=2, Lf=200, seed=5, wscale=1.0, bshift=0.0, **kw):
+    """A crbm_amd.CRBM and an OracleCRBM with identical parameters and sampler."""
+    from crbm_amd import CRBM
+    rng = np.random.default_rng(1000 + 7 * K + M)
+    W = (rng.standard_normal((K, 1, 4, M)) * wscale).astype(np.float32)
+    m = CRBM(K, M, doublestranded=ds, batchsize=batchsize, cd_k=cd_k, fantasy_hidden_len=Lf, seed=seed, **kw)
+    o = OracleCRBM(K, M, doublestranded=ds, batchsize=batchsize, cd_k=cd_k, fantasy_hidden_len=Lf, seed=seed,
+                   W=W, **{k: v for k, v in kw.items() if k in ("rho", "lambda_rate", "learning_rate", "momentum")})
+    b = (o.b + bshift).astype(np.float32)
+    c = (rng.standard_normal((1, 4)) * 0.1).astype(np.float32)
+    m.motifs.set_value(W)
+    m.bias.set_value(b)
+    m.c.set_value(c)
+    o.b, o.c = b.astype(np.float64), c.astype(np.float64)
+    return m, o
+
+
+def assert_samples(got, prob, u):
+    want = (prob > u).astype(np.float32)
+    bad = got != want
+    assert np.all(np.abs(prob - u)[bad] < 1e-6), "sample differs away from a p == u tie"
+    assert bad.mean() < 1e-4
+
+
+# ---- reference tests/testcrbm.py:148-200 ------------------------------------
+@pytest.mark.parametrize("flip", [False, True])
+def test_bottomup(flip):
+    data = synthetic_onehot(11, 200, seed=3)
+    nmot, mlen = 10, 5
+    model, o = make_pair(nmot, mlen)
+    w = model.motifs.get_value()[:, :, ::-1, ::-1] if flip else model.motifs.get_value()
+    b = model.bias.get_value()
+    output = model._bottomUpActivity(data, flip)
+    output_control = np.zeros(output.shape)
+    for seq in range(data.shape[0]):
+        for s in range(data.shape[3] - w.shape[3] + 1):
+            for m in range(w.shape[0]):
+                output_control[seq, m, 0, s] += \
+                    np.multiply(w[m, 0, :, :], data[seq, 0, :, s:(s + w.shape[3])]).sum() + b[0, m]
+    np.testing.assert_allclose(output, output_control, rtol=1e-5, atol=1e-5)
+    sig = 1. / (1. + np.exp(-output_control))
+    np.testing.assert_allclose(sig, model._bottomUpProbabilityOfData(data, flip), rtol=1e-5, atol=1e-5)
+    p, h = model._computeHgivenV(data, flip, rng_step=4)
+    np.testing.assert_allclose(p, sig, rtol=1e-5, atol=1e-5)
+    assert p.shape == (data.shape[0], nmot, 1, data.shape[3] - mlen + 1)
+    np.testing.assert_allclose(p, o._computeHgivenV(data, flip)[0], rtol=RTOL, atol=1e-7)
+    u = hidden_uniforms(model.seed, 4, np.arange(11), nmot, 196, 1 if flip else 0, KIND_API_H)
+    assert_samples(h, p.astype(np.float64), u)
+
+
+# ---- reference tests/testcrbm.py:319-504 ------------------------------------
+@pytest.mark.parametrize("kind", ["zeros", "ones", "random"])
+@pytest.mark.parametrize("ds", [False, True])
+def test_topdown(kind, ds):
+    nseq, seqlen, nmot, mlen = 11, 200, 10, 5
+    rng = np.random.default_rng(8)
+    shape = (nseq, nmot, 1, seqlen - mlen + 1)
+
+    def hid():
+        if kind == "zeros":
+            return np.zeros(shape, dtype="float32")
+        if kind == "ones":
+            return np.ones(shape, dtype="float32")
+        return rng.binomial(1, 0.1, size=shape).astype("float32")
+
+    model, o = make_pair(nmot, mlen)
+    if kind == "zeros":
+        model.c.set_value(np.zeros((1, 4), dtype=np.float32))
+        o.c = np.zeros((1, 4))
+    data, datap = hid(), (hid() if ds else None)
+    oa = model._topDownActivity(data, datap)
+    op = model._topDownProbabilityOfHidden(data, datap)
+    op2, sample = model._computeVgivenH(data, datap, rng_step=2)
+    assert oa.shape == (nseq, 1, 4, seqlen) and op.shape == oa.shape and op2.shape == oa.shape
+    np.testing.assert_equal(op, op2)                                     # :337
+    ctrl = o._topDownActivity(data, datap)                               # pinned by test_oracle
+    np.testing.assert_allclose(oa, ctrl, rtol=1e-5, atol=1e-5)           # :389
+    ctrl_p = np.exp(ctrl) / np.exp(ctrl).sum(axis=2, keepdims=True)
+    np.testing.assert_allclose(ctrl_p, op, rtol=1e-5, atol=1e-5)         # :397
+    if kind == "zeros":
+        np.testing.assert_allclose(0.25, op, rtol=1e-5, atol=1e-5)       # :340, :363
+    np.testing.assert_array_equal(sample.sum(axis=2), 1.0)
+    u = visible_uniforms(model.seed, 2, np.arange(nseq), seqlen, KIND_API_V)
+    ref = o._topDownSample(ctrl_p, u)
+    bad = (sample != ref).any(axis=2)[:, 0]
+    gap = np.min(np.abs(np.cumsum(ctrl_p[:, 0], axis=1) - u[:, None, :]), axis=1)
+    assert np.all(gap[bad] < 1e-6) and bad.mean() < 1e-3
+
+
+@pytest.mark.parametrize("ds", [False, True])
+def test_topdown_full(ds):
+    """tests/testcrbm.py:257-316."""
+    data = synthetic_onehot(11, 200, seed=9)
+    model, _ = make_pair(10, 5, ds=ds, bshift=4.0)
+    _, h1 = model._computeHgivenV(data, False, rng_step=1)
+    h2 = model._computeHgivenV(data, True, rng_step=1)[1] if ds else None
+    assert h1.sum() > 0
+    poutput, soutput = model._computeVgivenH(h1, h2, rng_step=1)
+    assert poutput.shape == data.shape
+    np.testing.assert_allclose(poutput.sum(), data.shape[0] * data.shape[3], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(soutput.sum(), data.shape[0] * data.shape[3], rtol=1e-4, atol=1e-4)
+
+
+# ---- evaluation: tests/testcrbm.py:116-146, :507-519 -------------------------
+@pytest.mark.parametrize("ds", [False, True])
+def test_hitprobs_free_energy_pfms(ds, tmp_path):
+    data = synthetic_onehot(100, 200, seed=10)
+    model, o = make_pair(10, 15, ds=ds, bshift=3.0)
+    pred = model.motifHitProbs(data)
+    assert pred.shape == (100, 10, 1, 186)                               # :129
+    np.testing.assert_allclose(pred, o.motifHitProbs(data), rtol=RTOL, atol=1e-7)
+    fe = model.freeEnergy(data)
+    assert fe.shape == (100,)                                            # :519
+    np.testing.assert_allclose(fe, o.freeEnergy(data), rtol=RTOL)
+    np.testing.assert_allclose(model.freeEnergy(data, permotif=True), o.freeEnergy(data, True), rtol=RTOL)
+    pfms = model.getPFMs()
+    assert len(pfms) == 10
+    for i in range(10):
+        np.testing.assert_allclose(pfms[i].sum(), 15)                    # :146
+        np.testing.assert_allclose(pfms[i], o.getPFMs()[i], rtol=1e-5)
+    np.testing.assert_allclose(model._evaluateParams(), o.evaluateParams(), rtol=1e-5)
+    mfe, nmh = model._evaluateData(data)
+    omfe, onmh = o.evaluateData(data, eval_step=0)
+    np.testing.assert_allclose(mfe, omfe, rtol=RTOL)
+    np.testing.assert_allclose(nmh, onmh, rtol=1e-3, atol=1e-6)
+    # save / load round trip (tests/testcrbm.py:58-98)
+    fn = str(tmp_path / "model.pkl")
+    model.saveModel(fn)
+    from crbm_amd import CRBM
+    model2 = CRBM.loadModel(fn)
+    for attr in ("num_motifs", "motif_length", "epochs", "input_dims", "doublestranded", "batchsize",
+                 "momentum", "pooling", "cd_k", "rho", "lambda_rate"):
+        assert getattr(model, attr) == getattr(model2, attr)
+    np.testing.assert_allclose(model.motifs.get_value(), model2.motifs.get_value())
+    np.testing.assert_allclose(model2.motifHitProbs(data[:5]), pred[:5], rtol=1e-6)
+
+
+# ---- persistent chain (convRBM.py:397-408) -----------------------------------
+@pytest.mark.parametrize("K,M,ds,Lf", [(10, 15, False, 186), (10, 15, True, 200), (20, 15, True, 120),
+                                       (50, 25, False, 100), (3, 4, True, 17)])
+def test_gibbs_chain_matches_oracle(K, M, ds, Lf):
+    B = 24
+    model, o = make_pair(K, M, ds=ds, batchsize=B, Lf=Lf, wscale=1.5, bshift=5.0)
+    rng = np.random.default_rng(4)
+    h0 = rng.binomial(1, 0.05, size=(B, K, 1, Lf)).astype(np.float32)
+    hp0 = rng.binomial(1, 0.05, size=(B, K, 1, Lf)).astype(np.float32) if ds else None
+    model.set_fantasy(h0, hp0)
+    o.fantasy_h, o.fantasy_h_prime = h0.astype(np.float64), (hp0.astype(np.float64) if ds else None)
+    a, b = model.get_fantasy()
+    np.testing.assert_array_equal(a, h0)
+    model.gibbsSteps(1)
+    model.gibbsSteps(2)
+    o.gibbs_steps(3)
+    h, hp = model.get_fantasy()
+    assert o.fantasy_h.sum() > 0
+    assert (h != o.fantasy_h).mean() < 1e-4
+    if ds:
+        assert (hp != o.fantasy_h_prime).mean() < 1e-4
+    v = model.get_fantasy_visible()
+    np.testing.assert_array_equal(v.sum(axis=2), 1.0)
+    assert (v != o.last_v_model).mean() < 1e-4
+
+
+def test_gibbs_rejects_bad_state():
+    model, _ = make_pair(4, 5, ds=False, batchsize=2, Lf=10)
+    bad = np.full((2, 4, 1, 10), 0.5, dtype=np.float32)
+    with pytest.raises(Exception, match="0/1"):
+        model.set_fantasy(bad)
+    with pytest.raises(Exception, match="one-hot"):
+        model.motifHitProbs(np.zeros((2, 1, 4, 30), dtype=np.float32))
+
+
+# ---- the PCD-k update (convRBM.py:373-438) -------------------------------------
+@pytest.mark.parametrize("K,M,ds", [(10, 15, True), (10, 15, False), (4, 5, True), (20, 15, True), (50, 25, False)])
+def test_train_step_trace(K, M, ds):
+    B, Lf, n, L = 16, 40, 13, M + 57          # data batch != fantasy batch, lengths differ
+    model, o = make_pair(K, M, ds=ds, batchsize=B, Lf=Lf, cd_k=2, bshift=4.0, rho=0.02)
+    for step in range(3):
+        D = synthetic_onehot(n, L, seed=100 + step)
+        model._trainingFct(D)
+        o.train_step(D)
+        np.testing.assert_allclose(model.motifs.get_value(), o.W, rtol=RTOL, atol=2e-6)
+        np.testing.assert_allclose(model.bias.get_value(), o.b, rtol=RTOL, atol=2e-6)
+        np.testing.assert_allclose(model.c.get_value(), o.c, rtol=RTOL, atol=2e-6)
+        h, hp = model.get_fantasy()
+        assert (h != o.fantasy_h).mean() < 1e-3
+    vW, vb, vc = model.get_velocities()
+    np.testing.assert_allclose(vW, o.vW, rtol=1e-3, atol=2e-6)
+    np.testing.assert_allclose(vc, o.vc, rtol=1e-3, atol=2e-6)
+
+
+def test_host_reduced_data_parallel_equals_single():
+    """a G-rank step on N rows == the 1-rank step on the same rows.
+    Two handles on one GPU play two ranks; the host sums their packed buffers
+    (what the RCCL all-reduce does) and both apply the same update."""
+    import ctypes
+    from crbm_amd._lib import fptr
+    K, M, ds, B, Lf, n, L = 10, 15, True, 16, 30, 12, 60
+    single, o = make_pair(K, M, ds=ds, batchsize=B, Lf=Lf, cd_k=1, bshift=4.0)
+    D = synthetic_onehot(n, L, seed=31)
+    single._trainingFct(D)
+    ranks = []
+    for r in range(2):
+        m, _ = make_pair(K, M, ds=ds, batchsize=B, Lf=Lf, cd_k=1, bshift=4.0)
+        m.rank, m.world_size = r, 2
+        ranks.append(m)
+    sums = []
+    for r, m in enumerate(ranks):
+        h = m._h()
+        cnt = m._lib.crbm_sums_count(h)
+        buf = np.zeros(cnt, dtype=np.float32)
+        lo, hi = m._shard_rows(0, n)
+        rows = np.ascontiguousarray(D[lo:hi])
+        m._call("crbm_train_local", fptr(rows), hi - lo, L, fptr(buf))
+        sums.append(buf)
+    total = (sums[0].astype(np.float64) + sums[1]).astype(np.float32)
+    for m in ranks:
+        m._call("crbm_train_apply", fptr(total), L)
+        np.testing.assert_allclose(m.motifs.get_value(), single.motifs.get_value(), rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(m.bias.get_value(), single.bias.get_value(), rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(m.c.get_value(), single.c.get_value(), rtol=1e-5, atol=1e-7)
+    hs, _ = single.get_fantasy()
+    h0, _ = ranks[0].get_fantasy()
+    h1, _ = ranks[1].get_fantasy()
+    np.testing.assert_array_equal(np.concatenate([h0, h1]), hs)          # identical samples
+
+
+def test_rccl_single_rank_communicator():
+    """The RCCL path with a 1-rank communicator must reproduce the plain step."""
+    import ctypes
+    from crbm_amd import _lib, dist
+    a, _ = make_pair(10, 15, batchsize=8, Lf=30, cd_k=1, bshift=4.0)
+    b, _ = make_pair(10, 15, batchsize=8, Lf=30, cd_k=1, bshift=4.0)
+    uid = dist.exchange_unique_id(0, 1)
+    buf = (ctypes.c_uint8 * _lib.UNIQUE_ID_BYTES).from_buffer_copy(uid)
+    b._call("crbm_comm_init", buf, 1, 0)
+    D = synthetic_onehot(8, 50, seed=2)
+    a._trainingFct(D)
+    b._trainingFct(D)
+    np.testing.assert_array_equal(a.motifs.get_value(), b.motifs.get_value())
+    b._call("crbm_comm_destroy")
+
+
+# ---- fit(): tests/testcrbm.py:100-114 ------------------------------------------
+@pytest.mark.parametrize("ds", [True, False])
+def test_training_fit(ds, capsys):
+    from crbm_amd import CRBM
+    data = synthetic_onehot(100, 200, seed=12)
+    model = CRBM(num_motifs=10, motif_length=15, doublestranded=ds, epochs=1, seed=1)
+    w0 = model.motifs.get_value()
+    model.fit(data)
+    model.trainModel(data, data[:10])
+    out = capsys.readouterr().out
+    assert "BatchSize: 20" in out and "Epoch 0: FE=" in out and "Training finished after" in out
+    w1 = model.motifs.get_value()
+    assert np.isfinite(w1).all() and not np.array_equal(w0, w1)
+    c = model.c.get_value()
+    np.testing.assert_allclose(c[0], c[0, ::-1], atol=1e-6)             # symmetrised letter statistics
+
+
+def test_fit_matches_oracle_one_epoch():
+    """Config #1 plumbing shape at small scale: resident data set + batch loop."""
+    K, M = 6, 9
+    model, o = make_pair(K, M, ds=True, batchsize=20, cd_k=5, Lf=200, bshift=4.0, epochs=1)
+    data = synthetic_onehot(50, 60, seed=13)       # 3 batches, last one short
+    model.epochs = 1
+    model.fit(data)
+    for lo, hi in o._iterateBatchIndices(50, 20):
+        o.train_step(data[lo:hi])
+    np.testing.assert_allclose(model.motifs.get_value(), o.W, rtol=RTOL, atol=5e-6)
+    np.testing.assert_allclose(model.bias.get_value(), o.b, rtol=RTOL, atol=5e-6)
+
+
+# ---- golden fixtures ---------------------------------------------------------------
+def test_golden_fixtures(golden_dir):
+    from crbm_amd import CRBM
+    g = np.load(os.path.join(golden_dir, "crbm_golden.npz"))
+    for tag in ("ss", "ds"):
+        ds = tag == "ds"
+        K, M = int(g[tag + "_K"]), int(g[tag + "_M"])
+        m = CRBM(K, M, doublestranded=ds, batchsize=int(g[tag + "_B"]), cd_k=int(g[tag + "_cdk"]),
+                 fantasy_hidden_len=int(g[tag + "_Lf"]), seed=int(g[tag + "_seed"]), rho=float(g[tag + "_rho"]))
+        m.motifs.set_value(g[tag + "_W"]); m.bias.set_value(g[tag + "_b"]); m.c.set_value(g[tag + "_c"])
+        D = g[tag + "_D"]
+        np.testing.assert_allclose(m._bottomUpActivity(D), g[tag + "_act"], rtol=RTOL, atol=1e-5)
+        np.testing.assert_allclose(m._bottomUpActivity(D, True), g[tag + "_act_rc"], rtol=RTOL, atol=1e-5)
+        np.testing.assert_allclose(m.motifHitProbs(D), g[tag + "_hit"], rtol=RTOL, atol=1e-7)
+        np.testing.assert_allclose(m.freeEnergy(D), g[tag + "_fe"], rtol=RTOL)
+        np.testing.assert_allclose(m._topDownProbabilityOfHidden(g[tag + "_h"], g[tag + "_hp"] if ds else None),
+                                   g[tag + "_pv"], rtol=RTOL, atol=1e-7)
+        for step in range(int(g[tag + "_steps"])):
+            m._trainingFct(D)
+        np.testing.assert_allclose(m.motifs.get_value(), g[tag + "_W_after"], rtol=RTOL, atol=5e-6)
+        np.testing.assert_allclose(m.bias.get_value(), g[tag + "_b_after"], rtol=RTOL, atol=5e-6)
+        np.testing.assert_allclose(m.c.get_value(), g[tag + "_c_after"], rtol=RTOL, atol=5e-6)
+        h, _ = m.get_fantasy()
+        assert (h != g[tag + "_fh_after"]).mean() < 1e-3

@@ -1,0 +1,97 @@
+"""CPU-only tests of the host side: the C-ABI library loads and exports every
+symbol include/crbm_amd.h declares, the CRBM class validates like the
+reference (tests/testcrbm.py:14-98), the product path never touches the oracle
+and fails loudly without a GPU."""
+import os
+import re
+import warnings
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_abi_exports_every_declared_symbol():
+    from crbm_amd import _lib
+    header = open(os.path.join(ROOT, "include", "crbm_amd.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(crbm_[a-z_]+)\s*\(", header))
+    declared -= {"crbm_status", "crbm_config", "crbm_handle", "crbm_launch_info"}
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.load()                      # binds every symbol or raises
+    assert lib.crbm_abi_version() == 1
+    assert lib.crbm_device_count() >= 0
+
+
+def test_crbm_parametervalues():
+    """reference tests/testcrbm.py:14-56."""
+    from crbm_amd import CRBM
+    bad = [dict(num_motifs=0, motif_length=5), dict(num_motifs=1, motif_length=0),
+           dict(num_motifs=1, motif_length=1, epochs=-1), dict(num_motifs=1, motif_length=1, input_dims=-1),
+           dict(num_motifs=1, motif_length=1, batchsize=0), dict(num_motifs=1, motif_length=1, learning_rate=0.0),
+           dict(num_motifs=1, motif_length=1, momentum=-1.), dict(num_motifs=1, motif_length=1, momentum=1.1),
+           dict(num_motifs=1, motif_length=1, pooling=0), dict(num_motifs=1, motif_length=1, cd_k=0),
+           dict(num_motifs=1, motif_length=1, rho=-1.), dict(num_motifs=1, motif_length=1, rho=1.1),
+           dict(num_motifs=1, motif_length=1, lambda_rate=-.1)]
+    for kw in bad:
+        with pytest.raises(Exception):
+            CRBM(**kw)
+    with pytest.warns(UserWarning):
+        CRBM(num_motifs=1, motif_length=1, input_dims=3)
+    CRBM(num_motifs=1, motif_length=1, epochs=0)            # legal (convRBM.py:79)
+
+
+def test_crbm_creation_and_reload(tmp_path):
+    """reference tests/testcrbm.py:58-98 (host state only: no GPU call is made)."""
+    from crbm_amd import CRBM
+    model = CRBM(num_motifs=2, motif_length=5)
+    W, b, c = model.motifs.get_value(), model.bias.get_value(), model.c.get_value()
+    assert W.shape == (2, 1, 4, 5) and b.shape == (1, 2) and c.shape == (1, 4)
+    assert W.dtype == np.float32 and b.dtype == np.float32
+    fn = str(tmp_path / "model.pkl")
+    model.saveModel(fn)
+    model2 = CRBM.loadModel(fn)
+    for attr in ("num_motifs", "motif_length", "epochs", "input_dims", "doublestranded", "batchsize",
+                 "momentum", "pooling", "cd_k", "rho", "lambda_rate"):
+        assert getattr(model, attr) == getattr(model2, attr)
+    np.testing.assert_allclose(W, model2.motifs.get_value())
+    np.testing.assert_allclose(b, model2.bias.get_value())
+    np.testing.assert_allclose(c, model2.c.get_value())
+    # reference pickle layout (convRBM.py:186-204)
+    import joblib
+    params, hyper = joblib.load(fn)
+    assert len(params) == 3 and len(hyper) == 13 and hyper[-1] == "entropy"
+
+
+def test_init_matches_reference_formulas():
+    from crbm_amd import CRBM
+    m = CRBM(10, 15)
+    np.testing.assert_allclose(m.bias.get_value(), -9.0099, atol=1e-4)     # norm.ppf(0.01, 0, sqrt(15))
+    assert CRBM(10, 15, rho=0.0).rho == 1.0 / 300                          # convRBM.py:136-140
+    assert CRBM(10, 15, rho=0.0, doublestranded=False).rho == 1.0 / 150
+    assert m._iterateBatchIndices(45, 20) == [[0, 20], [20, 40], [40, 45]]
+    assert CRBM.trainModel is CRBM.fit
+    assert "Number of motifs: 10" in repr(m)
+    with pytest.raises(ValueError):
+        m.motifs.set_value(np.zeros((3, 3)))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "crbm_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text, f
+                assert "oracle/" not in text.replace("oracle/crbm_oracle.py", ""), f
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="GPU present")
+def test_fails_loudly_without_gpu():
+    from crbm_amd import CRBM
+    m = CRBM(4, 5)
+    with pytest.raises(Exception, match="no HIP device|no CPU"):
+        m.motifHitProbs(np.zeros((1, 1, 4, 20), dtype=np.float32))
+    with pytest.raises(Exception):
+        m.fit(np.zeros((2, 1, 4, 20), dtype=np.float32))
