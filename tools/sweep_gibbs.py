@@ -1,0 +1,44 @@
+"""Development tool: times the Gibbs kernel under different launch geometries
+(env overrides read by crbm_create).  Usage: python tools/sweep_gibbs.py [cfg]"""
+import ctypes
+import itertools
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def time_cfg(cfg, env, steps=300):
+    for k, v in env.items():
+        os.environ[k] = str(v)
+    model = bench.build_model(cfg, 1, 0)
+    try:
+        model._h()
+    except Exception as e:
+        return None, str(e)
+    model._call("crbm_gibbs_steps", 10)
+    ms = ctypes.c_float()
+    model._call("crbm_time_gibbs", cfg["k"], 30, ctypes.byref(ms))
+    model._call("crbm_time_gibbs", cfg["k"], steps, ctypes.byref(ms))
+    from crbm_amd import _lib
+    info = _lib.CrbmLaunchInfo()
+    model._lib.crbm_get_launch_info(model._handle, ctypes.byref(info))
+    h, _ = model.get_fantasy()
+    res = (1e3 * ms.value / steps, info.gibbs_grid, info.gibbs_block, info.gibbs_seqs_per_tile, info.gibbs_lds_bytes,
+           info.group, float(h.mean()))
+    for k in env:
+        os.environ.pop(k, None)
+    del model
+    return res, None
+
+
+if __name__ == "__main__":
+    cfg = bench.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "cfg2"]
+    print("us/launch grid block S lds G activity")
+    for S, thr, G in itertools.product([2, 4, 5, 8, 16], [256, 512], [2, 3]):
+        res, err = time_cfg(cfg, {"CRBM_GIBBS_S": S, "CRBM_GIBBS_THREADS": thr, "CRBM_GROUP": G})
+        print("S=%d thr=%d G=%d ->" % (S, thr, G), res if res else err, flush=True)
