@@ -55,6 +55,7 @@ _U8P = ctypes.POINTER(ctypes.c_uint8)
 # name -> (restype, argtypes); every symbol declared in include/crbm_amd.h
 SIGNATURES = {
     "crbm_create": (_I32, [ctypes.POINTER(CrbmConfig), ctypes.POINTER(_H)]),
+    "crbm_precompile": (_I32, [ctypes.POINTER(CrbmConfig)]),
     "crbm_destroy": (_I32, [_H]),
     "crbm_last_error": (ctypes.c_char_p, [_H]),
     "crbm_abi_version": (_I32, []),

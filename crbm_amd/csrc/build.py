@@ -2,9 +2,10 @@
 
     python -m crbm_amd.csrc.build        # or: python crbm_amd/csrc/build.py
 
-One object per instantiated motif-quad count (compiled in parallel), plus the
-host API; everything links into crbm_amd/csrc/libcrbm_hip.so.  Objects are
-rebuilt only when a source they depend on is newer.
+The host API and the model-independent kernels are compiled ahead of time into
+crbm_amd/csrc/libcrbm_hip.so; the model-dependent kernels (crbm_kernels.h) are
+specialised per model with hiprtc when a handle is created and cached under
+crbm_amd/csrc/jit_cache/ (precompile() fills the cache without a GPU).
 """
 import os
 import subprocess
@@ -14,12 +15,11 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libcrbm_hip.so")
-NQS = [1, 2, 3, 4, 5, 6, 8, 10, 13, 16]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
-HEADERS = ["crbm_kernels.h", "crbm_layout.h", os.path.join("..", "..", "include", "crbm_amd.h")]
+HEADERS = ["crbm_kernels.h", "crbm_layout.h", "crbm_jit.h", os.path.join("..", "..", "include", "crbm_amd.h")]
 
 
 def _newer(target, deps):
@@ -46,14 +46,12 @@ def _compile(job):
 def build(verbose=True, jobs=None):
     os.makedirs(OBJ, exist_ok=True)
     work = [("crbm_api.hip", os.path.join(OBJ, "crbm_api.o"), [])]
-    for nq in NQS:
-        work.append(("crbm_kernels_inst.hip", os.path.join(OBJ, "kernels_nq%d.o" % nq), ["-DCRBM_NQ=%d" % nq]))
     jobs = jobs or min(8, os.cpu_count() or 4)
     with ThreadPoolExecutor(max_workers=jobs) as ex:
         results = list(ex.map(_compile, work))
     objs = [o for o, _ in results]
     if any(changed for _, changed in results) or _newer(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
+        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-lhiprtc", "-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed: %s\n%s\n%s" % (" ".join(cmd), r.stdout, r.stderr))
@@ -62,6 +60,26 @@ def build(verbose=True, jobs=None):
     elif verbose:
         print("up to date:", LIB)
     return LIB
+
+
+def precompile(configs, verbose=True):
+    """JIT-compile the kernels of the given models into the on-disk cache.
+    configs: iterable of dicts with num_motifs, motif_length, doublestranded,
+    batchsize, fantasy_hidden_len.  Needs no GPU."""
+    import ctypes
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from crbm_amd import _lib
+    lib = _lib.load()
+    for c in configs:
+        cfg = _lib.CrbmConfig(num_motifs=c["num_motifs"], motif_length=c["motif_length"], input_dims=4,
+                              doublestranded=int(c.get("doublestranded", 0)), batchsize=c.get("batchsize", 20),
+                              cd_k=1, pooling=1, fantasy_hidden_len=c.get("fantasy_hidden_len", 200),
+                              learning_rate=0.1, momentum=0.9, rho=0.01, lambda_rate=0.1, seed=0, device=0, reserved=0)
+        rc = lib.crbm_precompile(ctypes.byref(cfg))
+        if rc != 0:
+            raise RuntimeError("precompile failed for %s: %s" % (c, lib.crbm_last_error(None).decode()))
+        if verbose:
+            print("jit cache ready:", c)
 
 
 if __name__ == "__main__":

@@ -3,6 +3,7 @@
 // each entry point into kernel launches.  No torch, no Python types.
 #define CRBM_DEFINE_MISC_KERNELS
 #include "crbm_kernels.h"
+#include "crbm_jit.h"
 #include "../../include/crbm_amd.h"
 
 #include <dlfcn.h>
@@ -17,27 +18,6 @@
 #include <vector>
 
 using namespace crbm;
-
-namespace crbm {
-#define CRBM_DECL_TABLE(n) const KernelTable* kernel_table_nq##n();
-CRBM_DECL_TABLE(1) CRBM_DECL_TABLE(2) CRBM_DECL_TABLE(3) CRBM_DECL_TABLE(4) CRBM_DECL_TABLE(5)
-CRBM_DECL_TABLE(6) CRBM_DECL_TABLE(8) CRBM_DECL_TABLE(10) CRBM_DECL_TABLE(13) CRBM_DECL_TABLE(16)
-const KernelTable* kernel_table(int nq) {
-  switch (nq) {
-    case 1: return kernel_table_nq1();
-    case 2: return kernel_table_nq2();
-    case 3: return kernel_table_nq3();
-    case 4: return kernel_table_nq4();
-    case 5: return kernel_table_nq5();
-    case 6: return kernel_table_nq6();
-    case 8: return kernel_table_nq8();
-    case 10: return kernel_table_nq10();
-    case 13: return kernel_table_nq13();
-    case 16: return kernel_table_nq16();
-    default: return nullptr;
-  }
-}
-}  // namespace crbm
 
 namespace {
 
@@ -114,12 +94,15 @@ struct DevBuf {
 
 struct crbm_handle {
   crbm_config cfg;
-  int K = 0, M = 0, ds = 0, NQ = 0, NW = 0, G = 0, KP = 0, KAM = 0;
+  int K = 0, M = 0, ds = 0, NW = 0, G = 0, KAM = 0;
   int Lf = 0, Lv = 0, B = 0;
   int device = 0, num_cu = 256;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  const KernelTable* kt = nullptr;
+  ModelShape ms;
+  JitKernels jk;            // kernels specialised for this model (hiprtc)
+  float* d_tables = nullptr;   // precomputed LDS images (gather / top-down tables, c)
+  bool tables_dirty = true;
   // parameters and optimiser state
   float *dW = nullptr, *db = nullptr, *dc = nullptr, *dvW = nullptr, *dvb = nullptr, *dvc = nullptr;
   // persistent chains: K-bit masks per hidden position, letters of the last visible sample
@@ -164,16 +147,6 @@ int fail(crbm_handle* h, int code, const std::string& msg) {
     if (!(cond)) return fail(h, CRBM_ERR_INVALID, msg);   \
   } while (0)
 
-ModelView model_view(const crbm_handle* h) {
-  ModelView mv;
-  mv.W = h->dW; mv.b = h->db; mv.c = h->dc;
-  mv.K = h->K; mv.M = h->M; mv.G = h->G;
-  mv.ngroups = (h->M + h->G - 1) / h->G;
-  mv.rows = pow4(h->G);
-  mv.ds = h->ds;
-  return mv;
-}
-
 RngView rng_view(const crbm_handle* h, uint32_t step, uint32_t seq_offset) {
   RngView r;
   r.seed_lo = (uint32_t)(h->seed & 0xffffffffu);
@@ -183,7 +156,18 @@ RngView rng_view(const crbm_handle* h, uint32_t step, uint32_t seq_offset) {
   return r;
 }
 
-int tab_bytes(const crbm_handle* h) { return gather_table_floats(h->M, h->G, h->KP) * 4; }
+int tab_bytes(const crbm_handle* h) { return h->ms.TAB * 4; }
+
+// (re)build the LDS table images after a parameter change
+int ensure_tables(crbm_handle* h) {
+  if (!h->tables_dirty) return CRBM_OK;
+  TablesArgs t;
+  t.W = h->dW; t.b = h->db; t.c = h->dc; t.out = h->d_tables;
+  const unsigned grid = (unsigned)std::max(1, std::min((h->ms.TABLES_ALL + 255) / 256, h->num_cu * 4));
+  HIPCHK(jit_launch(h->jk.build_tables, t, grid, 1, 256, 0, h->stream));
+  h->tables_dirty = false;
+  return CRBM_OK;
+}
 
 int grid_for(long items, int threads, int cap) {
   long g = (items + threads - 1) / threads;
@@ -221,8 +205,10 @@ int encode_host(crbm_handle* h, const float* v, int n, int L, uint32_t* d_letter
 
 int launch_hgv(crbm_handle* h, const uint32_t* d_letters, int n, int L, int mode, float* act, float* prob,
                float* sample, unsigned long long* ones, uint32_t kind, uint32_t step, uint32_t seq_offset) {
+  int rc = ensure_tables(h);
+  if (rc) return rc;
   HgvArgs a;
-  a.mv = model_view(h);
+  a.tables = h->d_tables;
   a.letters = d_letters;
   a.n = n; a.L = L; a.Lh = L - h->M + 1; a.LW = letter_words(L);
   a.TS = tile_seqs(a.Lh, 4096);
@@ -231,49 +217,47 @@ int launch_hgv(crbm_handle* h, const uint32_t* d_letters, int n, int L, int mode
   a.act = act; a.prob = prob; a.sample = sample; a.ones = ones;
   a.rng = rng_view(h, step, seq_offset);
   a.kind = kind;
-  LaunchCfg c;
   const int ntiles = (n + a.TS - 1) / a.TS;
-  c.gx = (uint32_t)std::max(1, std::min(ntiles, h->num_cu * 8));
-  c.gy = 1; c.block = 256;
-  c.lds = (uint32_t)((mode == 2 ? 2 : 1) * tab_bytes(h));
-  c.stream = h->stream;
-  h->kt->hgv(a, c);
-  HIPCHK(hipGetLastError());
+  const unsigned gx = (unsigned)std::max(1, std::min(ntiles, h->num_cu * 8));
+  HIPCHK(jit_launch(h->jk.hgv, a, gx, 1, 256, (unsigned)((mode == 2 ? 2 : 1) * tab_bytes(h)), h->stream));
   return CRBM_OK;
 }
 
 int launch_gibbs(crbm_handle* h, int steps) {
+  int rc = ensure_tables(h);
+  if (rc) return rc;
   GibbsArgs a;
-  a.mv = model_view(h);
+  a.tables = h->d_tables;
   a.hm = h->d_hm; a.hmp = h->ds ? h->d_hmp : nullptr; a.vout = h->d_vf;
-  a.nchains = h->B; a.Lf = h->Lf; a.Lv = h->gl.Lv; a.Lhp = h->gl.Lhp; a.LWs = h->gl.LWs; a.S = h->gl.S;
-  a.divLv = make_fastdiv((uint32_t)a.Lv);
-  a.divLf = make_fastdiv((uint32_t)a.Lf);
-  a.divRow = make_fastdiv((uint32_t)(a.Lhp * h->gl.NW));
+  a.nchains = h->B; a.Lf = h->Lf; a.Lv = h->gl.Lv; a.S = h->gl.S;
+  a.nvb = h->gl.nvb; a.nhb = h->gl.nhb; a.Lrow = h->gl.Lrow; a.LWs = h->gl.LWs;
+  a.divVB = make_fastdiv((uint32_t)a.nvb);
+  a.divHB = make_fastdiv((uint32_t)a.nhb);
+  a.divRow = make_fastdiv((uint32_t)(a.Lrow * h->NW));
+  a.divLfw = make_fastdiv((uint32_t)(a.Lf * h->NW));
   a.steps = steps;
   a.rng = rng_view(h, h->gibbs_step, h->chain_offset);
-  LaunchCfg c;
-  c.gx = (uint32_t)h->gibbs_grid; c.gy = 1; c.block = (uint32_t)h->gibbs_threads;
-  c.lds = (uint32_t)h->gl.lds_bytes; c.stream = h->stream;
-  h->kt->gibbs(a, c);
-  HIPCHK(hipGetLastError());
+  HIPCHK(jit_launch(h->jk.gibbs, a, (unsigned)h->gibbs_grid, 1, (unsigned)h->gibbs_threads,
+                    (unsigned)h->gl.lds_bytes, h->stream));
   h->gibbs_step += (uint32_t)steps;
   return CRBM_OK;
 }
 
 // raw statistic sums of (letters, n, L) -> sums half (data or model)
 int launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool data_half) {
+  int rc = ensure_tables(h);
+  if (rc) return rc;
   const int want_sp = data_half ? 1 : 0;
-  const StatsLayout st = stats_layout(h->K, h->M, h->ds, h->NQ, h->G, want_sp, h->stats_threads);
+  const StatsLayout st = stats_layout(h->ms, want_sp, h->stats_threads);
   StatsArgs a;
-  a.mv = model_view(h);
+  a.tables = h->d_tables;
   a.letters = d_letters;
   a.n = n; a.L = L; a.Lh = L - h->M + 1; a.LW = letter_words(L);
   a.TS = tile_seqs(std::max(a.Lh, L), 8192);
   a.divLh = make_fastdiv((uint32_t)a.Lh);
   a.divL = make_fastdiv((uint32_t)L);
   a.want_sparsity = want_sp;
-  a.ntk = st.ntk; a.ntj = st.ntj; a.ntiles = st.ntiles;
+  a.ntiles = st.ntiles;
   a.row = st.row;
   a.off_vh0 = st.off_vh[0]; a.off_vh1 = st.off_vh[1]; a.off_h0 = st.off_h[0]; a.off_h1 = st.off_h[1];
   a.off_sw = st.off_sw; a.off_sb = st.off_sb; a.off_v = st.off_v;
@@ -282,11 +266,8 @@ int launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool d
   HIPCHK(h->partials.ensure((size_t)rows * st.row));
   a.partials = h->partials.p;
   HIPCHK(hipMemsetAsync(h->partials.p, 0, (size_t)rows * st.row * sizeof(float), h->stream));
-  LaunchCfg c;
-  c.gx = (uint32_t)rows; c.gy = (uint32_t)st.grid_y; c.block = (uint32_t)h->stats_threads;
-  c.lds = (uint32_t)st.lds_bytes; c.stream = h->stream;
-  h->kt->stats(a, c);
-  HIPCHK(hipGetLastError());
+  HIPCHK(jit_launch(h->jk.stats, a, (unsigned)rows, (unsigned)st.grid_y, (unsigned)h->stats_threads,
+                    (unsigned)st.lds_bytes, h->stream));
   ReduceArgs r;
   r.partials = h->partials.p;
   r.nrows = rows; r.row = st.row;
@@ -298,7 +279,7 @@ int launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool d
     r.skip_begin = h->sl.model_skip_begin; r.skip_len = h->sl.model_skip_len;
   }
   r.n_value = (float)n;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((st.row + 255) / 256), dim3(256), 0, h->stream, r);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((st.row + 3) / 4), dim3(256), 0, h->stream, r);
   HIPCHK(hipGetLastError());
   return CRBM_OK;
 }
@@ -313,6 +294,7 @@ int launch_update(crbm_handle* h, int L_data) {
   u.lr = h->cfg.learning_rate; u.momentum = h->cfg.momentum; u.rho = h->cfg.rho; u.lambda_rate = h->cfg.lambda_rate;
   hipLaunchKernelGGL(apply_update_kernel, dim3(1), dim3(256), 0, h->stream, u);
   HIPCHK(hipGetLastError());
+  h->tables_dirty = true;
   return CRBM_OK;
 }
 
@@ -367,10 +349,13 @@ int crbm_device_count(void) {
 
 const char* crbm_last_error(const crbm_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
-int crbm_create(const crbm_config* cfg, crbm_handle** out) {
+}  // extern "C"
+
+namespace {
+
+int validate_config(const crbm_config* cfg) {
   crbm_handle* h = nullptr;   // fail() routes to the create-error slot
-  if (!cfg || !out) return fail(h, CRBM_ERR_INVALID, "null argument");
-  *out = nullptr;
+  if (!cfg) return fail(h, CRBM_ERR_INVALID, "null argument");
   ARGCHK(cfg->num_motifs >= 1, "Number of motifs must be positive.");
   ARGCHK(cfg->num_motifs <= 64, "num_motifs > 64 is not supported by the HIP kernels");
   ARGCHK(cfg->motif_length >= 1, "Motif length must be positive.");
@@ -384,6 +369,77 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
   ARGCHK(cfg->learning_rate > 0.f, "learning_rate must be positive.");
   ARGCHK(cfg->momentum >= 0.f && cfg->momentum < 1.f, "momentum must be between zero and one.");
   ARGCHK(cfg->lambda_rate >= 0.f, "lambda_rate must be non-negative.");
+  return CRBM_OK;
+}
+
+// Gibbs launch geometry.  A thread owns 4 consecutive positions, a block owns
+// tiles of S whole chains (grid-stride).  Pick (S, threads) that keeps lanes
+// busy in both phases and splits the tiles evenly over the CUs.
+struct GibbsGeom {
+  int S, threads, grid, lds;
+};
+
+GibbsGeom choose_gibbs_geometry(const ModelShape& ms, int Lf, int B, int num_cu) {
+  const int forceS = env_int("CRBM_GIBBS_S", 0), forceT = env_int("CRBM_GIBBS_THREADS", 0);
+  GibbsGeom best{1, 256, 1, 0};
+  double best_score = -1.0;
+  for (int threads : {256, 128, 64}) {   // the kernels are compiled with __launch_bounds__(256)
+    if (forceT > 0 && threads != forceT) continue;
+    for (int S = 1; S <= std::min(B, 64); ++S) {
+      if (forceS > 0 && S != forceS) continue;
+      const GibbsLayout gl = gibbs_layout(ms, Lf, S);
+      if (gl.lds_bytes > 64 * 1024 && !(forceS > 0)) continue;
+      if (gl.lds_bytes > 160 * 1024 || (long)S * gl.Lrow * ms.NW >= (1 << 20)) continue;
+      const double iv = (double)S * gl.nvb, ih = (double)S * gl.nhb;
+      const double pv = std::ceil(iv / threads), ph = std::ceil(ih / threads);
+      const double util = (iv + 1.5 * ih) / ((pv + 1.5 * ph) * threads);      // h|v costs ~1.5x v|h per block
+      const double ntiles = std::ceil((double)B / S);
+      const double per_cu_tiles = ntiles / num_cu;
+      const double balance = per_cu_tiles / std::ceil(per_cu_tiles);
+      const int blocks_cu = std::max(1, std::min((160 * 1024) / gl.lds_bytes, 1024 / threads));   // <= 16 waves / CU
+      const double waves_cu = std::min(per_cu_tiles, (double)blocks_cu) * threads / 64.0;
+      const double occupancy = std::min(1.0, waves_cu / 8.0);                 // >= 2 waves / SIMD wanted
+      const double score = util * balance * (0.5 + 0.5 * occupancy) - 1e-4 * S;
+      if (score > best_score) {
+        best_score = score;
+        best = GibbsGeom{S, threads, (int)std::min(ntiles, (double)num_cu * blocks_cu), gl.lds_bytes};
+      }
+    }
+  }
+  const int forceG = env_int("CRBM_GIBBS_GRID", 0);
+  if (forceG > 0) best.grid = forceG;
+  return best;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Compile the kernels of a model into the on-disk cache without touching a GPU
+// (used by __graft_entry__.build()).
+int crbm_precompile(const crbm_config* cfg) {
+  int rc = validate_config(cfg);
+  if (rc) return rc;
+  const int ds = cfg->doublestranded ? 1 : 0;
+  int G = env_int("CRBM_GROUP", 0);
+  if (G < 1 || G > 4) G = choose_group(cfg->num_motifs, cfg->motif_length, ds, env_int("CRBM_TABLE_BUDGET", 40 * 1024));
+  const ModelShape ms = model_shape(cfg->num_motifs, cfg->motif_length, ds, G);
+  std::vector<char> code;
+  bool cached = false;
+  std::string file, err;
+  if (jit_compile(ms.K, ms.M, ms.DS, ms.G, &code, &cached, &file, &err) != 0) {
+    g_create_error = err;
+    return CRBM_ERR_HIP;
+  }
+  return CRBM_OK;
+}
+
+int crbm_create(const crbm_config* cfg, crbm_handle** out) {
+  crbm_handle* h = nullptr;   // fail() routes to the create-error slot
+  if (!cfg || !out) return fail(h, CRBM_ERR_INVALID, "null argument");
+  *out = nullptr;
+  int rc = validate_config(cfg);
+  if (rc) return rc;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(h, CRBM_ERR_NO_GPU, "no HIP device visible (this library has no CPU path)");
@@ -392,17 +448,17 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
   crbm_handle* hh = new crbm_handle();
   hh->cfg = *cfg;
   hh->K = cfg->num_motifs; hh->M = cfg->motif_length; hh->ds = cfg->doublestranded ? 1 : 0;
-  hh->NQ = instantiated_nq(nq_for(hh->K));
-  hh->KP = 4 * hh->NQ;
-  hh->NW = mask_words_for_nq(hh->NQ);
   hh->KAM = hh->K * 4 * hh->M;
   hh->Lf = cfg->fantasy_hidden_len; hh->Lv = hh->Lf + hh->M - 1; hh->B = cfg->batchsize;
   hh->seed = cfg->seed;
   hh->device = cfg->device;
-  hh->kt = kernel_table(hh->NQ);
   hh->sl = sums_layout(hh->K, hh->M);
+  // gather-table group size, derived shapes
+  hh->G = env_int("CRBM_GROUP", 0);
+  if (hh->G < 1 || hh->G > 4) hh->G = choose_group(hh->K, hh->M, hh->ds, env_int("CRBM_TABLE_BUDGET", 40 * 1024));
+  hh->ms = model_shape(hh->K, hh->M, hh->ds, hh->G);
+  hh->NW = hh->ms.NW;
   auto bail = [&](int code) { crbm_destroy(hh); return code; };
-  if (!hh->kt) { g_create_error = "no kernel specialisation"; delete hh; return CRBM_ERR_INVALID; }
   hipError_t e;
 #define TRY(expr)                                                                                 \
   if ((e = (expr)) != hipSuccess) {                                                               \
@@ -413,6 +469,22 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
   hipDeviceProp_t prop;
   TRY(hipGetDeviceProperties(&prop, hh->device));
   hh->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  // launch geometry, then the model-specific kernels (hiprtc; cached on disk)
+  const GibbsGeom geom = choose_gibbs_geometry(hh->ms, hh->Lf, hh->B, hh->num_cu);
+  hh->gl = gibbs_layout(hh->ms, hh->Lf, geom.S);
+  hh->gibbs_threads = geom.threads;
+  hh->gibbs_grid = geom.grid;
+  if (geom.lds <= 0) {
+    g_create_error = "model too large for the LDS-resident Gibbs kernel";
+    return bail(CRBM_ERR_INVALID);
+  }
+  {
+    std::string err;
+    if (jit_load(hh->K, hh->M, hh->ds, hh->G, &hh->jk, &err) != 0) {
+      g_create_error = "kernel specialisation failed: " + err;
+      return bail(CRBM_ERR_HIP);
+    }
+  }
   TRY(hipStreamCreateWithFlags(&hh->stream, hipStreamNonBlocking));
   TRY(hipEventCreate(&hh->ev0));
   TRY(hipEventCreate(&hh->ev1));
@@ -423,38 +495,17 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
   TRY(hipMemset(hh->dW, 0, kam * 4)); TRY(hipMemset(hh->dvW, 0, kam * 4));
   TRY(hipMemset(hh->db, 0, k * 4));   TRY(hipMemset(hh->dvb, 0, k * 4));
   TRY(hipMemset(hh->dc, 0, 16));      TRY(hipMemset(hh->dvc, 0, 16));
+  TRY(hipMalloc((void**)&hh->d_tables, (size_t)hh->ms.TABLES_ALL * 4));
   const size_t mwords = (size_t)hh->B * hh->Lf * hh->NW;
   TRY(hipMalloc((void**)&hh->d_hm, mwords * 4)); TRY(hipMemset(hh->d_hm, 0, mwords * 4));
   TRY(hipMalloc((void**)&hh->d_hmp, mwords * 4)); TRY(hipMemset(hh->d_hmp, 0, mwords * 4));
-  const size_t vwords = (size_t)hh->B * letter_words(hh->Lv);
+  const size_t vwords = (size_t)hh->B * hh->gl.LWs;
   TRY(hipMalloc((void**)&hh->d_vf, vwords * 4)); TRY(hipMemset(hh->d_vf, 0, vwords * 4));
   TRY(hipMalloc((void**)&hh->d_flags, 16)); TRY(hipMemset(hh->d_flags, 0, 16));
   TRY(hipMalloc((void**)&hh->d_ones, 16)); TRY(hipMemset(hh->d_ones, 0, 16));
   TRY(hipMalloc((void**)&hh->d_sums, (size_t)hh->sl.count * 4)); TRY(hipMemset(hh->d_sums, 0, (size_t)hh->sl.count * 4));
 #undef TRY
-  // gather-table group size
-  const int budget = env_int("CRBM_TABLE_BUDGET", 40 * 1024);
-  hh->G = env_int("CRBM_GROUP", 0);
-  if (hh->G < 1 || hh->G > 4) hh->G = choose_group(hh->M, hh->KP, hh->ds, budget);
-  // Gibbs launch geometry: chains per tile so that a tile keeps the block busy
-  // for several passes while several blocks still fit one CU's 160 KB LDS
-  hh->gibbs_threads = env_int("CRBM_GIBBS_THREADS", 256);
-  int S = env_int("CRBM_GIBBS_S", 0);
-  if (S < 1) {
-    S = std::max(1, std::min(16, (4 * hh->gibbs_threads) / hh->Lv));
-    while (S > 1 && gibbs_layout(hh->K, hh->M, hh->ds, hh->NQ, hh->G, hh->Lf, S).lds_bytes > 64 * 1024) --S;
-  }
-  S = std::min(S, hh->B);
-  hh->gl = gibbs_layout(hh->K, hh->M, hh->ds, hh->NQ, hh->G, hh->Lf, S);
-  if (hh->gl.lds_bytes > 160 * 1024 || (long)S * hh->gl.Lhp * hh->gl.NW >= (1 << 20)) {
-    g_create_error = "model too large for the LDS-resident Gibbs kernel";
-    crbm_destroy(hh);
-    return CRBM_ERR_INVALID;
-  }
-  const int ntiles = (hh->B + S - 1) / S;
-  const int per_cu = std::max(1, std::min(8, (160 * 1024) / std::max(1, hh->gl.lds_bytes)));
-  hh->gibbs_grid = env_int("CRBM_GIBBS_GRID", 0);
-  if (hh->gibbs_grid < 1) hh->gibbs_grid = std::min(ntiles, hh->num_cu * per_cu);
+  hh->tables_dirty = true;
   hh->stats_threads = 256;
   hh->stats_rows = env_int("CRBM_STATS_ROWS", 2 * hh->num_cu);
   *out = hh;
@@ -466,11 +517,12 @@ int crbm_destroy(crbm_handle* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
-  void* ptrs[] = {h->dW, h->db, h->dc, h->dvW, h->dvb, h->dvc, h->d_hm, h->d_hmp, h->d_vf, h->d_flags, h->d_ones, h->d_sums};
+  void* ptrs[] = {h->dW, h->db, h->dc, h->dvW, h->dvb, h->dvc, h->d_hm, h->d_hmp, h->d_vf, h->d_flags, h->d_ones, h->d_sums, h->d_tables};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   h->stage.release(); h->stage2.release(); h->out_a.release(); h->out_b.release(); h->out_c.release();
   h->letters.release(); h->dataset.release(); h->masks_tmp.release(); h->partials.release();
+  if (h->jk.module) (void)hipModuleUnload(h->jk.module);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -490,6 +542,7 @@ int crbm_set_params(crbm_handle* h, const float* W, const float* b, const float*
   HIPCHK(hipMemcpyAsync(h->db, b, (size_t)h->K * 4, hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(h->dc, c, 16, hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  h->tables_dirty = true;
   return CRBM_OK;
 }
 
@@ -569,7 +622,7 @@ int crbm_get_fantasy_visible(crbm_handle* h, float* v) {
   const size_t count = (size_t)h->B * 4 * h->Lv;
   HIPCHK(h->stage.ensure(count));
   DecodeArgs a;
-  a.letters = h->d_vf; a.v = h->stage.p; a.n = h->B; a.L = h->Lv; a.LW = letter_words(h->Lv);
+  a.letters = h->d_vf; a.v = h->stage.p; a.n = h->B; a.L = h->Lv; a.LW = h->gl.LWs;
   hipLaunchKernelGGL(decode_onehot_kernel, dim3(grid_for((long)h->B * h->Lv, 256, h->num_cu * 8)), dim3(256), 0, h->stream, a);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(v, h->stage.p, count * 4, hipMemcpyDeviceToHost, h->stream));
@@ -733,7 +786,7 @@ int crbm_v_given_h(crbm_handle* h, const float* hid, const float* hid_prime, int
   if (prob) HIPCHK(h->out_b.ensure(vcount));
   if (sample) HIPCHK(h->out_c.ensure(vcount));
   VghArgs a;
-  a.mv = model_view(h);
+  a.W = h->dW; a.c = h->dc; a.K = h->K; a.M = h->M;
   a.hid = h->stage.p; a.hidp = hid_prime ? h->stage2.p : nullptr;
   a.n = n; a.Lh = Lh; a.L = L;
   a.TS = tile_seqs(L, 4096);
@@ -781,19 +834,15 @@ static int free_energy_common(crbm_handle* h, const float* v, int n, int L, floa
   if (rc) return rc;
   HIPCHK(h->out_a.ensure((size_t)n));
   HIPCHK(h->out_b.ensure((size_t)n * h->K));
+  rc = ensure_tables(h);
+  if (rc) return rc;
   FeArgs a;
-  a.mv = model_view(h);
+  a.tables = h->d_tables;
   a.letters = h->letters.p;
   a.n = n; a.L = L; a.Lh = L - h->M + 1; a.LW = letter_words(L);
   a.fe = h->out_a.p; a.fem = h->out_b.p;
-  LaunchCfg c;
-  c.block = 256;
-  c.gx = (uint32_t)std::max(1, std::min((n + 3) / 4, h->num_cu * 8));
-  c.gy = 1;
-  c.lds = (uint32_t)((1 + h->ds) * tab_bytes(h));
-  c.stream = h->stream;
-  h->kt->free_energy(a, c);
-  HIPCHK(hipGetLastError());
+  const unsigned gx = (unsigned)std::max(1, std::min((n + 3) / 4, h->num_cu * 8));
+  HIPCHK(jit_launch(h->jk.free_energy, a, gx, 1, 256, (unsigned)((1 + h->ds) * tab_bytes(h)), h->stream));
   if (fe && (rc = copy_out(h, fe, h->out_a.p, (size_t)n))) return rc;
   if (fem && (rc = copy_out(h, fem, h->out_b.p, (size_t)n * h->K))) return rc;
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -937,8 +986,8 @@ int crbm_train_apply(crbm_handle* h, const float* sums_in, int32_t L_data) {
 
 int crbm_get_launch_info(const crbm_handle* h, crbm_launch_info* out) {
   if (!h || !out) return CRBM_ERR_INVALID;
-  const StatsLayout st = stats_layout(h->K, h->M, h->ds, h->NQ, h->G, 1, h->stats_threads);
-  out->nq = h->NQ; out->group = h->G;
+  const StatsLayout st = stats_layout(h->ms, 1, h->stats_threads);
+  out->nq = h->ms.NQ; out->group = h->G;
   out->gibbs_grid = h->gibbs_grid; out->gibbs_block = h->gibbs_threads;
   out->gibbs_seqs_per_tile = h->gl.S; out->gibbs_lds_bytes = h->gl.lds_bytes;
   out->stats_grid_x = h->stats_rows; out->stats_grid_y = st.grid_y;
@@ -949,7 +998,7 @@ int crbm_get_launch_info(const crbm_handle* h, crbm_launch_info* out) {
 int64_t crbm_gibbs_state_bytes(const crbm_handle* h) {
   if (!h) return 0;
   const int64_t masks = (int64_t)h->B * h->Lf * h->NW * 4 * (1 + h->ds);
-  const int64_t vout = (int64_t)h->B * letter_words(h->Lv) * 4;
+  const int64_t vout = (int64_t)h->B * h->gl.LWs * 4;
   return 2 * masks + vout;   // masks read + written, last visible sample written
 }
 

@@ -1,0 +1,178 @@
+// Per-model kernel specialisation with hiprtc.
+//
+// The reference compiles its Theano graph when a CRBM is constructed
+// (convRBM.py:175, :453-515).  The MI355X-native counterpart: crbm_create
+// instantiates the kernel templates of crbm_kernels.h for this model's
+// Cfg<K,M,DS,G>, compiles them for gfx950 with hiprtc and loads the code
+// object.  Code objects are cached on disk next to the library
+// (csrc/jit_cache/crbm_<hash>.hsaco, keyed by the full source text and
+// options), so a configuration is compiled once per source revision;
+// __graft_entry__.build() pre-populates the cache for the BASELINE configs.
+#pragma once
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+namespace crbm {
+
+struct JitKernels {
+  hipModule_t module = nullptr;
+  hipFunction_t build_tables = nullptr, hgv = nullptr, gibbs = nullptr, stats = nullptr, free_energy = nullptr;
+  bool from_cache = false;
+  std::string cache_file;
+};
+
+inline std::string jit_dirname(const std::string& p) {
+  const size_t pos = p.find_last_of('/');
+  return pos == std::string::npos ? std::string(".") : p.substr(0, pos);
+}
+
+// Directory holding crbm_kernels.h / crbm_layout.h: next to this shared library.
+inline std::string jit_source_dir() {
+  if (const char* e = getenv("CRBM_KERNEL_SRC_DIR")) return e;
+  Dl_info info;
+  if (dladdr(reinterpret_cast<const void*>(&jit_source_dir), &info) && info.dli_fname) return jit_dirname(info.dli_fname);
+  return ".";
+}
+
+inline bool jit_read_file(const std::string& path, std::string* out) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) return false;
+  std::ostringstream ss;
+  ss << f.rdbuf();
+  *out = ss.str();
+  return true;
+}
+
+inline uint64_t jit_fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull) {
+  for (unsigned char ch : s) {
+    h ^= ch;
+    h *= 1099511628211ull;
+  }
+  return h;
+}
+
+inline std::string jit_stub(int K, int M, int DS, int G) {
+  char buf[2048];
+  snprintf(buf, sizeof(buf),
+           "#include \"crbm_kernels.h\"\n"
+           "using ModelCfg = crbm::Cfg<%d, %d, %d, %d>;\n"
+           "extern \"C\" __global__ void __launch_bounds__(256) crbm_build_tables(crbm::TablesArgs a) { crbm::build_tables_body<ModelCfg>(a); }\n"
+           "extern \"C\" __global__ void __launch_bounds__(256) crbm_hgv(crbm::HgvArgs a) { crbm::hgv_body<ModelCfg>(a); }\n"
+           "extern \"C\" __global__ void __launch_bounds__(256) crbm_gibbs(crbm::GibbsArgs a) { crbm::gibbs_body<ModelCfg>(a); }\n"
+           "extern \"C\" __global__ void __launch_bounds__(256) crbm_stats(crbm::StatsArgs a) { crbm::stats_body<ModelCfg>(a); }\n"
+           "extern \"C\" __global__ void __launch_bounds__(256) crbm_free_energy(crbm::FeArgs a) { crbm::free_energy_body<ModelCfg>(a); }\n",
+           K, M, DS, G);
+  return buf;
+}
+
+// Compile (or fetch from the cache) the code object; no device needed.
+inline int jit_compile(int K, int M, int DS, int G, std::vector<char>* code, bool* from_cache,
+                       std::string* cache_file, std::string* err) {
+  const std::string dir = jit_source_dir();
+  std::string kernels, layout;
+  if (!jit_read_file(dir + "/crbm_kernels.h", &kernels) || !jit_read_file(dir + "/crbm_layout.h", &layout)) {
+    *err = "kernel sources not found in " + dir + " (set CRBM_KERNEL_SRC_DIR)";
+    return -1;
+  }
+  const std::string stub = jit_stub(K, M, DS, G);
+  const std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+                                         "-I" + dir, "-I/opt/rocm/include"};
+  int rtc_major = 0, rtc_minor = 0;
+  hiprtcVersion(&rtc_major, &rtc_minor);
+  uint64_t h = jit_fnv1a(stub);
+  h = jit_fnv1a(kernels, h);
+  h = jit_fnv1a(layout, h);
+  for (const auto& o : opts)
+    if (o.rfind("-I", 0) != 0) h = jit_fnv1a(o, h);
+  h = jit_fnv1a(std::to_string(rtc_major) + "." + std::to_string(rtc_minor), h);
+  std::string cdir = dir + "/jit_cache";
+  if (const char* e = getenv("CRBM_JIT_CACHE")) cdir = e;
+  char name[64];
+  snprintf(name, sizeof(name), "/crbm_%016llx.hsaco", (unsigned long long)h);
+  const std::string cfile = cdir + name;
+  if (cache_file) *cache_file = cfile;
+  std::string cached;
+  if (!getenv("CRBM_JIT_NOCACHE") && jit_read_file(cfile, &cached) && cached.size() > 64) {
+    code->assign(cached.begin(), cached.end());
+    *from_cache = true;
+    return 0;
+  }
+  *from_cache = false;
+  hiprtcProgram prog = nullptr;
+  if (hiprtcCreateProgram(&prog, stub.c_str(), "crbm_model.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
+    *err = "hiprtcCreateProgram failed";
+    return -1;
+  }
+  std::vector<const char*> copts;
+  for (const auto& o : opts) copts.push_back(o.c_str());
+  const hiprtcResult r = hiprtcCompileProgram(prog, (int)copts.size(), copts.data());
+  if (r != HIPRTC_SUCCESS) {
+    size_t ls = 0;
+    hiprtcGetProgramLogSize(prog, &ls);
+    std::string log(ls, '\0');
+    if (ls) hiprtcGetProgramLog(prog, &log[0]);
+    *err = std::string("hiprtc: ") + hiprtcGetErrorString(r) + "\n" + log;
+    hiprtcDestroyProgram(&prog);
+    return -1;
+  }
+  size_t cs = 0;
+  hiprtcGetCodeSize(prog, &cs);
+  code->resize(cs);
+  hiprtcGetCode(prog, code->data());
+  hiprtcDestroyProgram(&prog);
+  // best-effort cache write (atomic rename); failures are not errors
+  mkdir(cdir.c_str(), 0755);
+  const std::string tmp = cfile + "." + std::to_string((long)getpid()) + ".tmp";
+  {
+    std::ofstream f(tmp, std::ios::binary);
+    if (f) {
+      f.write(code->data(), (std::streamsize)code->size());
+      f.close();
+      if (rename(tmp.c_str(), cfile.c_str()) != 0) unlink(tmp.c_str());
+    }
+  }
+  return 0;
+}
+
+inline int jit_load(int K, int M, int DS, int G, JitKernels* out, std::string* err) {
+  std::vector<char> code;
+  if (jit_compile(K, M, DS, G, &code, &out->from_cache, &out->cache_file, err) != 0) return -1;
+  hipError_t e = hipModuleLoadData(&out->module, code.data());
+  if (e != hipSuccess) {
+    *err = std::string("hipModuleLoadData: ") + hipGetErrorString(e);
+    return -1;
+  }
+  struct { const char* name; hipFunction_t* f; } syms[] = {
+      {"crbm_build_tables", &out->build_tables}, {"crbm_hgv", &out->hgv}, {"crbm_gibbs", &out->gibbs},
+      {"crbm_stats", &out->stats}, {"crbm_free_energy", &out->free_energy}};
+  for (auto& s : syms) {
+    e = hipModuleGetFunction(s.f, out->module, s.name);
+    if (e != hipSuccess) {
+      *err = std::string("hipModuleGetFunction(") + s.name + "): " + hipGetErrorString(e);
+      return -1;
+    }
+  }
+  return 0;
+}
+
+template <typename Args>
+inline hipError_t jit_launch(hipFunction_t f, const Args& args, unsigned gx, unsigned gy, unsigned block, unsigned lds,
+                             hipStream_t stream) {
+  Args copy = args;
+  void* params[] = {&copy};
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  return hipModuleLaunchKernel(f, gx, gy, 1, block, 1, 1, lds, stream, params, nullptr);
+}
+
+}  // namespace crbm

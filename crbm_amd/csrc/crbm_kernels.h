@@ -1,5 +1,12 @@
 // CDNA4 (gfx950) kernels of the CRBM hot path.  Wave64 throughout.
 //
+// The model-dependent kernels are templates over crbm::Cfg<K,M,DS,G> and are
+// compiled per model by hiprtc when a handle is created (crbm_jit.h) -- the
+// counterpart of the reference compiling its Theano graph at construction
+// (convRBM.py:175, :453-515).  K, M, the strand count and the table grouping
+// are therefore compile-time constants: every motif loop is unrolled into
+// registers and every LDS table offset is an instruction immediate.
+//
 // Design (details in DESIGN.md):
 //  * The visible layer is one-hot wherever the forward correlation is applied
 //    (reference sequences.py:28-31, convRBM.py:304-310), so a sequence is kept
@@ -7,10 +14,12 @@
 //    gather-add.  Letters are taken G at a time: LDS holds pre-summed rows
 //    T[g][letter-tuple][k], one ds_read_b128 feeds four motifs.
 //  * The hidden layer is binary wherever the transposed convolution is applied
-//    (convRBM.py:259-267), so chain state is a K-bit mask per hidden position
-//    and the top-down pass adds W[k,:,j] (one float4) per set bit.
-//  * One workgroup owns whole chains, so a k-step Gibbs chain runs entirely in
-//    LDS; HBM sees the masks once in and once out per launch.
+//    (convRBM.py:259-267), so chain state is a K-bit mask per hidden position.
+//    For small K*M the top-down pass is a dense walk over pre-summed tables
+//    indexed by 5-bit mask chunks; otherwise it adds W[k,:,j] per set bit.
+//  * One workgroup owns whole chains and one thread owns 4 consecutive
+//    positions, so a k-step Gibbs chain runs entirely in LDS/registers; HBM
+//    sees the masks once in and once out per launch.
 //  * MFMA is not used: the transposed conv has output width 4 and the forward
 //    has one-hot operands (BASELINE.json north_star).
 #pragma once
@@ -19,6 +28,11 @@
 #include "crbm_layout.h"
 
 namespace crbm {
+
+template <int I>
+struct IC {
+  static constexpr int value = I;
+};
 
 // ---------------------------------------------------------------------------
 // Philox-4x32-10 (Random123 constants); same counters as oracle/crbm_oracle.py
@@ -54,10 +68,19 @@ __device__ __forceinline__ uint32_t philox_pick(const Philox4& r, int i) {
   return (i & 2) ? hi : lo;
 }
 
+// 12-bit field I (0..9) of the 128-bit little-endian value v0 | v1<<32 | ...
+template <int I>
+__device__ __forceinline__ uint32_t philox_field12(const Philox4& r) {
+  constexpr int w = (12 * I) / 32, b = (12 * I) % 32;
+  if (b <= 20) return (r.v[w] >> b) & 0xFFFu;
+  return ((r.v[w] >> b) | (r.v[(w + 1) & 3] << ((32 - b) & 31))) & 0xFFFu;
+}
+
 __device__ __forceinline__ float u01(uint32_t r) { return (float)(r >> 8) * 5.9604644775390625e-8f; }
 
-__device__ __forceinline__ uint32_t rng_word2(uint32_t kind, uint32_t strand, uint32_t kgroup) {
-  return (kind << 28) | (strand << 24) | kgroup;
+// counter word 2: kind | strand | sub-stream (0 coarse, 1 fine) | group
+__device__ __forceinline__ uint32_t rng_word2(uint32_t kind, uint32_t strand, uint32_t sub, uint32_t group) {
+  return (kind << 28) | (strand << 24) | (sub << 16) | group;
 }
 
 __device__ __forceinline__ uint32_t fastdiv(uint32_t i, const FastDiv& f) {
@@ -73,60 +96,89 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // ---------------------------------------------------------------------------
-// Gather tables.  T[g][r][k] = sum_{t<G, j=gG+t<M} Wf[k][(r>>2t)&3][j]
-// (+ b[k] folded into group 0), Wf = W or rc(W) = W[k][3-a][M-1-j]
-// (convRBM.py:241, :285).  Pad columns k >= K get -1e30 in group 0 so that
-// sigmoid -> 0, softplus -> 0 and no bit is ever sampled there.
+// Sampling K hidden units from their activations (convRBM.py:259-267: h = 1 if
+// p > u).  The uniform of unit k is 24 bits wide, u = (coarse*4096 + fine) /
+// 2^24, where coarse and fine are the (k % 10)-th 12-bit fields of two Philox
+// calls shared by the 10 units of group k / 10.  Almost every decision is
+// settled by the coarse field alone: with e = exp(-x),
+//     (coarse + 1)(1 + e) <= 4096  =>  h = 1,      coarse (1 + e) > 4096  =>  h = 0,
+// and the fine call is made only when some lane of the wave lands in between
+// (2^-12 per unit).  Returns the K-bit mask; optionally the probabilities.
 // ---------------------------------------------------------------------------
-__device__ inline void build_gather_table(float* T, const ModelView& mv, int KP, bool rc) {
-  const int total = mv.ngroups * mv.rows * KP;
-  for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
-    const int k = idx % KP;
-    const int r = (idx / KP) % mv.rows;
-    const int g = idx / (KP * mv.rows);
-    float acc = 0.f;
-    if (k < mv.K) {
-      for (int t = 0; t < mv.G; ++t) {
-        const int j = g * mv.G + t;
-        if (j < mv.M) {
-          const int a = (r >> (2 * t)) & 3;
-          acc += rc ? mv.W[(k * 4 + (3 - a)) * mv.M + (mv.M - 1 - j)] : mv.W[(k * 4 + a) * mv.M + j];
-        }
+template <class C, bool WANT_P>
+__device__ __forceinline__ void sample_hidden(const float (&x)[C::KP], uint32_t n, uint32_t s, uint32_t kind,
+                                              uint32_t strand, const RngView& rng, uint32_t step,
+                                              uint32_t (&mask)[C::NW], float (&p)[C::KP]) {
+#pragma unroll
+  for (int w = 0; w < C::NW; ++w) mask[w] = 0u;
+#pragma unroll
+  for (int g = 0; g < C::NGRP; ++g) {
+    const Philox4 rc = philox4x32_10(n, s, rng_word2(kind, strand, 0, (uint32_t)g), step, rng.seed_lo, rng.seed_hi);
+    uint32_t amb = 0u;   // units of this group that need the fine field
+    auto unit = [&](auto I) {
+      constexpr int i = decltype(I)::value;
+      const int k = 10 * g + i;
+      if (k < C::K) {
+        const float e = __expf(-x[k]);
+        const float af = (float)philox_field12<i>(rc);
+        const float x1 = fmaf(af, e, af);          // coarse * (1 + e)
+        const float x2 = x1 + (1.0f + e);          // (coarse + 1) * (1 + e)
+        const uint32_t one = x2 <= 4096.0f ? 1u : 0u;
+        amb |= (x1 <= 4096.0f && !(x2 <= 4096.0f)) ? (1u << i) : 0u;
+        mask[k >> 5] |= one << (k & 31);
+        if (WANT_P) p[k] = __fdividef(1.0f, 1.0f + e);
       }
-      if (g == 0) acc += mv.b[k];
-    } else if (g == 0) {
-      acc = -1e30f;
+    };
+    unit(IC<0>{}); unit(IC<1>{}); unit(IC<2>{}); unit(IC<3>{}); unit(IC<4>{});
+    unit(IC<5>{}); unit(IC<6>{}); unit(IC<7>{}); unit(IC<8>{}); unit(IC<9>{});
+    if (__any(amb != 0u)) {
+      const Philox4 rf = philox4x32_10(n, s, rng_word2(kind, strand, 1, (uint32_t)g), step, rng.seed_lo, rng.seed_hi);
+      auto fix = [&](auto I) {
+        constexpr int i = decltype(I)::value;
+        const int k = 10 * g + i;
+        if (k < C::K) {
+          if (amb & (1u << i)) {
+            // P*4096 - coarse lies in [0,1) up to rounding; compare with fine/4096
+            const float t = 4096.0f / (1.0f + __expf(-x[k]));
+            const float frac = t - (float)philox_field12<i>(rc);
+            const uint32_t one = frac * 4096.0f > (float)philox_field12<i>(rf) ? 1u : 0u;
+            mask[k >> 5] |= one << (k & 31);
+          }
+        }
+      };
+      fix(IC<0>{}); fix(IC<1>{}); fix(IC<2>{}); fix(IC<3>{}); fix(IC<4>{});
+      fix(IC<5>{}); fix(IC<6>{}); fix(IC<7>{}); fix(IC<8>{}); fix(IC<9>{});
     }
-    T[idx] = acc;
   }
 }
 
 // M letters (2 bits each) starting at position s of a packed row.
-__device__ __forceinline__ uint64_t letter_window(const uint32_t* w, int s, int M) {
+template <int M>
+__device__ __forceinline__ uint64_t letter_window(const uint32_t* w, int s) {
   const int i = s >> 4;
   const int sh = (s & 15) * 2;
   const uint64_t lo = (uint64_t)w[i] | ((uint64_t)w[i + 1] << 32);
   uint64_t win = lo >> sh;
-  if (2 * M + sh > 64) win |= (uint64_t)w[i + 2] << (64 - sh);
+  if (2 * M + 30 > 64) {
+    if (sh > 0) win |= (uint64_t)w[i + 2] << (64 - sh);
+  }
   if (M < 32) win &= (1ull << (2 * M)) - 1ull;
   return win;
 }
 
-template <int NQ, bool ACCUMULATE = false>
-__device__ __forceinline__ void conv_gather(const float* T, uint64_t win, const ModelView& mv, float (&x)[4 * NQ]) {
-  constexpr int KP = 4 * NQ;
+// x[k] (+)= sum over letter groups of T[g][tuple][k]; b[k] is folded into group 0.
+template <class C, bool ACCUMULATE = false>
+__device__ __forceinline__ void conv_gather(const float* T, uint64_t win, float (&x)[C::KP]) {
   if (!ACCUMULATE) {
 #pragma unroll
-    for (int q = 0; q < KP; ++q) x[q] = 0.f;
+    for (int q = 0; q < C::KP; ++q) x[q] = 0.f;
   }
-  const int gb = 2 * mv.G;
-  const uint32_t rmask = (uint32_t)mv.rows - 1u;
-  for (int g = 0; g < mv.ngroups; ++g) {
-    const uint32_t r = (uint32_t)win & rmask;
-    win >>= gb;
-    const float4* row = reinterpret_cast<const float4*>(T + (size_t)(g * mv.rows + r) * KP);
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
+  for (int g = 0; g < C::NG; ++g) {
+    const uint32_t r = (uint32_t)(win >> (2 * C::G * g)) & (uint32_t)(C::ROWS - 1);
+    const float4* row = reinterpret_cast<const float4*>(T + (size_t)g * C::ROWS * C::KP) + (size_t)r * C::NQ;
+#pragma unroll
+    for (int q = 0; q < C::NQ; ++q) {
       const float4 t = row[q];
       x[4 * q + 0] += t.x;
       x[4 * q + 1] += t.y;
@@ -136,11 +188,595 @@ __device__ __forceinline__ void conv_gather(const float* T, uint64_t win, const 
   }
 }
 
-#ifdef CRBM_DEFINE_MISC_KERNELS
+// global precomputed tables -> LDS (plain float4 copy)
+template <int NFLOATS>
+__device__ __forceinline__ void copy_tables(float* dst, const float* src) {
+  static_assert(NFLOATS % 4 == 0, "tables are float4 granular");
+  const float4* s4 = reinterpret_cast<const float4*>(src);
+  float4* d4 = reinterpret_cast<float4*>(dst);
+  for (int i = threadIdx.x; i < NFLOATS / 4; i += blockDim.x) d4[i] = s4[i];
+}
+
 // ---------------------------------------------------------------------------
+// Tables, rebuilt whenever W, b or c change (set_params / apply_update):
+//  Tf[g][r][k]  = sum_{t<G, j=gG+t<M} W[k][(r>>2t)&3][j]  (+ b[k] in group 0)
+//  Tr           = same for rc(W) = W[k][3-a][M-1-j]       (convRBM.py:241,:285)
+//    pad columns k >= K get -1e30 in group 0: sigmoid -> 0, softplus -> 0.
+//  Tv[jr][ch][pat] (float4 over letters) = sum_{bit in pat} W[5ch+bit][:][M-1-jr]
+//  Tvr          = same for rc(W)                           (convRBM.py:279-287)
+//  Wt[jr][k]    (float4 over letters) = W[k][:][M-1-jr]    (sparse top-down)
+// ---------------------------------------------------------------------------
+struct TablesArgs {
+  const float* W;   // (K,4,M)
+  const float* b;   // (K)
+  const float* c;   // (4)
+  float* out;       // Cfg::TABLES_ALL floats
+};
+
+template <class C>
+__device__ void build_tables_body(const TablesArgs& a) {
+  constexpr int K = C::K, M = C::M;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < C::TABLES_ALL; idx += gridDim.x * blockDim.x) {
+    float val = 0.f;
+    const bool fwd = idx < C::TAB, rcg = idx >= C::OFF_TR && idx < C::OFF_TR + C::TAB;
+    if (fwd || rcg) {                                        // gather tables
+      const bool rc = rcg;
+      const int t0 = rc ? idx - C::OFF_TR : idx;
+      const int k = t0 % C::KP, r = (t0 / C::KP) % C::ROWS, g = t0 / (C::KP * C::ROWS);
+      if (k < K) {
+        for (int t = 0; t < C::G; ++t) {
+          const int j = g * C::G + t;
+          if (j < M) {
+            const int al = (r >> (2 * t)) & 3;
+            val += rc ? a.W[(k * 4 + (3 - al)) * M + (M - 1 - j)] : a.W[(k * 4 + al) * M + j];
+          }
+        }
+        if (g == 0) val += a.b[k];
+      } else if (g == 0) {
+        val = -1e30f;
+      }
+    } else if (idx < C::OFF_WT) {                            // dense top-down tables
+      const bool rc = C::DS && idx >= C::OFF_TVR;
+      const int t0 = idx - (rc ? C::OFF_TVR : C::OFF_TV);
+      const int al = t0 & 3, pat = (t0 >> 2) & 31, ch = (t0 >> 7) % C::NCH, jr = (t0 >> 7) / C::NCH;
+      for (int bit = 0; bit < 5; ++bit) {
+        const int k = 5 * ch + bit;
+        if (k < K && ((pat >> bit) & 1))
+          val += rc ? a.W[(k * 4 + (3 - al)) * M + jr] : a.W[(k * 4 + al) * M + (M - 1 - jr)];
+      }
+    } else if (idx < C::OFF_C) {                             // sparse scatter table
+      const int t0 = idx - C::OFF_WT;
+      const int al = t0 & 3, k = (t0 >> 2) % (C::NW * 32), jr = (t0 >> 2) / (C::NW * 32);
+      val = k < K ? a.W[(k * 4 + al) * M + (M - 1 - jr)] : 0.f;
+    } else {
+      val = a.c[idx - C::OFF_C];
+    }
+    a.out[idx] = val;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// h_given_v, dense outputs: _bottomUpActivity / _bottomUpProbability /
+// _bottomUpSample (convRBM.py:238-275) and motifHitProbs (:507-514).
+// mode 0: forward strand, 1: reverse-complement strand, 2: sigma(x + x').
+// ---------------------------------------------------------------------------
+struct HgvArgs {
+  const float* tables;
+  const uint32_t* letters;
+  int32_t n, L, Lh, LW;
+  int32_t TS;          // sequences per tile
+  FastDiv divLh;
+  int32_t mode;
+  float* act;
+  float* prob;
+  float* sample;
+  unsigned long long* ones;   // += number of sampled ones (may be null)
+  RngView rng;
+  uint32_t kind;
+};
+
+template <class C>
+__device__ void hgv_body(const HgvArgs& a) {
+  constexpr int KP = C::KP, K = C::K, M = C::M;
+  HIP_DYNAMIC_SHARED(float, smem);
+  float* T0 = smem;
+  float* T1 = smem + C::TAB;
+  copy_tables<C::TAB>(T0, a.tables + (a.mode == 1 ? C::OFF_TR : C::OFF_TF));
+  if (a.mode == 2) copy_tables<C::TAB>(T1, a.tables + C::OFF_TR);
+  __syncthreads();
+  const bool want_sample = (a.sample != nullptr) || (a.ones != nullptr);
+  const uint32_t strand = a.mode == 1 ? 1u : 0u;
+  unsigned long long cnt = 0;
+  const int ntiles = (a.n + a.TS - 1) / a.TS;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int n0 = tile * a.TS;
+    const int ns = min(a.TS, a.n - n0);
+    const uint32_t items = (uint32_t)ns * (uint32_t)a.Lh;
+    for (uint32_t i = threadIdx.x; i < items; i += blockDim.x) {
+      const uint32_t nl = fastdiv(i, a.divLh);
+      const int s = (int)(i - nl * (uint32_t)a.Lh);
+      const int nn = n0 + (int)nl;
+      const uint64_t win = letter_window<M>(a.letters + (size_t)nn * a.LW, s);
+      float x[KP];
+      conv_gather<C>(T0, win, x);
+      if (a.mode == 2) conv_gather<C, true>(T1, win, x);
+      uint32_t mask[C::NW];
+      float p[KP];
+      if (want_sample) {
+        sample_hidden<C, true>(x, a.rng.seq_offset + (uint32_t)nn, (uint32_t)s, a.kind, strand, a.rng, a.rng.step,
+                               mask, p);
+      } else {
+#pragma unroll
+        for (int k = 0; k < K; ++k) p[k] = sigmoidf_fast(x[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const size_t idx = ((size_t)nn * K + k) * a.Lh + s;
+        if (a.act) a.act[idx] = x[k];
+        if (a.prob) a.prob[idx] = p[k];
+        if (want_sample) {
+          const uint32_t hb = (mask[k >> 5] >> (k & 31)) & 1u;
+          if (a.sample) a.sample[idx] = (float)hb;
+          cnt += hb;
+        }
+      }
+    }
+  }
+  if (a.ones && cnt) atomicAdd(a.ones, cnt);
+}
+
+// ---------------------------------------------------------------------------
+// The persistent-chain kernel: `steps` Gibbs steps
+//   v ~ P(v|h,h')  (convRBM.py:317-325)   then   h,h' ~ P(h|v)  (:269-275)
+// for every chain of a tile, entirely in LDS (convRBM.py:397-408).
+// ---------------------------------------------------------------------------
+struct GibbsArgs {
+  const float* tables;
+  uint32_t* hm;        // [nchains][Lf][NW] in/out
+  uint32_t* hmp;       // reverse strand (ds) or null
+  uint32_t* vout;      // [nchains][LWs] letters of the last visible sample
+  int32_t nchains, Lf, Lv, S;
+  int32_t nvb, nhb;    // 4-position blocks per chain (visible, hidden)
+  int32_t Lrow;        // padded mask row (positions), multiple of 4
+  int32_t LWs;         // letter words per chain row
+  FastDiv divVB, divHB, divRow, divLfw;   // / nvb, / nhb, / (Lrow*NW), / (Lf*NW)
+  int32_t steps;
+  RngView rng;
+};
+
+// letter of one visible position from its 4 top-down activations
+__device__ __forceinline__ uint32_t sample_letter(float y0, float y1, float y2, float y3, float u) {
+  const float mx = fmaxf(fmaxf(y0, y1), fmaxf(y2, y3));
+  const float e0 = __expf(y0 - mx), e1 = __expf(y1 - mx), e2 = __expf(y2 - mx), e3 = __expf(y3 - mx);
+  const float t = u * ((e0 + e1) + (e2 + e3));
+  return (uint32_t)(t >= e0) + (uint32_t)(t >= e0 + e1) + (uint32_t)(t >= (e0 + e1) + e2);
+}
+
+template <class C>
+__device__ void gibbs_body(const GibbsArgs& a) {
+  constexpr int KP = C::KP, M = C::M, NW = C::NW, NCH = C::NCH;
+  HIP_DYNAMIC_SHARED(float, smem);
+  const float* Tf = smem + C::OFF_TF;
+  const float* Tr = smem + C::OFF_TR;
+  const float* cv = smem + C::OFF_C;
+  uint32_t* hm = reinterpret_cast<uint32_t*>(smem + C::TABLES);
+  uint32_t* hmp = hm + (size_t)a.S * a.Lrow * NW;
+  uint32_t* let = hmp + (C::DS ? (size_t)a.S * a.Lrow * NW : 0);
+
+  copy_tables<C::TABLES>(smem, a.tables);
+
+  const int rowW = a.Lrow * NW;
+  const int ntiles = (a.nchains + a.S - 1) / a.S;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int n0 = tile * a.S;
+    const int ns = min(a.S, a.nchains - n0);
+    __syncthreads();
+    // chain state -> zero-padded LDS rows (hidden position s sits at s + M-1)
+    for (uint32_t idx = threadIdx.x; idx < (uint32_t)(ns * rowW); idx += blockDim.x) {
+      const uint32_t nl = fastdiv(idx, a.divRow);
+      const uint32_t r = idx - nl * (uint32_t)rowW;
+      const int q = (int)(r / NW), w = (int)(r % NW);
+      const int s = q - (M - 1);
+      const bool in = s >= 0 && s < a.Lf;
+      const size_t g = ((size_t)(n0 + nl) * a.Lf + (in ? s : 0)) * NW + w;
+      hm[idx] = in ? a.hm[g] : 0u;
+      if (C::DS) hmp[idx] = in ? a.hmp[g] : 0u;
+    }
+    for (int idx = threadIdx.x; idx < ns * a.LWs; idx += blockDim.x) let[idx] = 0u;
+    for (int st = 0; st < a.steps; ++st) {
+      __syncthreads();
+      // ---- v | h : y[a,p] = c[a] + sum_{k,j} W[k,a,j] h[k,p-j] (+ rc strand) ----
+      for (uint32_t it = threadIdx.x; it < (uint32_t)(ns * a.nvb); it += blockDim.x) {
+        const uint32_t nl = fastdiv(it, a.divVB);
+        const int pb = (int)(it - nl * (uint32_t)a.nvb);
+        const int p0 = 4 * pb;
+        float y[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { y[i][0] = cv[0]; y[i][1] = cv[1]; y[i][2] = cv[2]; y[i][3] = cv[3]; }
+        if constexpr (C::DENSE) {
+          // masks p0 .. p0+M+2 (padded row), then one float4 table row per
+          // (filter column, 5-bit chunk) of each mask
+          constexpr int NMV = (M + 3 + 3) / 4;
+#pragma unroll
+          for (int strand = 0; strand <= C::DS; ++strand) {
+            const uint4* mrow = reinterpret_cast<const uint4*>((strand ? hmp : hm) + (size_t)nl * a.Lrow + p0);
+            const char* Tv = reinterpret_cast<const char*>(smem + (strand ? C::OFF_TVR : C::OFF_TV));
+            uint32_t off[4 * NMV][NCH];
+#pragma unroll
+            for (int v4 = 0; v4 < NMV; ++v4) {
+              const uint4 mm = mrow[v4];
+              const uint32_t m4[4] = {mm.x, mm.y, mm.z, mm.w};
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int ch = 0; ch < NCH; ++ch)
+                  off[4 * v4 + e][ch] = (5 * ch >= 4 ? (m4[e] >> (5 * ch - 4)) : (m4[e] << (4 - 5 * ch))) & 0x1F0u;
+            }
+#pragma unroll
+            for (int jr = 0; jr < M; ++jr)
+#pragma unroll
+              for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                  const float4 t = *reinterpret_cast<const float4*>(Tv + (jr * NCH + ch) * 512 + off[i + jr][ch]);
+                  y[i][0] += t.x; y[i][1] += t.y; y[i][2] += t.z; y[i][3] += t.w;
+                }
+          }
+        } else {
+          const float4* Wt = reinterpret_cast<const float4*>(smem + C::OFF_WT);   // [jr][slot] -> W[k][0..3][M-1-jr]
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const uint32_t* mrow = hm + (size_t)nl * rowW + (size_t)(p0 + i) * NW;
+            for (int jr = 0; jr < M; ++jr) {
+#pragma unroll
+              for (int w = 0; w < NW; ++w) {
+                uint32_t m = mrow[jr * NW + w];
+                while (m) {
+                  const int bit = __ffs(m) - 1;
+                  m &= m - 1;
+                  const float4 t = Wt[(jr * NW + w) * 32 + bit];
+                  y[i][0] += t.x; y[i][1] += t.y; y[i][2] += t.z; y[i][3] += t.w;
+                }
+              }
+            }
+            if (C::DS) {   // rc strand: rc(W)[k,a,j] = W[k,3-a,M-1-j]
+              const uint32_t* prow = hmp + (size_t)nl * rowW + (size_t)(p0 + i) * NW;
+              for (int jr = 0; jr < M; ++jr) {
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                  uint32_t m = prow[jr * NW + w];
+                  while (m) {
+                    const int bit = __ffs(m) - 1;
+                    m &= m - 1;
+                    const float4 t = Wt[((M - 1 - jr) * NW + w) * 32 + bit];
+                    y[i][0] += t.w; y[i][1] += t.z; y[i][2] += t.y; y[i][3] += t.x;
+                  }
+                }
+              }
+            }
+          }
+        }
+        // one Philox call serves the 4 positions of the block (convRBM.py:301-315)
+        const Philox4 r = philox4x32_10(a.rng.seq_offset + (uint32_t)(n0 + nl), (uint32_t)pb,
+                                        rng_word2(KIND_CHAIN_V, 0, 0, 0), a.rng.step + (uint32_t)st,
+                                        a.rng.seed_lo, a.rng.seed_hi);
+        uint32_t byte = 0u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint32_t l = sample_letter(y[i][0], y[i][1], y[i][2], y[i][3], u01(r.v[i]));
+          byte |= (p0 + i < a.Lv ? l : 0u) << (2 * i);
+        }
+        reinterpret_cast<unsigned char*>(let + (size_t)nl * a.LWs)[pb] = (unsigned char)byte;
+      }
+      __syncthreads();
+      // ---- h | v : x[k,s] = b[k] + sum_j W[k, letter[s+j], j]; h = [sigma(x) > u] ----
+      for (uint32_t it = threadIdx.x; it < (uint32_t)(ns * a.nhb); it += blockDim.x) {
+        const uint32_t nl = fastdiv(it, a.divHB);
+        const int s0 = 4 * (int)(it - nl * (uint32_t)a.nhb);
+        const uint32_t gn = a.rng.seq_offset + (uint32_t)(n0 + nl);
+        const uint32_t* lrow = let + (size_t)nl * a.LWs;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int s = s0 + i;
+          if (s < a.Lf) {
+            const uint64_t win = letter_window<M>(lrow, s);
+#pragma unroll
+            for (int strand = 0; strand <= C::DS; ++strand) {
+              float x[KP], p[KP];
+              conv_gather<C>(strand ? Tr : Tf, win, x);
+              uint32_t mask[NW];
+              sample_hidden<C, false>(x, gn, (uint32_t)s, KIND_CHAIN_H, (uint32_t)strand, a.rng,
+                                      a.rng.step + (uint32_t)st, mask, p);
+              uint32_t* dst = (strand ? hmp : hm) + (size_t)nl * rowW + (size_t)(s + M - 1) * NW;
+#pragma unroll
+              for (int w = 0; w < NW; ++w) dst[w] = mask[w];
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // LDS -> chain state
+    const uint32_t per = (uint32_t)(a.Lf * NW);
+    for (uint32_t idx = threadIdx.x; idx < (uint32_t)ns * per; idx += blockDim.x) {
+      const uint32_t nl = fastdiv(idx, a.divLfw);
+      const uint32_t r = idx - nl * per;
+      const size_t src = (size_t)nl * rowW + (size_t)(M - 1) * NW + r;
+      const size_t g = (size_t)(n0 + nl) * per + r;
+      a.hm[g] = hm[src];
+      if (C::DS) a.hmp[g] = hmp[src];
+    }
+    if (a.vout)
+      for (int idx = threadIdx.x; idx < ns * a.LWs; idx += blockDim.x)
+        a.vout[(size_t)n0 * a.LWs + idx] = let[idx];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Gradient statistics (convRBM.py:327-371 and the closed form of :440-451):
+// raw sums over (n,s) of
+//   P[k,s] * onehot[a,s+j]          -> vh   (per strand)
+//   P(1-P)[k,s] * onehot[a,s+j]     -> sw   (forward strand, if want_sparsity)
+//   P[k,s], P(1-P)[k,s]             -> h, sb
+//   onehot[a,p]                     -> v    (letter counts)
+// Phase A: one thread per hidden position computes P (and P') and parks it in
+// LDS.  Phase B: each wave owns one accumulator tile [4][JC][KC] in registers
+// for the whole kernel and streams every parked item through it; per-block
+// partial sums are written once at the end (deterministic order).
+// ---------------------------------------------------------------------------
+struct StatsArgs {
+  const float* tables;
+  const uint32_t* letters;
+  int32_t n, L, Lh, LW;
+  int32_t TS;
+  FastDiv divLh, divL;
+  int32_t want_sparsity;
+  int32_t ntiles;
+  int32_t row, off_vh0, off_vh1, off_h0, off_h1, off_sw, off_sb, off_v;
+  float* partials;     // [gridDim.x][row], zero-initialised by the host
+};
+
+template <class C>
+__device__ void stats_body(const StatsArgs& a) {
+  constexpr int KP = C::KP, K = C::K, M = C::M;
+  constexpr int NQC = C::NQC, KC = C::KC, JC = C::JC;
+  HIP_DYNAMIC_SHARED(float, smem);
+  const int nthr = blockDim.x;
+  float* Tf = smem;
+  float* Tr = Tf + C::TAB;
+  float* Pb0 = Tr + (C::DS ? C::TAB : 0);               // [nthr][KP]
+  float* Pb1 = Pb0 + (size_t)nthr * KP;                 // [nthr][KP] (ds)
+  uint32_t* Win = reinterpret_cast<uint32_t*>(Pb1 + (C::DS ? (size_t)nthr * KP : 0));   // [nthr][2]
+  float* red = reinterpret_cast<float*>(Win + 2 * nthr);                                 // [64]
+
+  copy_tables<C::TAB>(Tf, a.tables + C::OFF_TF);
+  if (C::DS) copy_tables<C::TAB>(Tr, a.tables + C::OFF_TR);
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = nthr >> 6;
+  // accumulator tile of this wave: (class, kt, jt)
+  const int tile_id = blockIdx.y * nwaves + wave;
+  const bool active = tile_id < a.ntiles;
+  int t_jt = 0, t_kt = 0, t_kind = 0, t_strand = 0;
+  if (active) {
+    int t = tile_id;
+    t_jt = t % C::NTJ; t /= C::NTJ;
+    t_kt = t % C::NTK; t /= C::NTK;
+    // accumulator classes: 0 = vh (forward strand), 1 = vh' (ds only), last = sw (forward, P(1-P))
+    t_kind = (a.want_sparsity && t == C::DS + 1) ? 1 : 0;
+    t_strand = (!t_kind && t == 1) ? 1 : 0;
+  }
+  float acc[4][JC][KC];
+#pragma unroll
+  for (int l = 0; l < 4; ++l)
+#pragma unroll
+    for (int jj = 0; jj < JC; ++jj)
+#pragma unroll
+      for (int q = 0; q < KC; ++q) acc[l][jj][q] = 0.f;
+
+  const bool owner = blockIdx.y == 0;   // h / sb / letter counts are accumulated once
+  float hs0[KP], hs1[KP], sb[KP];
+#pragma unroll
+  for (int q = 0; q < KP; ++q) { hs0[q] = 0.f; hs1[q] = 0.f; sb[q] = 0.f; }
+  float vc0 = 0.f, vc1 = 0.f, vc2 = 0.f, vc3 = 0.f;
+
+  const int nseqtiles = (a.n + a.TS - 1) / a.TS;
+  for (int tile = blockIdx.x; tile < nseqtiles; tile += gridDim.x) {
+    const int n0 = tile * a.TS;
+    const int ns = min(a.TS, a.n - n0);
+    const uint32_t items = (uint32_t)ns * (uint32_t)a.Lh;
+    for (uint32_t base = 0; base < items; base += nthr) {
+      __syncthreads();   // tables copied / previous batch consumed
+      const uint32_t i = base + threadIdx.x;
+      float* p0 = Pb0 + (size_t)threadIdx.x * KP;
+      float* p1 = Pb1 + (size_t)threadIdx.x * KP;
+      if (i < items) {
+        const uint32_t nl = fastdiv(i, a.divLh);
+        const int s = (int)(i - nl * (uint32_t)a.Lh);
+        const uint64_t win = letter_window<M>(a.letters + (size_t)(n0 + nl) * a.LW, s);
+        Win[2 * threadIdx.x] = (uint32_t)win;
+        Win[2 * threadIdx.x + 1] = (uint32_t)(win >> 32);
+        float x[KP];
+        conv_gather<C>(Tf, win, x);
+#pragma unroll
+        for (int q = 0; q < KP; ++q) {
+          const float p = sigmoidf_fast(x[q]);
+          p0[q] = p;
+          if (owner) { hs0[q] += p; sb[q] += p * (1.f - p); }
+        }
+        if (C::DS) {
+          conv_gather<C>(Tr, win, x);
+#pragma unroll
+          for (int q = 0; q < KP; ++q) {
+            const float p = sigmoidf_fast(x[q]);
+            p1[q] = p;
+            if (owner) hs1[q] += p;
+          }
+        }
+      } else {
+        Win[2 * threadIdx.x] = 0u;
+        Win[2 * threadIdx.x + 1] = 0u;
+#pragma unroll
+        for (int q = 0; q < KP; ++q) { p0[q] = 0.f; if (C::DS) p1[q] = 0.f; }
+      }
+      __syncthreads();
+      if (active) {
+        const float* Pb = t_strand ? Pb1 : Pb0;
+        for (int c = 0; c < nwaves; ++c) {
+          const int it = c * 64 + lane;
+          const uint64_t win = (uint64_t)Win[2 * it] | ((uint64_t)Win[2 * it + 1] << 32);
+          float pk[KC];
+          const float4* src = reinterpret_cast<const float4*>(Pb + (size_t)it * KP + t_kt * KC);
+#pragma unroll
+          for (int q = 0; q < NQC; ++q) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t_kt * NQC + q < C::NQ) v = src[q];
+            pk[4 * q] = v.x; pk[4 * q + 1] = v.y; pk[4 * q + 2] = v.z; pk[4 * q + 3] = v.w;
+          }
+          if (t_kind) {
+#pragma unroll
+            for (int q = 0; q < KC; ++q) pk[q] = pk[q] * (1.f - pk[q]);
+          }
+#pragma unroll
+          for (int jj = 0; jj < JC; ++jj) {
+            const int j = t_jt * JC + jj;
+            if (j < M) {
+              const uint32_t l = (uint32_t)(win >> (2 * j)) & 3u;
+              const float m0 = l == 0u ? 1.f : 0.f, m1 = l == 1u ? 1.f : 0.f;
+              const float m2 = l == 2u ? 1.f : 0.f, m3 = l == 3u ? 1.f : 0.f;
+#pragma unroll
+              for (int q = 0; q < KC; ++q) {
+                acc[0][jj][q] = fmaf(m0, pk[q], acc[0][jj][q]);
+                acc[1][jj][q] = fmaf(m1, pk[q], acc[1][jj][q]);
+                acc[2][jj][q] = fmaf(m2, pk[q], acc[2][jj][q]);
+                acc[3][jj][q] = fmaf(m3, pk[q], acc[3][jj][q]);
+              }
+            }
+          }
+        }
+      }
+    }
+    // letter counts of the whole visible rows of this tile
+    if (owner) {
+      const uint32_t vitems = (uint32_t)ns * (uint32_t)a.L;
+      for (uint32_t i = threadIdx.x; i < vitems; i += nthr) {
+        const uint32_t nl = fastdiv(i, a.divL);
+        const int p = (int)(i - nl * (uint32_t)a.L);
+        const uint32_t l = (a.letters[(size_t)(n0 + nl) * a.LW + (p >> 4)] >> (2 * (p & 15))) & 3u;
+        vc0 += l == 0u ? 1.f : 0.f; vc1 += l == 1u ? 1.f : 0.f;
+        vc2 += l == 2u ? 1.f : 0.f; vc3 += l == 3u ? 1.f : 0.f;
+      }
+    }
+  }
+
+  float* out = a.partials + (size_t)blockIdx.x * a.row;
+  // accumulator tiles: wave reduction, lane 0 writes (each slot has exactly one writer)
+  if (active) {
+    const int off = t_kind ? a.off_sw : (t_strand ? a.off_vh1 : a.off_vh0);
+#pragma unroll
+    for (int l = 0; l < 4; ++l)
+#pragma unroll
+      for (int jj = 0; jj < JC; ++jj)
+#pragma unroll
+        for (int q = 0; q < KC; ++q) {
+          const float v = wave_sum(acc[l][jj][q]);
+          const int k = t_kt * KC + q, j = t_jt * JC + jj;
+          if (lane == 0 && k < K && j < M) out[off + (k * 4 + l) * M + j] = v;
+        }
+  }
+  if (owner) {
+    // per-thread sums -> wave -> block (through LDS), fixed order
+    auto block_sum_store = [&](float v, int dst) {
+      v = wave_sum(v);
+      __syncthreads();
+      if (lane == 0) red[wave] = v;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < nwaves; ++w) t += red[w];
+        out[dst] = t;
+      }
+    };
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+      block_sum_store(hs0[q], a.off_h0 + q);
+      if (C::DS) block_sum_store(hs1[q], a.off_h1 + q);
+      if (a.want_sparsity) block_sum_store(sb[q], a.off_sb + q);
+    }
+    block_sum_store(vc0, a.off_v + 0);
+    block_sum_store(vc1, a.off_v + 1);
+    block_sum_store(vc2, a.off_v + 2);
+    block_sum_store(vc3, a.off_v + 3);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Free energy (convRBM.py:657-697): one wave per sequence.
+//   fe[n]    = ( -sum_{k,s} softplus(x) [- rc strand] - sum_p c[letter_p] ) / L
+//   fem[n,k] =   -sum_s softplus(x[k]) [- rc strand] - sum_p c[letter_p]
+// ---------------------------------------------------------------------------
+struct FeArgs {
+  const float* tables;
+  const uint32_t* letters;
+  int32_t n, L, Lh, LW;
+  float* fe;
+  float* fem;
+};
+
+__device__ __forceinline__ float softplusf(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
+
+template <class C>
+__device__ void free_energy_body(const FeArgs& a) {
+  constexpr int KP = C::KP, K = C::K, M = C::M;
+  HIP_DYNAMIC_SHARED(float, smem);
+  float* Tf = smem;
+  float* Tr = Tf + C::TAB;
+  copy_tables<C::TAB>(Tf, a.tables + C::OFF_TF);
+  if (C::DS) copy_tables<C::TAB>(Tr, a.tables + C::OFF_TR);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const float* cg = a.tables + C::OFF_C;
+  const float c0 = cg[0], c1 = cg[1], c2 = cg[2], c3 = cg[3];
+  for (int nn = blockIdx.x * nwaves + wave; nn < a.n; nn += gridDim.x * nwaves) {
+    const uint32_t* row = a.letters + (size_t)nn * a.LW;
+    float acc[KP];
+#pragma unroll
+    for (int q = 0; q < KP; ++q) acc[q] = 0.f;
+    for (int s = lane; s < a.Lh; s += 64) {
+      const uint64_t win = letter_window<M>(row, s);
+      float x[KP];
+      conv_gather<C>(Tf, win, x);
+#pragma unroll
+      for (int q = 0; q < K; ++q) acc[q] += softplusf(x[q]);
+      if (C::DS) {
+        conv_gather<C>(Tr, win, x);
+#pragma unroll
+        for (int q = 0; q < K; ++q) acc[q] += softplusf(x[q]);
+      }
+    }
+    float cs = 0.f;
+    for (int p = lane; p < a.L; p += 64) {
+      const uint32_t l = (row[p >> 4] >> (2 * (p & 15))) & 3u;
+      cs += l == 0u ? c0 : l == 1u ? c1 : l == 2u ? c2 : c3;
+    }
+    cs = wave_sum(cs);
+    float tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+      const float v = wave_sum(acc[q]);
+      tot += v;
+      if (lane == 0 && a.fem) a.fem[(size_t)nn * K + q] = -v - cs;
+    }
+    if (lane == 0 && a.fe) a.fe[nn] = (-tot - cs) / (float)a.L;
+  }
+}
+
+#ifdef CRBM_DEFINE_MISC_KERNELS
+// ===========================================================================
+// Model-independent kernels, compiled ahead of time into libcrbm_hip.so.
+// ===========================================================================
+
 // one-hot fp32 (n,1,4,L) -> packed letters [n][LW]; flags[0] |= 1 on a column
 // that is not exactly one-hot.
-// ---------------------------------------------------------------------------
 struct EncodeArgs {
   const float* v;
   uint32_t* letters;
@@ -235,88 +871,15 @@ __global__ void unpack_hidden_kernel(HiddenPackArgs a) {
   }
 }
 
-#endif  // CRBM_DEFINE_MISC_KERNELS
-
-// ---------------------------------------------------------------------------
-// h_given_v, dense outputs: _bottomUpActivity / _bottomUpProbability /
-// _bottomUpSample (convRBM.py:238-275) and motifHitProbs (:507-514).
-// mode 0: forward strand, 1: reverse-complement strand, 2: sigma(x + x').
-// ---------------------------------------------------------------------------
-struct HgvArgs {
-  ModelView mv;
-  const uint32_t* letters;
-  int32_t n, L, Lh, LW;
-  int32_t TS;          // sequences per tile
-  FastDiv divLh;
-  int32_t mode;
-  float* act;
-  float* prob;
-  float* sample;
-  unsigned long long* ones;   // += number of sampled ones (may be null)
-  RngView rng;
-  uint32_t kind;
-};
-
-template <int NQ>
-__global__ void __launch_bounds__(256) hgv_kernel(HgvArgs a) {
-  constexpr int KP = 4 * NQ;
-  HIP_DYNAMIC_SHARED(float, smem);
-  const ModelView& mv = a.mv;
-  const int tab = mv.ngroups * mv.rows * KP;
-  float* T0 = smem;
-  float* T1 = smem + tab;
-  build_gather_table(T0, mv, KP, a.mode == 1);
-  if (a.mode == 2) build_gather_table(T1, mv, KP, true);
-  __syncthreads();
-  const bool want_sample = (a.sample != nullptr) || (a.ones != nullptr);
-  const uint32_t strand = a.mode == 1 ? 1u : 0u;
-  unsigned long long cnt = 0;
-  const int ntiles = (a.n + a.TS - 1) / a.TS;
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int n0 = tile * a.TS;
-    const int ns = min(a.TS, a.n - n0);
-    const uint32_t items = (uint32_t)ns * (uint32_t)a.Lh;
-    for (uint32_t i = threadIdx.x; i < items; i += blockDim.x) {
-      const uint32_t nl = fastdiv(i, a.divLh);
-      const int s = (int)(i - nl * (uint32_t)a.Lh);
-      const int nn = n0 + (int)nl;
-      const uint64_t win = letter_window(a.letters + (size_t)nn * a.LW, s, mv.M);
-      float x[KP];
-      conv_gather<NQ>(T0, win, mv, x);
-      if (a.mode == 2) conv_gather<NQ, true>(T1, win, mv, x);
-      Philox4 r;
-#pragma unroll
-      for (int k = 0; k < KP; ++k) {
-        if (k < mv.K) {
-          const size_t idx = ((size_t)nn * mv.K + k) * a.Lh + s;
-          const float xv = x[k];
-          if (a.act) a.act[idx] = xv;
-          const float p = sigmoidf_fast(xv);
-          if (a.prob) a.prob[idx] = p;
-          if (want_sample) {
-            if ((k & 3) == 0)
-              r = philox4x32_10(a.rng.seq_offset + (uint32_t)nn, (uint32_t)s,
-                                rng_word2(a.kind, strand, (uint32_t)(k >> 2)), a.rng.step,
-                                a.rng.seed_lo, a.rng.seed_hi);
-            const float hv = p > u01(r.v[k & 3]) ? 1.f : 0.f;
-            if (a.sample) a.sample[idx] = hv;
-            cnt += (unsigned long long)hv;
-          }
-        }
-      }
-    }
-  }
-  if (a.ones && cnt) atomicAdd(a.ones, cnt);
-}
-
-#ifdef CRBM_DEFINE_MISC_KERNELS
 // ---------------------------------------------------------------------------
 // v_given_h from DENSE hidden tensors (any finite values): _topDownActivity,
 // _topDownProbability, _topDownSample (convRBM.py:277-325).  API/test pass;
-// the training chain uses gibbs_kernel.
+// the training chain uses the Gibbs kernel.
 // ---------------------------------------------------------------------------
 struct VghArgs {
-  ModelView mv;
+  const float* W;       // (K,4,M)
+  const float* c;       // (4)
+  int32_t K, M;
   const float* hid;
   const float* hidp;    // null when single-stranded
   int32_t n, Lh, L;
@@ -331,16 +894,15 @@ struct VghArgs {
 
 __global__ void __launch_bounds__(256) vgh_dense_kernel(VghArgs a) {
   HIP_DYNAMIC_SHARED(float, smem);
-  const ModelView& mv = a.mv;
-  const int K = mv.K, M = mv.M;
+  const int K = a.K, M = a.M;
   float4* W4 = reinterpret_cast<float4*>(smem);   // [j][k] -> W[k][0..3][j]
   for (int idx = threadIdx.x; idx < M * K; idx += blockDim.x) {
     const int j = idx / K, k = idx - j * K;
-    W4[idx] = make_float4(mv.W[(k * 4 + 0) * M + j], mv.W[(k * 4 + 1) * M + j],
-                          mv.W[(k * 4 + 2) * M + j], mv.W[(k * 4 + 3) * M + j]);
+    W4[idx] = make_float4(a.W[(k * 4 + 0) * M + j], a.W[(k * 4 + 1) * M + j],
+                          a.W[(k * 4 + 2) * M + j], a.W[(k * 4 + 3) * M + j]);
   }
   __syncthreads();
-  const float c0 = mv.c[0], c1 = mv.c[1], c2 = mv.c[2], c3 = mv.c[3];
+  const float c0 = a.c[0], c1 = a.c[1], c2 = a.c[2], c3 = a.c[3];
   const int ntiles = (a.n + a.TS - 1) / a.TS;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int n0 = tile * a.TS;
@@ -377,7 +939,7 @@ __global__ void __launch_bounds__(256) vgh_dense_kernel(VghArgs a) {
       }
       if (a.sample) {
         const Philox4 r = philox4x32_10(a.rng.seq_offset + (uint32_t)nn, (uint32_t)(p >> 2),
-                                        rng_word2(a.kind, 0, 0), a.rng.step, a.rng.seed_lo, a.rng.seed_hi);
+                                        rng_word2(a.kind, 0, 0, 0), a.rng.step, a.rng.seed_lo, a.rng.seed_hi);
         const float t = u01(philox_pick(r, p & 3)) * sum;
         const int l = (t >= e0) + (t >= e0 + e1) + (t >= (e0 + e1) + e2);
         a.sample[o] = l == 0 ? 1.f : 0.f; a.sample[o + a.L] = l == 1 ? 1.f : 0.f;
@@ -387,372 +949,8 @@ __global__ void __launch_bounds__(256) vgh_dense_kernel(VghArgs a) {
   }
 }
 
-#endif  // CRBM_DEFINE_MISC_KERNELS
-
-// ---------------------------------------------------------------------------
-// The persistent-chain kernel: `steps` Gibbs steps
-//   v ~ P(v|h,h')  (convRBM.py:317-325)   then   h,h' ~ P(h|v)  (:269-275)
-// for every chain of a tile, entirely in LDS (convRBM.py:397-408).
-// ---------------------------------------------------------------------------
-struct GibbsArgs {
-  ModelView mv;
-  uint32_t* hm;        // [nchains][Lf][NW] in/out
-  uint32_t* hmp;       // reverse strand (ds) or null
-  uint32_t* vout;      // [nchains][LWs] letters of the last visible sample
-  int32_t nchains, Lf, Lv, Lhp, LWs, S;
-  FastDiv divLv, divLf, divRow;   // divRow: / (Lhp*NW)
-  int32_t steps;
-  RngView rng;
-};
-
-template <int NQ>
-__global__ void __launch_bounds__(512) gibbs_kernel(GibbsArgs a) {
-  constexpr int KP = 4 * NQ;
-  constexpr int NW = (NQ <= 8) ? 1 : 2;
-  HIP_DYNAMIC_SHARED(float, smem);
-  const ModelView& mv = a.mv;
-  const int M = mv.M;
-  const int tab = mv.ngroups * mv.rows * KP;
-  float* Tf = smem;
-  float* Tr = Tf + tab;
-  float4* Wt = reinterpret_cast<float4*>(Tr + (mv.ds ? tab : 0));   // [jr][slot] -> W[k][0..3][M-1-jr]
-  float* cv = reinterpret_cast<float*>(Wt + M * NW * 32);
-  uint32_t* hm = reinterpret_cast<uint32_t*>(cv + 4);
-  uint32_t* hmp = hm + (size_t)a.S * a.Lhp * NW;
-  uint32_t* let = hmp + (mv.ds ? (size_t)a.S * a.Lhp * NW : 0);
-
-  build_gather_table(Tf, mv, KP, false);
-  if (mv.ds) build_gather_table(Tr, mv, KP, true);
-  for (int idx = threadIdx.x; idx < M * NW * 32; idx += blockDim.x) {
-    const int k = idx % (NW * 32), jr = idx / (NW * 32);
-    const int j = M - 1 - jr;
-    Wt[idx] = k < mv.K ? make_float4(mv.W[(k * 4 + 0) * M + j], mv.W[(k * 4 + 1) * M + j],
-                                     mv.W[(k * 4 + 2) * M + j], mv.W[(k * 4 + 3) * M + j])
-                       : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  if (threadIdx.x < 4) cv[threadIdx.x] = mv.c[threadIdx.x];
-
-  const int rowW = a.Lhp * NW;
-  const int ntiles = (a.nchains + a.S - 1) / a.S;
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int n0 = tile * a.S;
-    const int ns = min(a.S, a.nchains - n0);
-    __syncthreads();
-    // chain state -> zero-padded LDS rows (hidden position s sits at s + M-1)
-    for (uint32_t idx = threadIdx.x; idx < (uint32_t)(ns * rowW); idx += blockDim.x) {
-      const uint32_t nl = fastdiv(idx, a.divRow);
-      const uint32_t r = idx - nl * (uint32_t)rowW;
-      const int q = (int)(r / NW), w = (int)(r % NW);
-      const int s = q - (M - 1);
-      const bool in = s >= 0 && s < a.Lf;
-      const size_t g = ((size_t)(n0 + nl) * a.Lf + (in ? s : 0)) * NW + w;
-      hm[idx] = in ? a.hm[g] : 0u;
-      if (mv.ds) hmp[idx] = in ? a.hmp[g] : 0u;
-    }
-    for (int st = 0; st < a.steps; ++st) {
-      for (int idx = threadIdx.x; idx < ns * a.LWs; idx += blockDim.x) let[idx] = 0u;
-      __syncthreads();
-      // ---- v | h : y[a,p] = c[a] + sum over set bits (k, s=p-j) of W[k,a,j] ----
-      for (uint32_t i = threadIdx.x; i < (uint32_t)(ns * a.Lv); i += blockDim.x) {
-        const uint32_t nl = fastdiv(i, a.divLv);
-        const int p = (int)(i - nl * (uint32_t)a.Lv);
-        float y0 = cv[0], y1 = cv[1], y2 = cv[2], y3 = cv[3];
-        const uint32_t* mrow = hm + (size_t)nl * rowW + (size_t)p * NW;
-        for (int jr = 0; jr < M; ++jr) {
-#pragma unroll
-          for (int w = 0; w < NW; ++w) {
-            uint32_t m = mrow[jr * NW + w];
-            while (m) {
-              const int bit = __ffs(m) - 1;
-              m &= m - 1;
-              const float4 t = Wt[(jr * NW + w) * 32 + bit];
-              y0 += t.x; y1 += t.y; y2 += t.z; y3 += t.w;
-            }
-          }
-        }
-        if (mv.ds) {   // rc strand: rc(W)[k,a,j] = W[k,3-a,M-1-j]
-          const uint32_t* prow = hmp + (size_t)nl * rowW + (size_t)p * NW;
-          for (int jr = 0; jr < M; ++jr) {
-#pragma unroll
-            for (int w = 0; w < NW; ++w) {
-              uint32_t m = prow[jr * NW + w];
-              while (m) {
-                const int bit = __ffs(m) - 1;
-                m &= m - 1;
-                const float4 t = Wt[((M - 1 - jr) * NW + w) * 32 + bit];
-                y0 += t.w; y1 += t.z; y2 += t.y; y3 += t.x;
-              }
-            }
-          }
-        }
-        const float mx = fmaxf(fmaxf(y0, y1), fmaxf(y2, y3));
-        const float e0 = __expf(y0 - mx), e1 = __expf(y1 - mx), e2 = __expf(y2 - mx), e3 = __expf(y3 - mx);
-        const float sum = (e0 + e1) + (e2 + e3);
-        const Philox4 r = philox4x32_10(a.rng.seq_offset + (uint32_t)(n0 + nl), (uint32_t)(p >> 2),
-                                        rng_word2(KIND_CHAIN_V, 0, 0), a.rng.step + (uint32_t)st,
-                                        a.rng.seed_lo, a.rng.seed_hi);
-        const float t = u01(philox_pick(r, p & 3)) * sum;
-        const uint32_t l = (uint32_t)(t >= e0) + (uint32_t)(t >= e0 + e1) + (uint32_t)(t >= (e0 + e1) + e2);
-        atomicOr(&let[nl * a.LWs + (p >> 4)], l << (2 * (p & 15)));
-      }
-      __syncthreads();
-      // ---- h | v : x[k,s] = b[k] + sum_j W[k, letter[s+j], j]; h = [sigma(x) > u] ----
-      for (uint32_t i = threadIdx.x; i < (uint32_t)(ns * a.Lf); i += blockDim.x) {
-        const uint32_t nl = fastdiv(i, a.divLf);
-        const int s = (int)(i - nl * (uint32_t)a.Lf);
-        const uint64_t win = letter_window(let + (size_t)nl * a.LWs, s, M);
-        const uint32_t gn = a.rng.seq_offset + (uint32_t)(n0 + nl);
-#pragma unroll
-        for (int strand = 0; strand < 2; ++strand) {
-          if (strand == 1 && !mv.ds) break;
-          float x[KP];
-          conv_gather<NQ>(strand ? Tr : Tf, win, mv, x);
-          uint32_t mask[NW];
-#pragma unroll
-          for (int w = 0; w < NW; ++w) mask[w] = 0u;
-#pragma unroll
-          for (int kg = 0; kg < NQ; ++kg) {
-            if (4 * kg < mv.K) {
-              const Philox4 r = philox4x32_10(gn, (uint32_t)s, rng_word2(KIND_CHAIN_H, (uint32_t)strand, (uint32_t)kg),
-                                              a.rng.step + (uint32_t)st, a.rng.seed_lo, a.rng.seed_hi);
-#pragma unroll
-              for (int t = 0; t < 4; ++t) {
-                const int k = 4 * kg + t;
-                const float p = sigmoidf_fast(x[k]);
-                const uint32_t bit = p > u01(r.v[t]) ? 1u : 0u;
-                mask[k >> 5] |= bit << (k & 31);
-              }
-            }
-          }
-          uint32_t* dst = (strand ? hmp : hm) + (size_t)nl * rowW + (size_t)(s + M - 1) * NW;
-#pragma unroll
-          for (int w = 0; w < NW; ++w) dst[w] = mask[w];
-        }
-      }
-      __syncthreads();
-    }
-    // LDS -> chain state
-    for (uint32_t idx = threadIdx.x; idx < (uint32_t)(ns * a.Lf * NW); idx += blockDim.x) {
-      const uint32_t per = (uint32_t)(a.Lf * NW);
-      const uint32_t nl = idx / per;
-      const uint32_t r = idx - nl * per;
-      const size_t src = (size_t)nl * rowW + (size_t)(M - 1) * NW + r;
-      const size_t g = (size_t)(n0 + nl) * per + r;
-      a.hm[g] = hm[src];
-      if (mv.ds) a.hmp[g] = hmp[src];
-    }
-    if (a.vout)
-      for (int idx = threadIdx.x; idx < ns * a.LWs; idx += blockDim.x)
-        a.vout[(size_t)n0 * a.LWs + idx] = let[idx];
-  }
-}
-
-// ---------------------------------------------------------------------------
-// Gradient statistics (convRBM.py:327-371 and the closed form of :440-451):
-// raw sums over (n,s) of
-//   P[k,s] * onehot[a,s+j]          -> vh   (per strand)
-//   P(1-P)[k,s] * onehot[a,s+j]     -> sw   (forward strand, if want_sparsity)
-//   P[k,s], P(1-P)[k,s]             -> h, sb
-//   onehot[a,p]                     -> v    (letter counts)
-// Phase A: one thread per hidden position computes P (and P') and parks it in
-// LDS.  Phase B: each wave owns one accumulator tile [4][JC][KC] in registers
-// for the whole kernel and streams every parked item through it; per-block
-// partial sums are written once at the end (deterministic order).
-// ---------------------------------------------------------------------------
-struct StatsArgs {
-  ModelView mv;
-  const uint32_t* letters;
-  int32_t n, L, Lh, LW;
-  int32_t TS;
-  FastDiv divLh, divL;
-  int32_t want_sparsity;
-  int32_t ntk, ntj, ntiles;
-  int32_t row, off_vh0, off_vh1, off_h0, off_h1, off_sw, off_sb, off_v;
-  float* partials;     // [gridDim.x][row], zero-initialised by the host
-};
-
-template <int NQ>
-__global__ void __launch_bounds__(256) stats_kernel(StatsArgs a) {
-  constexpr int KP = 4 * NQ;
-  constexpr int NQC = NQ < 4 ? NQ : 4;
-  constexpr int KC = 4 * NQC;
-  constexpr int JC = NQC <= 3 ? 4 : 3;
-  HIP_DYNAMIC_SHARED(float, smem);
-  const ModelView& mv = a.mv;
-  const int M = mv.M, K = mv.K;
-  const int tab = mv.ngroups * mv.rows * KP;
-  const int nthr = blockDim.x;
-  float* Tf = smem;
-  float* Tr = Tf + tab;
-  float* Pb0 = Tr + (mv.ds ? tab : 0);               // [nthr][KP]
-  float* Pb1 = Pb0 + (size_t)nthr * KP;              // [nthr][KP] (ds)
-  uint32_t* Win = reinterpret_cast<uint32_t*>(Pb1 + (mv.ds ? (size_t)nthr * KP : 0));   // [nthr][2]
-  float* red = reinterpret_cast<float*>(Win + 2 * nthr);                                 // [64]
-
-  build_gather_table(Tf, mv, KP, false);
-  if (mv.ds) build_gather_table(Tr, mv, KP, true);
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = nthr >> 6;
-  // accumulator tile of this wave: (class, kt, jt)
-  const int tile_id = blockIdx.y * nwaves + wave;
-  const bool active = tile_id < a.ntiles;
-  int t_jt = 0, t_kt = 0, t_kind = 0, t_strand = 0;
-  if (active) {
-    int t = tile_id;
-    t_jt = t % a.ntj; t /= a.ntj;
-    t_kt = t % a.ntk; t /= a.ntk;
-    // accumulator classes: 0 = vh (forward strand), 1 = vh' (ds only), last = sw (forward, P(1-P))
-    t_kind = (a.want_sparsity && t == mv.ds + 1) ? 1 : 0;
-    t_strand = (!t_kind && t == 1) ? 1 : 0;
-  }
-  float acc[4][JC][KC];
-#pragma unroll
-  for (int l = 0; l < 4; ++l)
-#pragma unroll
-    for (int jj = 0; jj < JC; ++jj)
-#pragma unroll
-      for (int q = 0; q < KC; ++q) acc[l][jj][q] = 0.f;
-
-  const bool owner = blockIdx.y == 0;   // h / sb / letter counts are accumulated once
-  float hs0[KP], hs1[KP], sb[KP];
-#pragma unroll
-  for (int q = 0; q < KP; ++q) { hs0[q] = 0.f; hs1[q] = 0.f; sb[q] = 0.f; }
-  float vc0 = 0.f, vc1 = 0.f, vc2 = 0.f, vc3 = 0.f;
-
-  const int nseqtiles = (a.n + a.TS - 1) / a.TS;
-  for (int tile = blockIdx.x; tile < nseqtiles; tile += gridDim.x) {
-    const int n0 = tile * a.TS;
-    const int ns = min(a.TS, a.n - n0);
-    const uint32_t items = (uint32_t)ns * (uint32_t)a.Lh;
-    for (uint32_t base = 0; base < items; base += nthr) {
-      __syncthreads();   // tables built / previous batch consumed
-      const uint32_t i = base + threadIdx.x;
-      float* p0 = Pb0 + (size_t)threadIdx.x * KP;
-      float* p1 = Pb1 + (size_t)threadIdx.x * KP;
-      if (i < items) {
-        const uint32_t nl = fastdiv(i, a.divLh);
-        const int s = (int)(i - nl * (uint32_t)a.Lh);
-        const uint64_t win = letter_window(a.letters + (size_t)(n0 + nl) * a.LW, s, M);
-        Win[2 * threadIdx.x] = (uint32_t)win;
-        Win[2 * threadIdx.x + 1] = (uint32_t)(win >> 32);
-        float x[KP];
-        conv_gather<NQ>(Tf, win, mv, x);
-#pragma unroll
-        for (int q = 0; q < KP; ++q) {
-          const float p = sigmoidf_fast(x[q]);
-          p0[q] = p;
-          if (owner) { hs0[q] += p; sb[q] += p * (1.f - p); }
-        }
-        if (mv.ds) {
-          conv_gather<NQ>(Tr, win, mv, x);
-#pragma unroll
-          for (int q = 0; q < KP; ++q) {
-            const float p = sigmoidf_fast(x[q]);
-            p1[q] = p;
-            if (owner) hs1[q] += p;
-          }
-        }
-      } else {
-        Win[2 * threadIdx.x] = 0u;
-        Win[2 * threadIdx.x + 1] = 0u;
-#pragma unroll
-        for (int q = 0; q < KP; ++q) { p0[q] = 0.f; if (mv.ds) p1[q] = 0.f; }
-      }
-      __syncthreads();
-      if (active) {
-        const float* Pb = t_strand ? Pb1 : Pb0;
-        for (int c = 0; c < nwaves; ++c) {
-          const int it = c * 64 + lane;
-          const uint64_t win = (uint64_t)Win[2 * it] | ((uint64_t)Win[2 * it + 1] << 32);
-          float pk[KC];
-          const float4* src = reinterpret_cast<const float4*>(Pb + (size_t)it * KP + t_kt * KC);
-#pragma unroll
-          for (int q = 0; q < NQC; ++q) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t_kt * NQC + q < NQ) v = src[q];
-            pk[4 * q] = v.x; pk[4 * q + 1] = v.y; pk[4 * q + 2] = v.z; pk[4 * q + 3] = v.w;
-          }
-          if (t_kind) {
-#pragma unroll
-            for (int q = 0; q < KC; ++q) pk[q] = pk[q] * (1.f - pk[q]);
-          }
-#pragma unroll
-          for (int jj = 0; jj < JC; ++jj) {
-            const int j = t_jt * JC + jj;
-            if (j < M) {
-              const uint32_t l = (uint32_t)(win >> (2 * j)) & 3u;
-              const float m0 = l == 0u ? 1.f : 0.f, m1 = l == 1u ? 1.f : 0.f;
-              const float m2 = l == 2u ? 1.f : 0.f, m3 = l == 3u ? 1.f : 0.f;
-#pragma unroll
-              for (int q = 0; q < KC; ++q) {
-                acc[0][jj][q] = fmaf(m0, pk[q], acc[0][jj][q]);
-                acc[1][jj][q] = fmaf(m1, pk[q], acc[1][jj][q]);
-                acc[2][jj][q] = fmaf(m2, pk[q], acc[2][jj][q]);
-                acc[3][jj][q] = fmaf(m3, pk[q], acc[3][jj][q]);
-              }
-            }
-          }
-        }
-      }
-    }
-    // letter counts of the whole visible rows of this tile
-    if (owner) {
-      const uint32_t vitems = (uint32_t)ns * (uint32_t)a.L;
-      for (uint32_t i = threadIdx.x; i < vitems; i += nthr) {
-        const uint32_t nl = fastdiv(i, a.divL);
-        const int p = (int)(i - nl * (uint32_t)a.L);
-        const uint32_t l = (a.letters[(size_t)(n0 + nl) * a.LW + (p >> 4)] >> (2 * (p & 15))) & 3u;
-        vc0 += l == 0u ? 1.f : 0.f; vc1 += l == 1u ? 1.f : 0.f;
-        vc2 += l == 2u ? 1.f : 0.f; vc3 += l == 3u ? 1.f : 0.f;
-      }
-    }
-  }
-
-  float* out = a.partials + (size_t)blockIdx.x * a.row;
-  // accumulator tiles: wave reduction, lane 0 writes (each slot has exactly one writer)
-  if (active) {
-    const int off = t_kind ? a.off_sw : (t_strand ? a.off_vh1 : a.off_vh0);
-#pragma unroll
-    for (int l = 0; l < 4; ++l)
-#pragma unroll
-      for (int jj = 0; jj < JC; ++jj)
-#pragma unroll
-        for (int q = 0; q < KC; ++q) {
-          const float v = wave_sum(acc[l][jj][q]);
-          const int k = t_kt * KC + q, j = t_jt * JC + jj;
-          if (lane == 0 && k < K && j < M) out[off + (k * 4 + l) * M + j] = v;
-        }
-  }
-  if (owner) {
-    // per-thread sums -> wave -> block (through LDS), fixed order
-    auto block_sum_store = [&](float v, int dst) {
-      v = wave_sum(v);
-      __syncthreads();
-      if (lane == 0) red[wave] = v;
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        float t = 0.f;
-        for (int w = 0; w < nwaves; ++w) t += red[w];
-        out[dst] = t;
-      }
-    };
-#pragma unroll
-    for (int q = 0; q < KP; ++q) {
-      if (q < K) {
-        block_sum_store(hs0[q], a.off_h0 + q);
-        if (mv.ds) block_sum_store(hs1[q], a.off_h1 + q);
-        if (a.want_sparsity) block_sum_store(sb[q], a.off_sb + q);
-      }
-    }
-    block_sum_store(vc0, a.off_v + 0);
-    block_sum_store(vc1, a.off_v + 1);
-    block_sum_store(vc2, a.off_v + 2);
-    block_sum_store(vc3, a.off_v + 3);
-  }
-}
-
-#ifdef CRBM_DEFINE_MISC_KERNELS
-// sums[dst(r)] = sum over partial rows of column r, fixed order.
+// sums[dst(r)] = sum over partial rows of column r, fixed order (one wave per
+// column, lanes stride over rows, then a wave reduction).
 struct ReduceArgs {
   const float* partials;
   float* sums;
@@ -761,17 +959,19 @@ struct ReduceArgs {
   float n_value;                  // written after the last kept column
 };
 
-__global__ void reduce_partials_kernel(ReduceArgs a) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(256) reduce_partials_kernel(ReduceArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (r < a.row) {
     const bool skipped = r >= a.skip_begin && r < a.skip_begin + a.skip_len;
     if (!skipped) {
       float t = 0.f;
-      for (int i = 0; i < a.nrows; ++i) t += a.partials[(size_t)i * a.row + r];
-      a.sums[r < a.skip_begin ? r : r - a.skip_len] = t;
+      for (int i = lane; i < a.nrows; i += 64) t += a.partials[(size_t)i * a.row + r];
+      t = wave_sum(t);
+      if (lane == 0) a.sums[r < a.skip_begin ? r : r - a.skip_len] = t;
     }
   }
-  if (r == 0) a.sums[a.row - a.skip_len] = a.n_value;
+  if (r == 0 && lane == 0) a.sums[a.row - a.skip_len] = a.n_value;
 }
 
 // ---------------------------------------------------------------------------
@@ -837,87 +1037,6 @@ __global__ void apply_update_kernel(UpdateArgs a) {
     a.c[al] += v;
   }
 }
-
 #endif  // CRBM_DEFINE_MISC_KERNELS
-
-// ---------------------------------------------------------------------------
-// Free energy (convRBM.py:657-697): one wave per sequence.
-//   fe[n]    = ( -sum_{k,s} softplus(x) [- rc strand] - sum_p c[letter_p] ) / L
-//   fem[n,k] =   -sum_s softplus(x[k]) [- rc strand] - sum_p c[letter_p]
-// ---------------------------------------------------------------------------
-struct FeArgs {
-  ModelView mv;
-  const uint32_t* letters;
-  int32_t n, L, Lh, LW;
-  float* fe;
-  float* fem;
-};
-
-__device__ __forceinline__ float softplusf(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
-
-template <int NQ>
-__global__ void __launch_bounds__(256) free_energy_kernel(FeArgs a) {
-  constexpr int KP = 4 * NQ;
-  HIP_DYNAMIC_SHARED(float, smem);
-  const ModelView& mv = a.mv;
-  const int tab = mv.ngroups * mv.rows * KP;
-  float* Tf = smem;
-  float* Tr = Tf + tab;
-  build_gather_table(Tf, mv, KP, false);
-  if (mv.ds) build_gather_table(Tr, mv, KP, true);
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-  const float c0 = mv.c[0], c1 = mv.c[1], c2 = mv.c[2], c3 = mv.c[3];
-  for (int nn = blockIdx.x * nwaves + wave; nn < a.n; nn += gridDim.x * nwaves) {
-    const uint32_t* row = a.letters + (size_t)nn * a.LW;
-    float acc[KP];
-#pragma unroll
-    for (int q = 0; q < KP; ++q) acc[q] = 0.f;
-    for (int s = lane; s < a.Lh; s += 64) {
-      const uint64_t win = letter_window(row, s, mv.M);
-      float x[KP];
-      conv_gather<NQ>(Tf, win, mv, x);
-#pragma unroll
-      for (int q = 0; q < KP; ++q) acc[q] += softplusf(x[q]);
-      if (mv.ds) {
-        conv_gather<NQ>(Tr, win, mv, x);
-#pragma unroll
-        for (int q = 0; q < KP; ++q) acc[q] += softplusf(x[q]);
-      }
-    }
-    float cs = 0.f;
-    for (int p = lane; p < a.L; p += 64) {
-      const uint32_t l = (row[p >> 4] >> (2 * (p & 15))) & 3u;
-      cs += l == 0u ? c0 : l == 1u ? c1 : l == 2u ? c2 : c3;
-    }
-    cs = wave_sum(cs);
-    float tot = 0.f;
-#pragma unroll
-    for (int q = 0; q < KP; ++q) {
-      const float v = wave_sum(acc[q]);
-      if (q < mv.K) {
-        tot += v;
-        if (lane == 0 && a.fem) a.fem[(size_t)nn * mv.K + q] = -v - cs;
-      }
-    }
-    if (lane == 0 && a.fe) a.fe[nn] = (-tot - cs) / (float)a.L;
-  }
-}
-
-// ---------------------------------------------------------------------------
-// Dispatch table: one entry per instantiated NQ.
-// ---------------------------------------------------------------------------
-struct LaunchCfg {
-  uint32_t gx, gy, block, lds;
-  hipStream_t stream;
-};
-struct KernelTable {
-  int nq;
-  void (*hgv)(const HgvArgs&, const LaunchCfg&);
-  void (*gibbs)(const GibbsArgs&, const LaunchCfg&);
-  void (*stats)(const StatsArgs&, const LaunchCfg&);
-  void (*free_energy)(const FeArgs&, const LaunchCfg&);
-};
-const KernelTable* kernel_table(int nq);
 
 }  // namespace crbm

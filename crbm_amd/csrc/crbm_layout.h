@@ -1,6 +1,6 @@
-// Shapes, LDS layouts and launch geometry shared by the host API and the
-// kernels.  Pure C++ (no HIP types) so the same arithmetic sizes a launch in
-// crbm_api.hip and in the CPU emulation harness under tests/emu/.
+// Shapes, LDS layouts and launch geometry shared by the host API, the kernels
+// (compiled per model by hiprtc) and the CPU emulation harness under
+// tests/emu/.  Pure C++ (no HIP types).
 #pragma once
 #include <stdint.h>
 
@@ -23,18 +23,6 @@ inline FastDiv make_fastdiv(uint32_t d) {
   return f;
 }
 
-// What every kernel needs to know about the model.  Passed by value.
-struct ModelView {
-  const float* W;   // (K,4,M) row-major == reference (K,1,4,M)
-  const float* b;   // (K)
-  const float* c;   // (4)
-  int32_t K, M;
-  int32_t G;        // letters per gather-table group
-  int32_t ngroups;  // ceil(M / G)
-  int32_t rows;     // 4^G
-  int32_t ds;       // doublestranded
-};
-
 struct RngView {
   uint32_t seed_lo, seed_hi;
   uint32_t step;        // counter word 3
@@ -45,72 +33,110 @@ struct RngView {
 // 64+32-bit window read never leaves the row.
 inline int letter_words(int L) { return (L + 15) / 16 + 2; }
 
-inline int nq_for(int K) { return (K + 3) / 4; }
-inline int mask_words_for_nq(int NQ) { return NQ <= 8 ? 1 : 2; }
+constexpr int cpow4(int g) { return 1 << (2 * g); }
+constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-// Instantiated specialisations; a model with NQ quads runs on the smallest
-// instantiated NQ' >= NQ (pad columns are self-masking, see build_gather_table).
-static const int kInstantiatedNQ[] = {1, 2, 3, 4, 5, 6, 8, 10, 13, 16};
-inline int instantiated_nq(int NQ) {
-  for (int v : kInstantiatedNQ)
-    if (v >= NQ) return v;
-  return -1;
+// Everything that is fixed per model.  The kernels are compiled for one Cfg
+// (hiprtc at crbm_create, like the reference compiles its Theano graph at
+// construction, convRBM.py:175); the host uses the same formulas through
+// ModelShape below.
+template <int K_, int M_, int DS_, int G_>
+struct Cfg {
+  static constexpr int K = K_, M = M_, DS = DS_, G = G_;
+  static constexpr int NQ = cdiv(K, 4), KP = 4 * NQ;      // motifs padded to float4
+  static constexpr int NW = cdiv(K, 32);                  // 32-bit mask words per hidden position
+  static constexpr int NG = cdiv(M, G), ROWS = cpow4(G);  // gather table: groups x letter tuples
+  static constexpr int TAB = NG * ROWS * KP;              // floats per gather table
+  static constexpr int NCH = cdiv(K, 5);                  // 5-bit chunks of a position's mask
+  // v|h as dense table look-ups (small K*M) or as a loop over set bits
+  static constexpr bool DENSE = (NW == 1) && (NCH * M * (1 + DS) <= 64);
+  static constexpr int TV = DENSE ? M * NCH * 32 * 4 : 0; // floats per dense top-down table
+  static constexpr int WT = DENSE ? 0 : M * NW * 32 * 4;  // floats of the sparse scatter table
+  static constexpr int NGRP = cdiv(K, 10);                // sampler groups of 10 hidden units
+  // precomputed tables buffer (floats): [Tf][Tr*][Tv][Tvr*][Wt][c] is what the
+  // Gibbs kernel keeps in LDS (* = doublestranded only, TABLES floats); a
+  // single-stranded model still needs Tr for flip=True calls and for
+  // motifHitProbs (convRBM.py:511-514), kept after c in global memory only.
+  static constexpr int OFF_TF = 0;
+  static constexpr int OFF_TV = TAB * (1 + DS);
+  static constexpr int OFF_TVR = OFF_TV + TV;
+  static constexpr int OFF_WT = OFF_TV + TV * (1 + DS);
+  static constexpr int OFF_C = OFF_WT + WT;
+  static constexpr int TABLES = OFF_C + 4;                // multiple of 4 floats
+  static constexpr int OFF_TR = DS ? TAB : TABLES;
+  static constexpr int TABLES_ALL = DS ? TABLES : TABLES + TAB;
+  // statistics kernel accumulator tile [4][JC][KC]
+  static constexpr int NQC = NQ < 4 ? NQ : 4, KC = 4 * NQC, JC = NQC <= 3 ? 4 : 3;
+  static constexpr int NTK = cdiv(NQ, NQC), NTJ = cdiv(M, JC);
+};
+
+// Host-side mirror of Cfg (runtime values, same arithmetic).
+struct ModelShape {
+  int K, M, DS, G;
+  int NQ, KP, NW, NG, ROWS, TAB, NCH, DENSE, TV, WT, NGRP;
+  int OFF_TF, OFF_TR, OFF_TV, OFF_TVR, OFF_WT, OFF_C, TABLES, TABLES_ALL;
+  int NQC, KC, JC, NTK, NTJ;
+};
+inline ModelShape model_shape(int K, int M, int DS, int G) {
+  ModelShape s;
+  s.K = K; s.M = M; s.DS = DS; s.G = G;
+  s.NQ = cdiv(K, 4); s.KP = 4 * s.NQ; s.NW = cdiv(K, 32);
+  s.NG = cdiv(M, G); s.ROWS = cpow4(G); s.TAB = s.NG * s.ROWS * s.KP;
+  s.NCH = cdiv(K, 5);
+  s.DENSE = (s.NW == 1) && (s.NCH * M * (1 + DS) <= 64);
+  s.TV = s.DENSE ? M * s.NCH * 32 * 4 : 0;
+  s.WT = s.DENSE ? 0 : M * s.NW * 32 * 4;
+  s.NGRP = cdiv(K, 10);
+  s.OFF_TF = 0; s.OFF_TV = s.TAB * (1 + DS); s.OFF_TVR = s.OFF_TV + s.TV;
+  s.OFF_WT = s.OFF_TV + s.TV * (1 + DS); s.OFF_C = s.OFF_WT + s.WT; s.TABLES = s.OFF_C + 4;
+  s.OFF_TR = DS ? s.TAB : s.TABLES; s.TABLES_ALL = DS ? s.TABLES : s.TABLES + s.TAB;
+  s.NQC = s.NQ < 4 ? s.NQ : 4; s.KC = 4 * s.NQC; s.JC = s.NQC <= 3 ? 4 : 3;
+  s.NTK = cdiv(s.NQ, s.NQC); s.NTJ = cdiv(M, s.JC);
+  return s;
 }
 
-inline int pow4(int g) { return 1 << (2 * g); }
-inline int gather_table_floats(int M, int G, int KP) { return ((M + G - 1) / G) * pow4(G) * KP; }
-
-// Largest G whose table(s) fit the LDS budget.
-inline int choose_group(int M, int KP, int ds, int budget_bytes) {
+// Largest G whose gather table(s) fit the LDS budget.
+inline int choose_group(int K, int M, int ds, int budget_bytes) {
+  const int KP = 4 * cdiv(K, 4);
   for (int G = 4; G >= 2; --G)
-    if ((1 + ds) * gather_table_floats(M, G, KP) * 4 <= budget_bytes) return G;
+    if ((1 + ds) * cdiv(M, G) * cpow4(G) * KP * 4 <= budget_bytes) return G;
   return 1;
 }
 
-// ---- Gibbs kernel -----------------------------------------------------------
+// ---- Gibbs kernel -------------------------------------------------------------
+// A thread owns 4 consecutive positions.  Per chain: nvb = ceil(Lv/4) visible
+// blocks, nhb = ceil(Lf/4) hidden blocks.  Hidden position s sits at index
+// s + M-1 of a zero-padded mask row of Lrow positions (multiple of 4).
 struct GibbsLayout {
-  int S;        // chains per tile
-  int Lv;       // visible length of a chain = Lf + M - 1
-  int Lhp;      // padded hidden row = Lf + 2(M-1)
-  int LWs;      // letter words per chain row
-  int NW;       // mask words per hidden position
-  int tab;      // floats per gather table
-  int wt;       // floats of the scatter table  M * NW*32 * 4
+  int S, Lv, nvb, nhb, Lrow, LWs;
   int lds_bytes;
 };
-inline GibbsLayout gibbs_layout(int K, int M, int ds, int NQ, int G, int Lf, int S) {
+inline GibbsLayout gibbs_layout(const ModelShape& ms, int Lf, int S) {
   GibbsLayout g;
   g.S = S;
-  g.Lv = Lf + M - 1;
-  g.Lhp = Lf + 2 * (M - 1);
-  g.LWs = letter_words(g.Lv);
-  g.NW = mask_words_for_nq(NQ);
-  g.tab = gather_table_floats(M, G, 4 * NQ);
-  g.wt = M * g.NW * 32 * 4;
-  long words = (long)(1 + ds) * g.tab + g.wt + 4 + (long)(1 + ds) * S * g.Lhp * g.NW + (long)S * g.LWs;
+  g.Lv = Lf + ms.M - 1;
+  g.nvb = cdiv(g.Lv, 4);
+  g.nhb = cdiv(Lf, 4);
+  g.Lrow = 4 * cdiv(4 * g.nvb + ms.M - 1 + 3, 4);
+  g.LWs = letter_words(4 * g.nvb);
+  const long words = (long)ms.TABLES + (long)(1 + ms.DS) * S * g.Lrow * ms.NW + (long)S * g.LWs;
   g.lds_bytes = (int)(words * 4);
-  (void)K;
   return g;
 }
 
-// ---- statistics kernel --------------------------------------------------------
-// Accumulator tile owned by one wave: [4 letters][JC filter columns][KC motifs].
-inline int stats_nqc(int NQ) { return NQ < 4 ? NQ : 4; }
-inline int stats_jc(int NQ) { return stats_nqc(NQ) <= 3 ? 4 : 3; }
+// ---- statistics kernel ----------------------------------------------------------
 struct StatsLayout {
-  int ntk, ntj, ntiles;   // k-tiles, j-tiles, total (class x k x j)
+  int ntiles;             // accumulator tiles: (class x k-tile x j-tile); classes: vh, vh' (ds), sw
   int grid_y;
   int row;                // floats per partial row: 3*KAM + 3K + 4
   int off_vh[2], off_h[2], off_sw, off_sb, off_v;
   int lds_bytes;
 };
-inline StatsLayout stats_layout(int K, int M, int ds, int NQ, int G, int want_sparsity, int threads) {
+inline StatsLayout stats_layout(const ModelShape& ms, int want_sparsity, int threads) {
   StatsLayout s;
-  int KAM = K * 4 * M;
-  s.ntk = (NQ + stats_nqc(NQ) - 1) / stats_nqc(NQ);
-  s.ntj = (M + stats_jc(NQ) - 1) / stats_jc(NQ);
-  s.ntiles = (1 + ds + want_sparsity) * s.ntk * s.ntj;   // classes: vh, vh' (ds), sw
-  int waves = threads / 64;
+  const int K = ms.K, KAM = K * 4 * ms.M;
+  s.ntiles = (1 + ms.DS + want_sparsity) * ms.NTK * ms.NTJ;
+  const int waves = threads / 64;
   s.grid_y = (s.ntiles + waves - 1) / waves;
   s.off_vh[0] = 0;
   s.off_vh[1] = KAM;
@@ -120,8 +146,7 @@ inline StatsLayout stats_layout(int K, int M, int ds, int NQ, int G, int want_sp
   s.off_sb = 3 * KAM + 2 * K;
   s.off_v = 3 * KAM + 3 * K;
   s.row = 3 * KAM + 3 * K + 4;
-  long words = (long)(1 + ds) * gather_table_floats(M, G, 4 * NQ) + (long)(1 + ds) * threads * 4 * NQ +
-               2L * threads + 64;
+  const long words = (long)(1 + ms.DS) * ms.TAB + (long)(1 + ms.DS) * threads * ms.KP + 2L * threads + 64;
   s.lds_bytes = (int)(words * 4);
   return s;
 }
@@ -133,8 +158,8 @@ struct SumsLayout {
 };
 inline SumsLayout sums_layout(int K, int M) {
   SumsLayout s;
-  int KAM = K * 4 * M;
-  int row = 3 * KAM + 3 * K + 4;
+  const int KAM = K * 4 * M;
+  const int row = 3 * KAM + 3 * K + 4;
   s.data_off = 0;
   s.n_d = row;
   s.model_off = row + 1;

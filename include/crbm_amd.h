@@ -70,9 +70,12 @@ typedef struct crbm_handle crbm_handle;
 /* ---- lifetime ------------------------------------------------------------
  * crbm_create replaces CRBM.__init__'s shared-variable setup + the Theano
  * compile step (convRBM.py:127-175): allocates W,b,c, velocities (zero),
- * fantasy chains (zero), picks kernel specialisations.  W is zero until
- * crbm_set_params. */
+ * fantasy chains (zero) and compiles this model's kernels with hiprtc (cached
+ * on disk).  W is zero until crbm_set_params. */
 int crbm_create(const crbm_config* cfg, crbm_handle** out);
+/* Runs only the kernel specialisation step of crbm_create (hiprtc compile of
+ * the model's kernels into the on-disk cache); needs no GPU. */
+int crbm_precompile(const crbm_config* cfg);
 int crbm_destroy(crbm_handle* h);
 /* Message of the last failed call on h (h may be NULL: last crbm_create). */
 const char* crbm_last_error(const crbm_handle* h);

@@ -39,6 +39,14 @@ static void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, ui
 
 static inline float u01(uint32_t r) { return (float)(r >> 8) * 5.9604644775390625e-8f; }
 
+/* 12-bit field i (0..9) of the 128-bit little-endian Philox output */
+static inline uint32_t field12(const uint32_t r[4], int i) {
+  const int w = (12 * i) / 32, b = (12 * i) % 32;
+  uint32_t v = r[w] >> b;
+  if (b > 20) v |= r[(w + 1) & 3] << (32 - b);
+  return v & 0xFFFu;
+}
+
 int crbm_cpu_max_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();
@@ -111,11 +119,15 @@ void crbm_cpu_gibbs_step(const float* W, const float* b, const float* c, int K, 
               for (int s = 0; s < Lh; ++s) x[s] += w * vr[s];
             }
           for (int s = 0; s < Lh; ++s) {
-            uint32_t r[4];
+            /* 24-bit uniform of unit k: coarse and fine 12-bit fields of two
+             * Philox calls shared by the 10 units of group k/10 */
+            uint32_t rc[4], rf[4];
             const float p = 1.0f / (1.0f + expf(-x[s]));
-            philox4x32_10(seq_offset + (uint32_t)nn, (uint32_t)s,
-                          (1u << 28) | ((uint32_t)strand << 24) | (uint32_t)(k >> 2), step, k0, k1, r);
-            out[(size_t)k * Lh + s] = p > u01(r[k & 3]) ? 1.0f : 0.0f;
+            const uint32_t w2 = (1u << 28) | ((uint32_t)strand << 24) | (uint32_t)(k / 10);
+            philox4x32_10(seq_offset + (uint32_t)nn, (uint32_t)s, w2, step, k0, k1, rc);
+            philox4x32_10(seq_offset + (uint32_t)nn, (uint32_t)s, w2 | (1u << 16), step, k0, k1, rf);
+            const float u = (float)(field12(rc, k % 10) * 4096u + field12(rf, k % 10)) * 5.9604644775390625e-8f;
+            out[(size_t)k * Lh + s] = p > u ? 1.0f : 0.0f;
             if (pout) pout[(size_t)k * Lh + s] = p;
           }
         }

@@ -28,8 +28,10 @@ The reference seeds Theano's MRG31k3p stream from the wall clock
 reproduced.  The oracle and the HIP kernels share a counter-based generator
 instead: Philox-4x32-10 (Salmon et al., SC'11; the Random123 constants), keyed
 by ``seed`` and indexed by (sequence, position, motif-group, strand, kind,
-Gibbs step).  A uniform is ``(r >> 8) * 2**-24`` (exactly representable in
-float32), and the sampling rules are the reference's threshold forms:
+Gibbs step).  Every uniform has 24 bits (exactly representable in float32):
+``(r >> 8) * 2**-24`` for visible positions, ``(coarse*4096 + fine) * 2**-24``
+from two 12-bit Philox fields for hidden units (see ``hidden_uniforms``), and
+the sampling rules are the reference's threshold forms:
 ``h = 1 if p > u`` (convRBM.py:259-267, multinomial with one outcome) and
 "first letter whose cumulative probability exceeds u" (convRBM.py:301-310).
 """
@@ -88,25 +90,53 @@ def _u01(r):
     return (np.asarray(r, dtype=np.uint32) >> np.uint32(8)).astype(np.float64) * 2.0 ** -24
 
 
-def _word2(kind, strand, kgroup):
-    return (int(kind) << 28) | (int(strand) << 24) | kgroup
+def _word2(kind, strand, sub, group):
+    """Counter word 2: kind | strand | sub-stream (0 coarse, 1 fine) | group."""
+    return (int(kind) << 28) | (int(strand) << 24) | (int(sub) << 16) | group
+
+
+def _fields12(r):
+    """The ten 12-bit fields of a Philox output read as one 128-bit
+    little-endian number v0 | v1<<32 | v2<<64 | v3<<96; shape (..., 10)."""
+    lo = r[0].astype(np.uint64) | (r[1].astype(np.uint64) << np.uint64(32))
+    hi = r[2].astype(np.uint64) | (r[3].astype(np.uint64) << np.uint64(32))
+    out = []
+    for i in range(10):
+        bit = 12 * i
+        if bit + 12 <= 64:
+            f = lo >> np.uint64(bit)
+        elif bit >= 64:
+            f = hi >> np.uint64(bit - 64)
+        else:
+            f = (lo >> np.uint64(bit)) | (hi << np.uint64(64 - bit))
+        out.append(f & np.uint64(0xFFF))
+    return np.stack(out, axis=-1)
 
 
 def hidden_uniforms(seed, step, seq_index, K, Lh, strand=0, kind=KIND_CHAIN_H):
     """Uniforms for hidden units, shape (len(seq_index), K, 1, Lh).
 
-    Unit (n, k, s) of ``strand`` uses component ``k & 3`` of
-    ``philox(counter=(n, s, kind<<28 | strand<<24 | k>>2, step), key=seed)``.
+    Unit (n, k, s) of ``strand`` belongs to sampler group g = k // 10, slot
+    i = k % 10.  Two Philox calls per (n, s, strand, g) -- counter
+    (n, s, kind<<28 | strand<<24 | sub<<16 | g, step) with sub = 0 ("coarse")
+    and sub = 1 ("fine") -- each yield ten 12-bit fields; the unit's 24-bit
+    uniform is (coarse_i * 4096 + fine_i) / 2**24.  (The kernels evaluate the
+    fine call lazily: the coarse field alone settles all but ~2**-12 of the
+    decisions.)
     """
     seq_index = np.asarray(seq_index, dtype=np.uint64)
     n = seq_index[:, None, None]
-    kg = np.arange((K + 3) // 4, dtype=np.uint64)[None, :, None]
+    g = np.arange((K + 9) // 10, dtype=np.uint64)[None, :, None]
     s = np.arange(Lh, dtype=np.uint64)[None, None, :]
-    w2 = np.uint64(_word2(kind, strand, 0)) | kg
-    r = philox4x32(n, s, w2, np.uint64(step & 0xFFFFFFFF),
-                   seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
-    u = np.stack([_u01(x) for x in r], axis=2)          # (N, KG, 4, Lh)
-    u = u.reshape(len(seq_index), -1, Lh)[:, :K, :]
+    k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    parts = []
+    for sub in (0, 1):
+        w2 = np.uint64(_word2(kind, strand, sub, 0)) | g
+        r = philox4x32(n, s, w2, np.uint64(step & 0xFFFFFFFF), k0, k1)
+        parts.append(_fields12(r))                       # (N, G, Lh, 10)
+    U = parts[0] * np.uint64(4096) + parts[1]
+    u = U.astype(np.float64) * 2.0 ** -24
+    u = np.moveaxis(u, 3, 2).reshape(len(seq_index), -1, Lh)[:, :K, :]   # (N, G*10, Lh)
     return u[:, :, None, :]
 
 
@@ -119,7 +149,7 @@ def visible_uniforms(seed, step, seq_index, L, kind=KIND_CHAIN_V):
     seq_index = np.asarray(seq_index, dtype=np.uint64)
     n = seq_index[:, None]
     pg = np.arange((L + 3) // 4, dtype=np.uint64)[None, :]
-    r = philox4x32(n, pg, np.uint64(_word2(kind, 0, 0)),
+    r = philox4x32(n, pg, np.uint64(_word2(kind, 0, 0, 0)),
                    np.uint64(step & 0xFFFFFFFF),
                    seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
     u = np.stack([_u01(x) for x in r], axis=2)          # (N, PG, 4)

@@ -1,7 +1,7 @@
 // TEST INFRASTRUCTURE: runs the HIP kernels of crbm_amd/csrc/crbm_kernels.h on
 // CPU threads (see shim/hip/hip_runtime.h) so that indexing, LDS layouts and
 // barrier placement are checked under ASan/UBSan before a kernel ever reaches
-// a GPU.  Exposes plain C entry points for tests/test_emu.py (ctypes).
+// a GPU.  Exposes plain C entry points for tests/emu/run_emu.py (ctypes).
 #define CRBM_DEFINE_MISC_KERNELS
 #include "crbm_kernels.h"
 
@@ -12,8 +12,8 @@ namespace emu {
 thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
 thread_local BlockCtx* t_ctx;
 
-template <typename Args>
-void launch(void (*kernel)(Args), dim3 grid, dim3 block, size_t lds, const Args& args) {
+template <typename F>
+void launch(F kernel, dim3 grid, dim3 block, size_t lds) {
   const unsigned nthr = block.x, nwaves = (block.x + 63) / 64;
   for (unsigned by = 0; by < grid.y; ++by)
     for (unsigned bx = 0; bx < grid.x; ++bx) {
@@ -22,11 +22,12 @@ void launch(void (*kernel)(Args), dim3 grid, dim3 block, size_t lds, const Args&
       std::vector<pthread_barrier_t> wb(nwaves);
       for (unsigned w = 0; w < nwaves; ++w) pthread_barrier_init(&wb[w], nullptr, std::min(64u, nthr - w * 64));
       std::vector<float> scratch(nwaves * 64);
-      // exact size: out-of-bounds LDS accesses trip AddressSanitizer
-      std::vector<unsigned char> smem(lds ? lds : 1, 0xAB);
+      // exact size (16-byte aligned base): out-of-bounds LDS accesses trip AddressSanitizer
+      std::vector<float4> smem((lds + 15) / 16 + 1);
+      memset(smem.data(), 0xAB, smem.size() * 16);
       ctx.wave_bar = wb.data();
       ctx.wave_scratch = scratch.data();
-      ctx.smem = smem.data();
+      ctx.smem = reinterpret_cast<unsigned char*>(smem.data());
       std::vector<std::thread> threads;
       threads.reserve(nthr);
       for (unsigned t = 0; t < nthr; ++t)
@@ -36,7 +37,7 @@ void launch(void (*kernel)(Args), dim3 grid, dim3 block, size_t lds, const Args&
           t_blockDim = block;
           t_gridDim = grid;
           t_ctx = &ctx;
-          kernel(args);
+          kernel();
         });
       for (auto& th : threads) th.join();
       pthread_barrier_destroy(&ctx.bar);
@@ -48,110 +49,147 @@ void launch(void (*kernel)(Args), dim3 grid, dim3 block, size_t lds, const Args&
 using namespace crbm;
 
 namespace {
-ModelView make_mv(const float* W, const float* b, const float* c, int K, int M, int G, int ds) {
-  ModelView mv;
-  mv.W = W; mv.b = b; mv.c = c; mv.K = K; mv.M = M; mv.G = G;
-  mv.ngroups = (M + G - 1) / G; mv.rows = pow4(G); mv.ds = ds;
-  return mv;
-}
 RngView make_rng(uint64_t seed, uint32_t step, uint32_t off) {
   RngView r;
   r.seed_lo = (uint32_t)seed; r.seed_hi = (uint32_t)(seed >> 32); r.step = step; r.seq_offset = off;
   return r;
 }
 
-#define NQ_DISPATCH(nq, CALL)                \
-  switch (nq) {                              \
-    case 1: { constexpr int NQ = 1; CALL; break; }   \
-    case 2: { constexpr int NQ = 2; CALL; break; }   \
-    case 3: { constexpr int NQ = 3; CALL; break; }   \
-    case 5: { constexpr int NQ = 5; CALL; break; }   \
-    case 13: { constexpr int NQ = 13; CALL; break; } \
-    default: return -1;                      \
+// the model configurations the emulation is instantiated for (K, M, DS, G)
+#define CFG_DISPATCH(id, ...)                                    \
+  switch (id) {                                                  \
+    case 0: { using C = Cfg<10, 5, 0, 2>; __VA_ARGS__; break; }         \
+    case 1: { using C = Cfg<10, 15, 1, 3>; __VA_ARGS__; break; }        \
+    case 2: { using C = Cfg<2, 5, 1, 4>; __VA_ARGS__; break; }          \
+    case 3: { using C = Cfg<3, 4, 0, 1>; __VA_ARGS__; break; }          \
+    case 4: { using C = Cfg<20, 15, 1, 2>; __VA_ARGS__; break; }        \
+    case 5: { using C = Cfg<50, 25, 0, 2>; __VA_ARGS__; break; }        \
+    case 6: { using C = Cfg<7, 32, 1, 3>; __VA_ARGS__; break; }         \
+    case 7: { using C = Cfg<10, 15, 0, 3>; __VA_ARGS__; break; }        \
+    default: return -1;                                          \
   }
+
+template <class C>
+ModelShape shape_of() { return model_shape(C::K, C::M, C::DS, C::G); }
 }  // namespace
 
 extern "C" {
 
-int emu_encode(const float* v, uint32_t* letters, uint32_t* flags, int n, int L, int grid) {
-  EncodeArgs a{v, letters, flags, n, L, letter_words(L)};
-  emu::launch(encode_onehot_kernel, dim3(grid), dim3(64), 0, a);
+int emu_case_info(int id, int* out) {   // K, M, DS, G, TABLES, NW, DENSE
+  CFG_DISPATCH(id, (out[0] = C::K, out[1] = C::M, out[2] = C::DS, out[3] = C::G, out[4] = C::TABLES_ALL, out[5] = C::NW,
+                    out[6] = C::DENSE ? 1 : 0));
   return 0;
 }
 
-int emu_decode(const uint32_t* letters, float* v, int n, int L, int grid) {
-  DecodeArgs a{letters, v, n, L, letter_words(L)};
-  emu::launch(decode_onehot_kernel, dim3(grid), dim3(64), 0, a);
+int emu_encode(const float* v, uint32_t* letters, uint32_t* flags, int n, int L, int grid) {
+  EncodeArgs a{v, letters, flags, n, L, letter_words(L)};
+  emu::launch([&] { encode_onehot_kernel(a); }, dim3(grid), dim3(64), 0);
+  return 0;
+}
+
+int emu_decode(const uint32_t* letters, float* v, int n, int L, int LW, int grid) {
+  DecodeArgs a{letters, v, n, L, LW};
+  emu::launch([&] { decode_onehot_kernel(a); }, dim3(grid), dim3(64), 0);
   return 0;
 }
 
 int emu_pack_hidden(float* dense, uint32_t* masks, uint32_t* flags, int n, int K, int Lh, int NW, int unpack) {
   HiddenPackArgs a{dense, masks, flags, n, K, Lh, NW};
-  emu::launch(unpack ? unpack_hidden_kernel : pack_hidden_kernel, dim3(2), dim3(64), 0, a);
+  if (unpack) emu::launch([&] { unpack_hidden_kernel(a); }, dim3(2), dim3(64), 0);
+  else emu::launch([&] { pack_hidden_kernel(a); }, dim3(2), dim3(64), 0);
   return 0;
 }
 
-int emu_hgv(int nq, const float* W, const float* b, const float* c, int K, int M, int G, int ds,
-            const uint32_t* letters, int n, int L, int mode, float* act, float* prob, float* sample,
-            unsigned long long* ones, uint64_t seed, uint32_t step, uint32_t off, uint32_t kind,
+int emu_tables(int id, const float* W, const float* b, const float* c, float* out) {
+  TablesArgs a{W, b, c, out};
+  CFG_DISPATCH(id, emu::launch([&] { build_tables_body<C>(a); }, dim3(3), dim3(64), 0));
+  return 0;
+}
+
+int emu_hgv(int id, const float* tables, const uint32_t* letters, int n, int L, int mode, float* act, float* prob,
+            float* sample, unsigned long long* ones, uint64_t seed, uint32_t step, uint32_t off, uint32_t kind,
             int TS, int grid, int threads) {
   HgvArgs a;
-  a.mv = make_mv(W, b, c, K, M, G, ds);
-  a.letters = letters; a.n = n; a.L = L; a.Lh = L - M + 1; a.LW = letter_words(L);
-  a.TS = TS; a.divLh = make_fastdiv((uint32_t)a.Lh); a.mode = mode;
+  a.tables = tables; a.letters = letters; a.n = n; a.L = L; a.LW = letter_words(L);
+  a.TS = TS; a.mode = mode;
   a.act = act; a.prob = prob; a.sample = sample; a.ones = ones;
   a.rng = make_rng(seed, step, off); a.kind = kind;
-  const size_t lds = (size_t)(mode == 2 ? 2 : 1) * gather_table_floats(M, G, 4 * nq) * 4;
-  NQ_DISPATCH(nq, emu::launch(hgv_kernel<NQ>, dim3(grid), dim3(threads), lds, a));
+  CFG_DISPATCH(id, (a.Lh = L - C::M + 1, a.divLh = make_fastdiv((uint32_t)a.Lh),
+                    emu::launch([&] { hgv_body<C>(a); }, dim3(grid), dim3(threads),
+                                (size_t)(mode == 2 ? 2 : 1) * C::TAB * 4)));
   return 0;
 }
 
-int emu_vgh(const float* W, const float* b, const float* c, int K, int M, const float* hid, const float* hidp,
+int emu_vgh(const float* W, const float* c, int K, int M, const float* hid, const float* hidp,
             int n, int Lh, float* act, float* prob, float* sample, uint64_t seed, uint32_t step, uint32_t off,
             int TS, int grid, int threads) {
   VghArgs a;
-  a.mv = make_mv(W, b, c, K, M, 1, hidp ? 1 : 0);
+  a.W = W; a.c = c; a.K = K; a.M = M;
   a.hid = hid; a.hidp = hidp; a.n = n; a.Lh = Lh; a.L = Lh + M - 1;
   a.TS = TS; a.divL = make_fastdiv((uint32_t)a.L);
   a.act = act; a.prob = prob; a.sample = sample;
   a.rng = make_rng(seed, step, off); a.kind = KIND_API_V;
-  emu::launch(vgh_dense_kernel, dim3(grid), dim3(threads), (size_t)M * K * 16, a);
+  emu::launch([&] { vgh_dense_kernel(a); }, dim3(grid), dim3(threads), (size_t)M * K * 16);
   return 0;
 }
 
-int emu_gibbs(int nq, const float* W, const float* b, const float* c, int K, int M, int G, int ds,
-              uint32_t* hm, uint32_t* hmp, uint32_t* vout, int nchains, int Lf, int S, int steps,
-              uint64_t seed, uint32_t step, uint32_t off, int grid, int threads) {
-  const GibbsLayout gl = gibbs_layout(K, M, ds, nq, G, Lf, S);
+// returns LWs (letter words per chain row of vout) or -1
+int emu_gibbs(int id, const float* tables, uint32_t* hm, uint32_t* hmp, uint32_t* vout, int nchains, int Lf, int S,
+              int steps, uint64_t seed, uint32_t step, uint32_t off, int grid, int threads) {
   GibbsArgs a;
-  a.mv = make_mv(W, b, c, K, M, G, ds);
-  a.hm = hm; a.hmp = ds ? hmp : nullptr; a.vout = vout;
-  a.nchains = nchains; a.Lf = Lf; a.Lv = gl.Lv; a.Lhp = gl.Lhp; a.LWs = gl.LWs; a.S = S;
-  a.divLv = make_fastdiv((uint32_t)gl.Lv); a.divLf = make_fastdiv((uint32_t)Lf);
-  a.divRow = make_fastdiv((uint32_t)(gl.Lhp * gl.NW));
-  a.steps = steps; a.rng = make_rng(seed, step, off);
-  NQ_DISPATCH(nq, emu::launch(gibbs_kernel<NQ>, dim3(grid), dim3(threads), (size_t)gl.lds_bytes, a));
-  return 0;
+  a.tables = tables; a.hm = hm; a.hmp = hmp; a.vout = vout;
+  a.nchains = nchains; a.Lf = Lf; a.S = S; a.steps = steps; a.rng = make_rng(seed, step, off);
+  int lws = -1;
+  CFG_DISPATCH(id, {
+    const ModelShape ms = shape_of<C>();
+    const GibbsLayout gl = gibbs_layout(ms, Lf, S);
+    a.Lv = gl.Lv; a.nvb = gl.nvb; a.nhb = gl.nhb; a.Lrow = gl.Lrow; a.LWs = gl.LWs;
+    a.divVB = make_fastdiv((uint32_t)gl.nvb); a.divHB = make_fastdiv((uint32_t)gl.nhb);
+    a.divRow = make_fastdiv((uint32_t)(gl.Lrow * ms.NW)); a.divLfw = make_fastdiv((uint32_t)(Lf * ms.NW));
+    if (!C::DS) a.hmp = nullptr;
+    lws = gl.LWs;
+    if (vout) emu::launch([&] { gibbs_body<C>(a); }, dim3(grid), dim3(threads), (size_t)gl.lds_bytes);
+  });
+  return lws;
 }
 
 // statistics of one half + deterministic reduction into `sums` (row floats + n)
-int emu_stats(int nq, const float* W, const float* b, const float* c, int K, int M, int G, int ds,
-              const uint32_t* letters, int n, int L, int want_sparsity, int TS, int rows, int threads,
-              float* partials, float* sums, int skip_begin, int skip_len) {
-  const StatsLayout st = stats_layout(K, M, ds, nq, G, want_sparsity, threads);
+int emu_stats(int id, const float* tables, const uint32_t* letters, int n, int L, int LW, int want_sparsity, int TS,
+              int rows, int threads, float* partials, float* sums, int skip_begin, int skip_len) {
   StatsArgs a;
-  a.mv = make_mv(W, b, c, K, M, G, ds);
-  a.letters = letters; a.n = n; a.L = L; a.Lh = L - M + 1; a.LW = letter_words(L);
-  a.TS = TS; a.divLh = make_fastdiv((uint32_t)a.Lh); a.divL = make_fastdiv((uint32_t)L);
-  a.want_sparsity = want_sparsity; a.ntk = st.ntk; a.ntj = st.ntj; a.ntiles = st.ntiles;
-  a.row = st.row; a.off_vh0 = st.off_vh[0]; a.off_vh1 = st.off_vh[1]; a.off_h0 = st.off_h[0]; a.off_h1 = st.off_h[1];
-  a.off_sw = st.off_sw; a.off_sb = st.off_sb; a.off_v = st.off_v;
+  a.tables = tables; a.letters = letters; a.n = n; a.L = L; a.LW = LW;
+  a.TS = TS; a.divL = make_fastdiv((uint32_t)L);
+  a.want_sparsity = want_sparsity;
   a.partials = partials;
-  memset(partials, 0, sizeof(float) * (size_t)rows * st.row);
-  NQ_DISPATCH(nq, emu::launch(stats_kernel<NQ>, dim3(rows, st.grid_y), dim3(threads), (size_t)st.lds_bytes, a));
-  ReduceArgs r{partials, sums, rows, st.row, skip_begin < 0 ? st.row : skip_begin, skip_begin < 0 ? 0 : skip_len, (float)n};
-  emu::launch(reduce_partials_kernel, dim3((st.row + 63) / 64), dim3(64), 0, r);
-  return st.row;
+  int row = -1;
+  CFG_DISPATCH(id, {
+    const ModelShape ms = shape_of<C>();
+    const StatsLayout st = stats_layout(ms, want_sparsity, threads);
+    a.Lh = L - C::M + 1; a.divLh = make_fastdiv((uint32_t)a.Lh);
+    a.ntiles = st.ntiles; a.row = st.row;
+    a.off_vh0 = st.off_vh[0]; a.off_vh1 = st.off_vh[1]; a.off_h0 = st.off_h[0]; a.off_h1 = st.off_h[1];
+    a.off_sw = st.off_sw; a.off_sb = st.off_sb; a.off_v = st.off_v;
+    memset(partials, 0, sizeof(float) * (size_t)rows * st.row);
+    emu::launch([&] { stats_body<C>(a); }, dim3(rows, st.grid_y), dim3(threads), (size_t)st.lds_bytes);
+    // column sums on the host (the reduce kernel itself is emulated by emu_reduce
+    // on a small case: one OS thread per GPU thread is too slow for ~2000 columns)
+    const int sb = skip_begin < 0 ? st.row : skip_begin, sl = skip_begin < 0 ? 0 : skip_len;
+    for (int r = 0; r < st.row; ++r) {
+      if (r >= sb && r < sb + sl) continue;
+      float t = 0.f;
+      for (int i = 0; i < rows; ++i) t += partials[(size_t)i * st.row + r];
+      sums[r < sb ? r : r - sl] = t;
+    }
+    sums[st.row - sl] = (float)n;
+    row = st.row;
+  });
+  return row;
+}
+
+int emu_reduce(const float* partials, float* sums, int nrows, int row, int skip_begin, int skip_len, float n_value) {
+  ReduceArgs r{partials, sums, nrows, row, skip_begin, skip_len, n_value};
+  emu::launch([&] { reduce_partials_kernel(r); }, dim3((row + 1) / 2), dim3(128), 0);
+  return 0;
 }
 
 int emu_update(const float* sums, float* W, float* b, float* c, float* vW, float* vb, float* vc, int K, int M,
@@ -159,18 +197,18 @@ int emu_update(const float* sums, float* W, float* b, float* c, float* vW, float
   const SumsLayout sl = sums_layout(K, M);
   UpdateArgs u{sums, W, b, c, vW, vb, vc, K, M, ds, L_data, Lf, sl.data_off, sl.n_d, sl.model_off, sl.n_m,
                lr, momentum, rho, lambda_rate};
-  emu::launch(apply_update_kernel, dim3(1), dim3(64), 0, u);
+  emu::launch([&] { apply_update_kernel(u); }, dim3(1), dim3(64), 0);
   return 0;
 }
 
-int emu_free_energy(int nq, const float* W, const float* b, const float* c, int K, int M, int G, int ds,
-                    const uint32_t* letters, int n, int L, float* fe, float* fem, int grid, int threads) {
+int emu_free_energy(int id, const float* tables, const uint32_t* letters, int n, int L, float* fe, float* fem,
+                    int grid, int threads) {
   FeArgs a;
-  a.mv = make_mv(W, b, c, K, M, G, ds);
-  a.letters = letters; a.n = n; a.L = L; a.Lh = L - M + 1; a.LW = letter_words(L);
+  a.tables = tables; a.letters = letters; a.n = n; a.L = L; a.LW = letter_words(L);
   a.fe = fe; a.fem = fem;
-  const size_t lds = (size_t)(1 + ds) * gather_table_floats(M, G, 4 * nq) * 4;
-  NQ_DISPATCH(nq, emu::launch(free_energy_kernel<NQ>, dim3(grid), dim3(threads), lds, a));
+  CFG_DISPATCH(id, (a.Lh = L - C::M + 1,
+                    emu::launch([&] { free_energy_body<C>(a); }, dim3(grid), dim3(threads),
+                                (size_t)(1 + C::DS) * C::TAB * 4)));
   return 0;
 }
 

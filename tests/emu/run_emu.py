@@ -35,6 +35,21 @@ def model_arrays(o):
     return f32(o.W.reshape(o.num_motifs, 4, o.motif_length)), f32(o.b.ravel()), f32(o.c.ravel())
 
 
+def case_info(cid):
+    out = (ctypes.c_int * 7)()
+    assert lib.emu_case_info(cid, out) == 0
+    K, M, DS, G, TABLES, NW, DENSE = list(out)
+    return dict(K=K, M=M, ds=bool(DS), G=G, TABLES=TABLES, NW=NW, DENSE=DENSE)
+
+
+def build_tables(cid, o):
+    info = case_info(cid)
+    W, b, c = model_arrays(o)
+    t = np.zeros(info["TABLES"], dtype=np.float32)
+    assert lib.emu_tables(cid, fp(W), fp(b), fp(c), fp(t)) == 0
+    return t
+
+
 def encode(data):
     n, L = data.shape[0], data.shape[3]
     LW = lib.emu_letter_words(L)
@@ -79,20 +94,21 @@ def make_oracle(K, M, ds, seed=0, batch=4, Lf=20, cd_k=2, wscale=1.0, **kw):
     return o
 
 
-ALL_CASES = [  # K, M, ds, nq, G
-    (10, 5, False, 3, 2),
-    (10, 15, True, 3, 3),
-    (2, 5, True, 1, 4),
-    (3, 4, False, 1, 1),
-    (20, 15, True, 5, 2),
-    (50, 25, False, 13, 2),
-    (7, 32, True, 2, 3),
-]
+# case ids of the Cfg<K,M,DS,G> instantiations in emu_main.cpp:
+# 0 (10,5,ss,G2) 1 (10,15,ds,G3) 2 (2,5,ds,G4) 3 (3,4,ss,G1) 4 (20,15,ds,G2: sparse v|h)
+# 5 (50,25,ss,G2: two mask words) 6 (7,32,ds,G3: sparse, 96-bit letter window) 7 (10,15,ss,G3: config #2)
+ALL_CASES = list(range(8))
 # One OS thread per GPU thread makes barrier-heavy kernels slow on 8 cores: the
 # default run keeps the CPU suite to a few minutes, CRBM_EMU_FULL=1 runs all.
 FULL = os.environ.get("CRBM_EMU_FULL", "0") == "1"
-CASES = ALL_CASES if FULL else [ALL_CASES[1], ALL_CASES[2], ALL_CASES[3]]
-GIBBS_CASES = ALL_CASES if FULL else [ALL_CASES[1], ALL_CASES[3], ALL_CASES[5], ALL_CASES[6]]
+CASES = ALL_CASES if FULL else [1, 2, 3]
+GIBBS_CASES = ALL_CASES if FULL else [1, 3, 5, 6, 7]
+TRAIN_CASES = ALL_CASES[:6] if FULL else [1, 2]
+
+
+def oracle_for(cid, **kw):
+    info = case_info(cid)
+    return info, make_oracle(info["K"], info["M"], info["ds"], **kw)
 
 
 def test_encode_pack():
@@ -106,7 +122,7 @@ def test_encode_pack():
             assert (int(letters[n, p >> 4]) >> (2 * (p & 15))) & 3 == ref[n, p]
     assert np.all(letters[:, LW - 2:] == 0)
     back = np.zeros_like(d)
-    lib.emu_decode(up(letters), fp(back), 5, 37, 2)
+    lib.emu_decode(up(letters), fp(back), 5, 37, LW, 2)
     assert np.array_equal(back, d)
     bad = d.copy(); bad[2, 0, :, 5] = 0
     assert encode(bad)[1] == 1
@@ -120,13 +136,21 @@ def test_encode_pack():
         assert np.array_equal(unpack_hidden(m, K), h)
         h2 = h.copy(); h2[0, 0, 0, 0] = 0.25
         assert pack_hidden(h2, NW)[1] == 2
-    print("encode/pack ok")
+    # reduce_partials_kernel: column sums in fixed order, with a dropped column range
+    part = rng.standard_normal((70, 11)).astype(np.float32)
+    sums = np.full(11 - 3 + 1, -1.0, dtype=np.float32)
+    lib.emu_reduce(fp(part), fp(sums), 70, 11, 4, 3, ctypes.c_float(42.0))
+    keep = [0, 1, 2, 3, 7, 8, 9, 10]
+    np.testing.assert_allclose(sums[:8], part[:, keep].sum(axis=0), rtol=1e-5, atol=1e-5)
+    assert sums[8] == 42.0
+    print("encode/pack/reduce ok")
 
 
 def test_hgv():
-    for (K, M, ds, nq, G) in CASES:
-        o = make_oracle(K, M, ds)
-        W, b, c = model_arrays(o)
+    for cid in CASES:
+        info, o = oracle_for(cid)
+        K, M, ds = info["K"], info["M"], info["ds"]
+        tables = build_tables(cid, o)
         n, L = 5, M + 27
         d = synthetic_onehot(n, L, seed=K)
         letters, _ = encode(d)
@@ -136,7 +160,7 @@ def test_hgv():
             prob = np.zeros_like(act)
             smp = np.zeros_like(act)
             ones = ctypes.c_ulonglong(0)
-            rc = lib.emu_hgv(nq, fp(W), fp(b), fp(c), K, M, G, int(ds), up(letters), n, L, mode, fp(act), fp(prob),
+            rc = lib.emu_hgv(cid, fp(tables), up(letters), n, L, mode, fp(act), fp(prob),
                              fp(smp), ctypes.byref(ones), ctypes.c_uint64(77), 5, 3, KIND_API_H, 2, 2, 128)
             assert rc == 0
             if mode == 2:
@@ -149,12 +173,18 @@ def test_hgv():
             u = hidden_uniforms(77, 5, np.arange(n) + 3, K, Lh, 1 if mode == 1 else 0, KIND_API_H)
             ties = check_samples("hgv", smp, prob.astype(np.float64), u)
             assert ones.value == int(smp.sum())
-        print("hgv ok", (K, M, ds, nq, G), "ties", ties)
+            # probabilities only (no sampling path)
+            prob2 = np.zeros_like(act)
+            lib.emu_hgv(cid, fp(tables), up(letters), n, L, mode, None, fp(prob2), None, None,
+                        ctypes.c_uint64(77), 5, 3, KIND_API_H, 3, 1, 64)
+            np.testing.assert_allclose(prob2, p, rtol=1e-5, atol=1e-6)
+        print("hgv ok", cid, (K, M, ds), "ties", ties)
 
 
 def test_vgh():
-    for (K, M, ds, nq, G) in CASES[:5]:
-        o = make_oracle(K, M, ds)
+    for cid in CASES:
+        info, o = oracle_for(cid)
+        K, M, ds = info["K"], info["M"], info["ds"]
         W, b, c = model_arrays(o)
         rng = np.random.default_rng(K)
         n, Lh = 4, 23
@@ -166,7 +196,7 @@ def test_vgh():
         act = np.zeros((n, 1, 4, L), dtype=np.float32)
         prob = np.zeros_like(act)
         smp = np.zeros_like(act)
-        lib.emu_vgh(fp(W), fp(b), fp(c), K, M, fp(h), fp(hp), n, Lh, fp(act), fp(prob), fp(smp),
+        lib.emu_vgh(fp(W), fp(c), K, M, fp(h), fp(hp), n, Lh, fp(act), fp(prob), fp(smp),
                     ctypes.c_uint64(9), 2, 1, 2, 3, 64)
         ref = o._topDownActivity(h, hp)
         np.testing.assert_allclose(act, ref, rtol=1e-5, atol=1e-5)
@@ -183,43 +213,49 @@ def test_vgh():
         print("vgh ok", (K, M, ds))
 
 
-def run_gibbs(o, nq, G, S, steps, grid, threads):
-    K, M, ds = o.num_motifs, o.motif_length, o.doublestranded
-    W, b, c = model_arrays(o)
-    NW = 1 if nq <= 8 else 2
+def run_gibbs(cid, o, tables, S, steps, grid, threads):
+    info = case_info(cid)
+    K, M, ds, NW = info["K"], info["M"], info["ds"], info["NW"]
     hm, _ = pack_hidden(f32(o.fantasy_h), NW)
     hmp = pack_hidden(f32(o.fantasy_h_prime), NW)[0] if ds else np.zeros_like(hm)
     B, Lf = o.fantasy_h.shape[0], o.fantasy_h.shape[3]
     Lv = Lf + M - 1
-    vout = np.zeros((B, lib.emu_letter_words(Lv)), dtype=np.uint32)
-    rc = lib.emu_gibbs(nq, fp(W), fp(b), fp(c), K, M, G, int(ds), up(hm), up(hmp), up(vout), B, Lf, S, steps,
+    lws = lib.emu_gibbs(cid, fp(tables), up(hm), up(hmp), None, B, Lf, S, steps,
+                        ctypes.c_uint64(o.seed), o.gibbs_step, o.seq_offset, grid, threads)
+    assert lws > 0
+    vout = np.zeros((B, lws), dtype=np.uint32)
+    rc = lib.emu_gibbs(cid, fp(tables), up(hm), up(hmp), up(vout), B, Lf, S, steps,
                        ctypes.c_uint64(o.seed), o.gibbs_step, o.seq_offset, grid, threads)
-    assert rc == 0
+    assert rc == lws
     v = np.zeros((B, 1, 4, Lv), dtype=np.float32)
-    lib.emu_decode(up(vout), fp(v), B, Lv, 2)
-    return unpack_hidden(hm, K), (unpack_hidden(hmp, K) if ds else None), v, vout
+    lib.emu_decode(up(vout), fp(v), B, Lv, lws, 2)
+    return unpack_hidden(hm, K), (unpack_hidden(hmp, K) if ds else None), v, vout, lws
 
 
 def test_gibbs():
-    for (K, M, ds, nq, G) in GIBBS_CASES:
+    for cid in GIBBS_CASES:
         for (B, Lf, S, steps, grid, threads) in ((5, 21, 2, 3, 2, 128), (3, 40, 4, 1, 1, 64)):
-            o = make_oracle(K, M, ds, seed=11, batch=B, Lf=Lf, wscale=1.5)
+            info, o = oracle_for(cid, seed=11, batch=B, Lf=Lf, wscale=1.5)
+            ds = info["ds"]
             o.seq_offset = 6
             rng = np.random.default_rng(5)
             o.fantasy_h = rng.binomial(1, 0.1, size=o.fantasy_h.shape).astype(np.float64)
             if ds:
                 o.fantasy_h_prime = rng.binomial(1, 0.1, size=o.fantasy_h.shape).astype(np.float64)
-            h, hp, v, _ = run_gibbs(o, nq, G, S, steps, grid, threads)
+            tables = build_tables(cid, o)
+            h, hp, v, _, _ = run_gibbs(cid, o, tables, S, steps, grid, threads)
             o.gibbs_steps(steps)
             mism = int((h != o.fantasy_h).sum()) + (int((hp != o.fantasy_h_prime).sum()) if ds else 0)
             mism_v = int((v != o.last_v_model).sum())
-            assert mism == 0 and mism_v == 0, ("gibbs mismatch", (K, M, ds), mism, mism_v)
+            assert mism == 0 and mism_v == 0, ("gibbs mismatch", cid, mism, mism_v)
             assert o.fantasy_h.sum() > 0
-        print("gibbs ok", (K, M, ds, nq, G))
+        print("gibbs ok", cid, info)
 
 
 def test_train_step():
-    for (K, M, ds, nq, G) in (ALL_CASES[:6] if FULL else CASES[:2]):
+    for cid in TRAIN_CASES:
+        info = case_info(cid)
+        K, M, ds = info["K"], info["M"], info["ds"]
         B, Lf, n, L = 4, 18, 5, M + 20
         o = make_oracle(K, M, ds, seed=3, batch=B, Lf=Lf, cd_k=2, rho=0.05)
         o.vW = f32(np.random.default_rng(1).standard_normal(o.W.shape) * 0.01).astype(np.float64)
@@ -234,12 +270,13 @@ def test_train_step():
         rows, threads = 2, 128
         row = 3 * K * 4 * M + 3 * K + 4
         partials = np.zeros(rows * row, dtype=np.float32)
-        r = lib.emu_stats(nq, fp(W), fp(b), fp(c), K, M, G, int(ds), up(letters), n, L, 1, 2, rows, threads,
+        tables = build_tables(cid, o)
+        r = lib.emu_stats(cid, fp(tables), up(letters), n, L, lib.emu_letter_words(L), 1, 2, rows, threads,
                           fp(partials), fp(sums[data_off:]), -1, 0)
         assert r == row
-        _, _, v, vout = run_gibbs(o, nq, G, 2, o.cd_k, 2, threads)
+        _, _, v, vout, lws = run_gibbs(cid, o, tables, 2, o.cd_k, 2, threads)
         Lv = Lf + M - 1
-        r = lib.emu_stats(nq, fp(W), fp(b), fp(c), K, M, G, int(ds), up(vout), B, Lv, 0, 3, rows, threads,
+        r = lib.emu_stats(cid, fp(tables), up(vout), B, Lv, lws, 0, 3, rows, threads,
                           fp(partials), fp(sums[model_off:]), skipb, skipl)
         assert sums[n_d] == n and sums[n_m] == B
         # raw sums against the oracle's
@@ -266,19 +303,20 @@ def test_train_step():
         np.testing.assert_allclose(b, o.b.ravel(), rtol=1e-4, atol=1e-6)
         np.testing.assert_allclose(c, o.c.ravel(), rtol=1e-4, atol=1e-6)
         np.testing.assert_allclose(vW.reshape(o.W.shape), o.vW, rtol=1e-4, atol=1e-7)
-        print("train step ok", (K, M, ds, nq, G))
+        print("train step ok", cid, (K, M, ds))
 
 
 def test_free_energy():
-    for (K, M, ds, nq, G) in CASES:
-        o = make_oracle(K, M, ds)
-        W, b, c = model_arrays(o)
+    for cid in CASES:
+        info, o = oracle_for(cid)
+        K, M, ds = info["K"], info["M"], info["ds"]
+        tables = build_tables(cid, o)
         n, L = 7, M + 70
         d = synthetic_onehot(n, L, seed=K + 1)
         letters, _ = encode(d)
         fe = np.zeros(n, dtype=np.float32)
         fem = np.zeros((n, K), dtype=np.float32)
-        lib.emu_free_energy(nq, fp(W), fp(b), fp(c), K, M, G, int(ds), up(letters), n, L, fp(fe), fp(fem), 2, 128)
+        lib.emu_free_energy(cid, fp(tables), up(letters), n, L, fp(fe), fp(fem), 2, 128)
         np.testing.assert_allclose(fe, o.freeEnergy(d), rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(fem, o.freeEnergy(d, True), rtol=1e-5, atol=1e-5)
         print("free energy ok", (K, M, ds))

@@ -25,6 +25,9 @@ struct float4 {
   float x, y, z, w;
 };
 static inline float4 make_float4(float a, float b, float c, float d) { return float4{a, b, c, d}; }
+struct uint4 {
+  unsigned x, y, z, w;
+};
 typedef void* hipStream_t;
 
 namespace emu {
@@ -56,6 +59,10 @@ static inline float __shfl_down(float v, int off, int width = 64) {
   pthread_barrier_wait(&emu::t_ctx->wave_bar[wave]);
   return r;
 }
+
+// Only used to decide whether a wave takes a slow path that is a no-op for lanes
+// that do not need it, so the lane-local answer is an exact emulation.
+static inline int __any(int pred) { return pred; }
 
 static inline uint32_t atomicOr(uint32_t* p, uint32_t v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
 static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) {

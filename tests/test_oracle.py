@@ -37,9 +37,20 @@ def test_uniform_layout():
     u = hidden_uniforms(7, 3, [5, 9], K=10, Lh=6)
     assert u.shape == (2, 10, 1, 6)
     assert (u >= 0).all() and (u < 1).all()
-    # unit (n=9,k=6,s=4): component 6&3=2 of philox((9,4,1<<28|1,3),(7,0))
-    r = philox4x32(9, 4, (1 << 28) | 1, 3, 7, 0)
-    assert u[1, 6, 0, 4] == (int(r[2]) >> 8) * 2.0 ** -24
+    # unit (n=9,k=6,s=4): group 0, slot 6 -> bits 72..83 of the 128-bit output,
+    # i.e. bits 8..19 of word 2, of the coarse (sub 0) and fine (sub 1) calls
+    rc = philox4x32(9, 4, (1 << 28), 3, 7, 0)
+    rf = philox4x32(9, 4, (1 << 28) | (1 << 16), 3, 7, 0)
+    coarse, fine = (int(rc[2]) >> 8) & 0xFFF, (int(rf[2]) >> 8) & 0xFFF
+    assert u[1, 6, 0, 4] == (coarse * 4096 + fine) * 2.0 ** -24
+    # slot 5 straddles words 1 and 2 (bits 60..71)
+    c5 = ((int(rc[1]) >> 28) | (int(rc[2]) << 4)) & 0xFFF
+    f5 = ((int(rf[1]) >> 28) | (int(rf[2]) << 4)) & 0xFFF
+    assert u[1, 5, 0, 4] == (c5 * 4096 + f5) * 2.0 ** -24
+    u25 = hidden_uniforms(7, 3, [5], K=25, Lh=3, strand=1)
+    r2 = philox4x32(5, 2, (1 << 28) | (1 << 24) | 2, 3, 7, 0)       # group 2, slot 0 -> k = 20
+    r2f = philox4x32(5, 2, (1 << 28) | (1 << 24) | (1 << 16) | 2, 3, 7, 0)
+    assert u25[0, 20, 0, 2] == ((int(r2[0]) & 0xFFF) * 4096 + (int(r2f[0]) & 0xFFF)) * 2.0 ** -24
     v = visible_uniforms(7, 3, [5, 9], L=11)
     r = philox4x32(5, 10 >> 2, 2 << 28, 3, 7, 0)
     assert v[0, 10] == (int(r[10 & 3]) >> 8) * 2.0 ** -24

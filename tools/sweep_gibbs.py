@@ -39,6 +39,6 @@ def time_cfg(cfg, env, steps=300):
 if __name__ == "__main__":
     cfg = bench.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "cfg2"]
     print("us/launch grid block S lds G activity")
-    for S, thr, G in itertools.product([2, 4, 5, 8, 16], [256, 512], [2, 3]):
+    for S, thr, G in itertools.product([4, 5, 8, 10, 16, 20], [64, 128, 256], [3]):
         res, err = time_cfg(cfg, {"CRBM_GIBBS_S": S, "CRBM_GIBBS_THREADS": thr, "CRBM_GROUP": G})
         print("S=%d thr=%d G=%d ->" % (S, thr, G), res if res else err, flush=True)
