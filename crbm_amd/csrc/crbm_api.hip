@@ -390,16 +390,17 @@ GibbsGeom choose_gibbs_geometry(const ModelShape& ms, int Lf, int B, int num_cu)
       const GibbsLayout gl = gibbs_layout(ms, Lf, S);
       if (gl.lds_bytes > 64 * 1024 && !(forceS > 0)) continue;
       if (gl.lds_bytes > 160 * 1024 || (long)S * gl.Lrow * ms.NW >= (1 << 20)) continue;
+      // lanes are used at wave granularity (an idle wave of a pass costs nothing);
+      // h|v costs ~1.5x v|h per 4-position block
       const double iv = (double)S * gl.nvb, ih = (double)S * gl.nhb;
-      const double pv = std::ceil(iv / threads), ph = std::ceil(ih / threads);
-      const double util = (iv + 1.5 * ih) / ((pv + 1.5 * ph) * threads);      // h|v costs ~1.5x v|h per block
+      const double util = (iv + 1.5 * ih) / (64.0 * (std::ceil(iv / 64.0) + 1.5 * std::ceil(ih / 64.0)));
       const double ntiles = std::ceil((double)B / S);
       const double per_cu_tiles = ntiles / num_cu;
       const double balance = per_cu_tiles / std::ceil(per_cu_tiles);
       const int blocks_cu = std::max(1, std::min((160 * 1024) / gl.lds_bytes, 1024 / threads));   // <= 16 waves / CU
-      const double waves_cu = std::min(per_cu_tiles, (double)blocks_cu) * threads / 64.0;
-      const double occupancy = std::min(1.0, waves_cu / 8.0);                 // >= 2 waves / SIMD wanted
-      const double score = util * balance * (0.5 + 0.5 * occupancy) - 1e-4 * S;
+      const double waves_cu = std::min(per_cu_tiles, (double)blocks_cu) * std::min((double)threads, iv) / 64.0;
+      const double occupancy = std::min(1.0, waves_cu / 16.0);                // 4 waves / SIMD hide the LDS latency
+      const double score = util * balance * (0.4 + 0.6 * occupancy) - 1e-4 * S;
       if (score > best_score) {
         best_score = score;
         best = GibbsGeom{S, threads, (int)std::min(ntiles, (double)num_cu * blocks_cu), gl.lds_bytes};

@@ -87,7 +87,10 @@ __device__ __forceinline__ uint32_t fastdiv(uint32_t i, const FastDiv& f) {
   return f.d <= 1 ? i : __umulhi(i, f.inv);
 }
 
-__device__ __forceinline__ float sigmoidf_fast(float x) { return __fdividef(1.0f, 1.0f + __expf(-x)); }
+// z = -x*log2(e) (what conv_gather returns): exp(-x) = 2^z
+__device__ __forceinline__ float exp_neg_x(float z) { return __builtin_amdgcn_exp2f(z); }
+__device__ __forceinline__ float sigmoid_z(float z) { return __fdividef(1.0f, 1.0f + exp_neg_x(z)); }
+__device__ __forceinline__ float x_of_z(float z) { return -0.6931471805599453f * z; }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -96,8 +99,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // ---------------------------------------------------------------------------
-// Sampling K hidden units from their activations (convRBM.py:259-267: h = 1 if
-// p > u).  The uniform of unit k is 24 bits wide, u = (coarse*4096 + fine) /
+// Sampling K hidden units from z = -x*log2(e) of their activations x
+// (convRBM.py:259-267: h = 1 if p > u).  The uniform of unit k is 24 bits wide, u = (coarse*4096 + fine) /
 // 2^24, where coarse and fine are the (k % 10)-th 12-bit fields of two Philox
 // calls shared by the 10 units of group k / 10.  Almost every decision is
 // settled by the coarse field alone: with e = exp(-x),
@@ -106,7 +109,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 // (2^-12 per unit).  Returns the K-bit mask; optionally the probabilities.
 // ---------------------------------------------------------------------------
 template <class C, bool WANT_P>
-__device__ __forceinline__ void sample_hidden(const float (&x)[C::KP], uint32_t n, uint32_t s, uint32_t kind,
+__device__ __forceinline__ void sample_hidden(const float (&z)[C::KP], uint32_t n, uint32_t s, uint32_t kind,
                                               uint32_t strand, const RngView& rng, uint32_t step,
                                               uint32_t (&mask)[C::NW], float (&p)[C::KP]) {
 #pragma unroll
@@ -119,7 +122,7 @@ __device__ __forceinline__ void sample_hidden(const float (&x)[C::KP], uint32_t 
       constexpr int i = decltype(I)::value;
       const int k = 10 * g + i;
       if (k < C::K) {
-        const float e = __expf(-x[k]);
+        const float e = exp_neg_x(z[k]);
         const float af = (float)philox_field12<i>(rc);
         const float x1 = fmaf(af, e, af);          // coarse * (1 + e)
         const float x2 = x1 + (1.0f + e);          // (coarse + 1) * (1 + e)
@@ -139,7 +142,7 @@ __device__ __forceinline__ void sample_hidden(const float (&x)[C::KP], uint32_t 
         if (k < C::K) {
           if (amb & (1u << i)) {
             // P*4096 - coarse lies in [0,1) up to rounding; compare with fine/4096
-            const float t = 4096.0f / (1.0f + __expf(-x[k]));
+            const float t = __fdividef(4096.0f, 1.0f + exp_neg_x(z[k]));
             const float frac = t - (float)philox_field12<i>(rc);
             const uint32_t one = frac * 4096.0f > (float)philox_field12<i>(rf) ? 1u : 0u;
             mask[k >> 5] |= one << (k & 31);
@@ -166,7 +169,7 @@ __device__ __forceinline__ uint64_t letter_window(const uint32_t* w, int s) {
   return win;
 }
 
-// x[k] (+)= sum over letter groups of T[g][tuple][k]; b[k] is folded into group 0.
+// z[k] (+)= sum over letter groups of T[g][tuple][k]  (z = -log2(e) * activation).
 template <class C, bool ACCUMULATE = false>
 __device__ __forceinline__ void conv_gather(const float* T, uint64_t win, float (&x)[C::KP]) {
   if (!ACCUMULATE) {
@@ -199,9 +202,11 @@ __device__ __forceinline__ void copy_tables(float* dst, const float* src) {
 
 // ---------------------------------------------------------------------------
 // Tables, rebuilt whenever W, b or c change (set_params / apply_update):
-//  Tf[g][r][k]  = sum_{t<G, j=gG+t<M} W[k][(r>>2t)&3][j]  (+ b[k] in group 0)
+//  Tf[g][r][k]  = -log2(e) * ( sum_{t<G, j=gG+t<M} W[k][(r>>2t)&3][j]  (+ b[k] in group 0) )
 //  Tr           = same for rc(W) = W[k][3-a][M-1-j]       (convRBM.py:241,:285)
-//    pad columns k >= K get -1e30 in group 0: sigmoid -> 0, softplus -> 0.
+//    The gather therefore yields z = -x*log2(e), so exp(-x) is one v_exp_f32
+//    (2^z) with no multiply; kernels that need x itself use x = -ln(2)*z.
+//    Pad columns k >= K get +1e30 in group 0: exp(-x) = inf, sigmoid -> 0.
 //  Tv[jr][ch][pat] (float4 over letters) = sum_{bit in pat} W[5ch+bit][:][M-1-jr]
 //  Tvr          = same for rc(W)                           (convRBM.py:279-287)
 //  Wt[jr][k]    (float4 over letters) = W[k][:][M-1-jr]    (sparse top-down)
@@ -232,8 +237,9 @@ __device__ void build_tables_body(const TablesArgs& a) {
           }
         }
         if (g == 0) val += a.b[k];
+        val *= -1.4426950408889634f;
       } else if (g == 0) {
-        val = -1e30f;
+        val = 1e30f;
       }
     } else if (idx < C::OFF_WT) {                            // dense top-down tables
       const bool rc = C::DS && idx >= C::OFF_TVR;
@@ -307,12 +313,12 @@ __device__ void hgv_body(const HgvArgs& a) {
                                mask, p);
       } else {
 #pragma unroll
-        for (int k = 0; k < K; ++k) p[k] = sigmoidf_fast(x[k]);
+        for (int k = 0; k < K; ++k) p[k] = sigmoid_z(x[k]);
       }
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         const size_t idx = ((size_t)nn * K + k) * a.Lh + s;
-        if (a.act) a.act[idx] = x[k];
+        if (a.act) a.act[idx] = x_of_z(x[k]);
         if (a.prob) a.prob[idx] = p[k];
         if (want_sample) {
           const uint32_t hb = (mask[k >> 5] >> (k & 31)) & 1u;
@@ -599,7 +605,7 @@ __device__ void stats_body(const StatsArgs& a) {
         conv_gather<C>(Tf, win, x);
 #pragma unroll
         for (int q = 0; q < KP; ++q) {
-          const float p = sigmoidf_fast(x[q]);
+          const float p = sigmoid_z(x[q]);
           p0[q] = p;
           if (owner) { hs0[q] += p; sb[q] += p * (1.f - p); }
         }
@@ -607,7 +613,7 @@ __device__ void stats_body(const StatsArgs& a) {
           conv_gather<C>(Tr, win, x);
 #pragma unroll
           for (int q = 0; q < KP; ++q) {
-            const float p = sigmoidf_fast(x[q]);
+            const float p = sigmoid_z(x[q]);
             p1[q] = p;
             if (owner) hs1[q] += p;
           }
@@ -746,11 +752,11 @@ __device__ void free_energy_body(const FeArgs& a) {
       float x[KP];
       conv_gather<C>(Tf, win, x);
 #pragma unroll
-      for (int q = 0; q < K; ++q) acc[q] += softplusf(x[q]);
+      for (int q = 0; q < K; ++q) acc[q] += softplusf(x_of_z(x[q]));
       if (C::DS) {
         conv_gather<C>(Tr, win, x);
 #pragma unroll
-        for (int q = 0; q < K; ++q) acc[q] += softplusf(x[q]);
+        for (int q = 0; q < K; ++q) acc[q] += softplusf(x_of_z(x[q]));
       }
     }
     float cs = 0.f;

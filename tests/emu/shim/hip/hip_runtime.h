@@ -71,6 +71,7 @@ static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long 
 static inline int __ffs(uint32_t v) { return __builtin_ffs((int)v); }
 static inline uint32_t __umulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
 #define __expf(x) expf(x)
+static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
 static inline float __fdividef(float a, float b) { return a / b; }
 using std::max;
 using std::min;
