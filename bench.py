@@ -115,12 +115,22 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
     import torch
+    # CRBM_BENCH_BACKEND=gloo rehearses the N>1 plumbing on a box with ONE GPU
+    # (all ranks share device 0, no RCCL communicator); the driver's runs use nccl.
+    backend = os.environ.get("CRBM_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank = 0
+        os.environ["LOCAL_RANK"] = "0"
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "gloo":
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    red_dev = "cpu" if backend == "gloo" else "cuda"
 
     def barrier():
         if dist is not None:
@@ -149,7 +159,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed, total_ms.value / 1e3], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, total_ms.value / 1e3], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_s = float(t[0]), float(t[1])
     else:
@@ -166,7 +176,7 @@ def main():
     train = None
     if not args.no_train:
         try:
-            if world > 1:
+            if world > 1 and backend != "gloo":
                 uid = cdist.exchange_unique_id(rank, world)
                 buf = (ctypes.c_uint8 * _lib.UNIQUE_ID_BYTES).from_buffer_copy(uid)
                 model._call("crbm_comm_init", buf, world, rank)
@@ -182,11 +192,11 @@ def main():
             barrier()
             tel = time.perf_counter() - t1
             if dist is not None:
-                tt = torch.tensor([tel], dtype=torch.float64, device="cuda")
+                tt = torch.tensor([tel], dtype=torch.float64, device=red_dev)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 tel = float(tt[0])
             train = {"train_steps_per_s": tsteps / tel, "global_batch": n * world, "cd_k": k,
-                     "all_reduce": "rccl" if world > 1 else "none", "ms_per_train_step": 1e3 * tel / tsteps}
+                     "all_reduce": "rccl" if (world > 1 and backend != "gloo") else "none", "ms_per_train_step": 1e3 * tel / tsteps}
         except Exception as e:                      # report, never hide: the headline is the Gibbs metric
             train = {"error": str(e)[:300]}
 

@@ -176,8 +176,7 @@ __device__ __forceinline__ void conv_gather(const float* T, uint64_t win, float 
 #pragma unroll
     for (int q = 0; q < C::KP; ++q) x[q] = 0.f;
   }
-#pragma unroll
-  for (int g = 0; g < C::NG; ++g) {
+  auto group = [&](int g) {
     const uint32_t r = (uint32_t)(win >> (2 * C::G * g)) & (uint32_t)(C::ROWS - 1);
     const float4* row = reinterpret_cast<const float4*>(T + (size_t)g * C::ROWS * C::KP) + (size_t)r * C::NQ;
 #pragma unroll
@@ -188,6 +187,14 @@ __device__ __forceinline__ void conv_gather(const float* T, uint64_t win, float 
       x[4 * q + 2] += t.z;
       x[4 * q + 3] += t.w;
     }
+  };
+  if constexpr (C::NG * C::NQ <= 48) {
+#pragma unroll
+    for (int g = 0; g < C::NG; ++g) group(g);
+  } else {
+    // large models: a rolled loop keeps the in-flight LDS reads (and registers) bounded
+#pragma unroll 1
+    for (int g = 0; g < C::NG; ++g) group(g);
   }
 }
 
@@ -431,7 +438,7 @@ __device__ void gibbs_body(const GibbsArgs& a) {
         } else {
           const float4* Wt = reinterpret_cast<const float4*>(smem + C::OFF_WT);   // [jr][slot] -> W[k][0..3][M-1-jr]
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
+          for (int i = 0; i < 4; ++i) {   // y[i] is indexed statically; the bit loops below are runtime loops
             const uint32_t* mrow = hm + (size_t)nl * rowW + (size_t)(p0 + i) * NW;
             for (int jr = 0; jr < M; ++jr) {
 #pragma unroll
@@ -481,8 +488,7 @@ __device__ void gibbs_body(const GibbsArgs& a) {
         const int s0 = 4 * (int)(it - nl * (uint32_t)a.nhb);
         const uint32_t gn = a.rng.seq_offset + (uint32_t)(n0 + nl);
         const uint32_t* lrow = let + (size_t)nl * a.LWs;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        auto one_position = [&](int i) {
           const int s = s0 + i;
           if (s < a.Lf) {
             const uint64_t win = letter_window<M>(lrow, s);
@@ -498,6 +504,15 @@ __device__ void gibbs_body(const GibbsArgs& a) {
               for (int w = 0; w < NW; ++w) dst[w] = mask[w];
             }
           }
+        };
+        if constexpr (C::KP * (1 + C::DS) <= 16) {
+          // small models: the 4 positions of the block interleave (ILP)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) one_position(i);
+        } else {
+          // large models: one position at a time keeps x[] in registers
+#pragma unroll 1
+          for (int i = 0; i < 4; ++i) one_position(i);
         }
       }
     }

@@ -314,3 +314,79 @@ def test_golden_fixtures(golden_dir):
         np.testing.assert_allclose(m.c.get_value(), g[tag + "_c_after"], rtol=RTOL, atol=5e-6)
         h, _ = m.get_fantasy()
         assert (h != g[tag + "_fh_after"]).mean() < 1e-3
+
+
+# ---- full BASELINE sizes: size-independent properties (the oracle is too slow here) ----------
+def _cfg2_model(chains, offset=0, seed=2026, **kw):
+    from crbm_amd import CRBM
+    m = CRBM(10, 15, doublestranded=False, batchsize=chains, cd_k=1, fantasy_hidden_len=186, seed=seed, **kw)
+    m.motifs.set_value(np.random.default_rng(42).standard_normal((10, 1, 4, 15)).astype(np.float32))
+    m._h()
+    m._call("crbm_set_shard", offset)
+    return m
+
+
+def test_full_size_chain_properties():
+    """Config #2 at 8192 chains: determinism, k-step composition, shard
+    invariance (what 1 -> N GPUs relies on), one-hot visible samples, and
+    agreement of the first chains with the oracle."""
+    B = 8192
+    a = _cfg2_model(B)
+    a.gibbsSteps(3)
+    ha, _ = a.get_fantasy()
+    va = a.get_fantasy_visible()
+    np.testing.assert_array_equal(va.sum(axis=2), 1.0)                  # one 1 per position
+    assert 0.001 < ha.mean() < 0.2
+    b = _cfg2_model(B)                                                   # same seed: identical
+    b.gibbsSteps(1); b.gibbsSteps(2)                                     # 1 + 2 == 3
+    hb, _ = b.get_fantasy()
+    np.testing.assert_array_equal(ha, hb)
+    lo = _cfg2_model(B // 2, 0)                                          # two "ranks"
+    hi = _cfg2_model(B // 2, B // 2)
+    lo.gibbsSteps(3); hi.gibbsSteps(3)
+    np.testing.assert_array_equal(np.concatenate([lo.get_fantasy()[0], hi.get_fantasy()[0]]), ha)
+    c = _cfg2_model(B, seed=7)                                           # another seed: different chain
+    c.gibbsSteps(3)
+    assert (c.get_fantasy()[0] != ha).mean() > 1e-3
+    # first 32 chains against the oracle
+    o = OracleCRBM(10, 15, doublestranded=False, batchsize=32, cd_k=1, fantasy_hidden_len=186, seed=2026,
+                   W=np.random.default_rng(42).standard_normal((10, 1, 4, 15)).astype(np.float32))
+    o.gibbs_steps(3)
+    assert (ha[:32] != o.fantasy_h).mean() < 1e-4
+
+
+def test_full_size_geometry_independence(monkeypatch):
+    """The chain must not depend on tile size / block size (launch geometry)."""
+    B = 4096
+    ref = _cfg2_model(B)
+    ref.gibbsSteps(2)
+    h0, _ = ref.get_fantasy()
+    for S, T in ((3, 128), (16, 256), (5, 64)):
+        monkeypatch.setenv("CRBM_GIBBS_S", str(S))
+        monkeypatch.setenv("CRBM_GIBBS_THREADS", str(T))
+        m = _cfg2_model(B)
+        m.gibbsSteps(2)
+        np.testing.assert_array_equal(m.get_fantasy()[0], h0)
+    monkeypatch.delenv("CRBM_GIBBS_S"); monkeypatch.delenv("CRBM_GIBBS_THREADS")
+
+
+@pytest.mark.parametrize("K,M,ds,L,chains", [(50, 25, False, 1000, 2048), (20, 15, True, 500, 4096)])
+def test_large_config_train_and_chain(K, M, ds, L, chains):
+    """Configs #4 / #5 model sizes at (reduced-batch) full sequence length:
+    a training step keeps everything finite, c stays letter-symmetric, the
+    chain composes, the first chains match the oracle."""
+    from crbm_amd import CRBM
+    Lf = L - M + 1
+    W = np.random.default_rng(42).standard_normal((K, 1, 4, M)).astype(np.float32)
+    m = CRBM(K, M, doublestranded=ds, batchsize=chains, cd_k=2, fantasy_hidden_len=Lf, seed=3)
+    m.motifs.set_value(W)
+    D = synthetic_onehot(256, L, seed=5)
+    m._trainingFct(D)
+    Wn, cn = m.motifs.get_value(), m.c.get_value()
+    assert np.isfinite(Wn).all() and not np.array_equal(Wn, W)
+    np.testing.assert_allclose(cn[0], cn[0, ::-1], atol=1e-6)
+    h1, _ = m.get_fantasy()
+    assert h1.shape == (chains, K, 1, Lf) and set(np.unique(h1)) <= {0.0, 1.0}
+    o = OracleCRBM(K, M, doublestranded=ds, batchsize=4, cd_k=2, fantasy_hidden_len=Lf, seed=3, W=W)
+    o.gibbs_steps(2)                       # the chain of step 1 does not depend on the data
+    assert (h1[:4] != o.fantasy_h).mean() < 1e-4
