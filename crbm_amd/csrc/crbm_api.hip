@@ -120,7 +120,7 @@ struct crbm_handle {
   // launch geometry
   GibbsLayout gl;
   int gibbs_threads = 256, gibbs_grid = 0;
-  int stats_threads = 256, stats_rows = 0;
+  int stats_rows = 0, stats_lds_budget = 72 * 1024;
   SumsLayout sl;
   // data parallel
   ncclComm_t comm = nullptr;
@@ -248,25 +248,28 @@ int launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool d
   int rc = ensure_tables(h);
   if (rc) return rc;
   const int want_sp = data_half ? 1 : 0;
-  const StatsLayout st = stats_layout(h->ms, want_sp, h->stats_threads);
+  const int Lh = L - h->M + 1;
+  const StatsLayout st = stats_layout(h->ms, want_sp, Lh, n, h->stats_lds_budget);
   StatsArgs a;
   a.tables = h->d_tables;
   a.letters = d_letters;
-  a.n = n; a.L = L; a.Lh = L - h->M + 1; a.LW = letter_words(L);
-  a.TS = tile_seqs(std::max(a.Lh, L), 8192);
-  a.divLh = make_fastdiv((uint32_t)a.Lh);
-  a.divL = make_fastdiv((uint32_t)L);
+  a.n = n; a.L = L; a.Lh = Lh; a.LW = letter_words(L);
+  a.S = st.S; a.LS = st.LS; a.nseg = st.nseg; a.Rrow = st.Rrow;
+  a.PB = st.PB; a.parts = st.parts; a.npasses = st.npasses;
   a.want_sparsity = want_sp;
-  a.ntiles = st.ntiles;
+  a.divLS = make_fastdiv((uint32_t)st.LS);
+  a.divLvis = make_fastdiv((uint32_t)(st.LS + h->M - 1));   // only used when nseg == 1 (S > 1)
+  a.divL = make_fastdiv((uint32_t)L);
   a.row = st.row;
   a.off_vh0 = st.off_vh[0]; a.off_vh1 = st.off_vh[1]; a.off_h0 = st.off_h[0]; a.off_h1 = st.off_h[1];
   a.off_sw = st.off_sw; a.off_sb = st.off_sb; a.off_v = st.off_v;
-  const int nseqtiles = (n + a.TS - 1) / a.TS;
-  const int rows = std::max(1, std::min(nseqtiles, h->stats_rows));
+  const int ntiles = ((n + st.S - 1) / st.S) * st.nseg;
+  const int gx = std::max(1, std::min(ntiles, h->stats_rows));
+  const int rows = gx * st.parts;
   HIPCHK(h->partials.ensure((size_t)rows * st.row));
   a.partials = h->partials.p;
   HIPCHK(hipMemsetAsync(h->partials.p, 0, (size_t)rows * st.row * sizeof(float), h->stream));
-  HIPCHK(jit_launch(h->jk.stats, a, (unsigned)rows, (unsigned)st.grid_y, (unsigned)h->stats_threads,
+  HIPCHK(jit_launch(h->jk.stats, a, (unsigned)gx, (unsigned)st.grid_y, (unsigned)st.threads,
                     (unsigned)st.lds_bytes, h->stream));
   ReduceArgs r;
   r.partials = h->partials.p;
@@ -388,7 +391,7 @@ GibbsGeom choose_gibbs_geometry(const ModelShape& ms, int Lf, int B, int num_cu)
     for (int S = 1; S <= std::min(B, 64); ++S) {
       if (forceS > 0 && S != forceS) continue;
       const GibbsLayout gl = gibbs_layout(ms, Lf, S);
-      if (gl.lds_bytes > 64 * 1024 && !(forceS > 0)) continue;
+      if (gl.lds_bytes > 100 * 1024 && !(forceS > 0)) continue;
       if (gl.lds_bytes > 160 * 1024 || (long)S * gl.Lrow * ms.NW >= (1 << 20)) continue;
       // lanes are used at wave granularity (an idle wave of a pass costs nothing);
       // h|v costs ~1.5x v|h per 4-position block
@@ -507,8 +510,8 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
   TRY(hipMalloc((void**)&hh->d_sums, (size_t)hh->sl.count * 4)); TRY(hipMemset(hh->d_sums, 0, (size_t)hh->sl.count * 4));
 #undef TRY
   hh->tables_dirty = true;
-  hh->stats_threads = 256;
   hh->stats_rows = env_int("CRBM_STATS_ROWS", 2 * hh->num_cu);
+  hh->stats_lds_budget = env_int("CRBM_STATS_LDS", 72 * 1024);
   *out = hh;
   return CRBM_OK;
 }
@@ -987,12 +990,12 @@ int crbm_train_apply(crbm_handle* h, const float* sums_in, int32_t L_data) {
 
 int crbm_get_launch_info(const crbm_handle* h, crbm_launch_info* out) {
   if (!h || !out) return CRBM_ERR_INVALID;
-  const StatsLayout st = stats_layout(h->ms, 1, h->stats_threads);
+  const StatsLayout st = stats_layout(h->ms, 1, h->Lf, h->B, h->stats_lds_budget);
   out->nq = h->ms.NQ; out->group = h->G;
   out->gibbs_grid = h->gibbs_grid; out->gibbs_block = h->gibbs_threads;
   out->gibbs_seqs_per_tile = h->gl.S; out->gibbs_lds_bytes = h->gl.lds_bytes;
   out->stats_grid_x = h->stats_rows; out->stats_grid_y = st.grid_y;
-  out->stats_block = h->stats_threads; out->stats_lds_bytes = st.lds_bytes;
+  out->stats_block = st.threads; out->stats_lds_bytes = st.lds_bytes;
   return CRBM_OK;
 }
 

@@ -540,59 +540,76 @@ __device__ void gibbs_body(const GibbsArgs& a) {
 //   P(1-P)[k,s] * onehot[a,s+j]     -> sw   (forward strand, if want_sparsity)
 //   P[k,s], P(1-P)[k,s]             -> h, sb
 //   onehot[a,p]                     -> v    (letter counts)
-// Phase A: one thread per hidden position computes P (and P') and parks it in
-// LDS.  Phase B: each wave owns one accumulator tile [4][JC][KC] in registers
-// for the whole kernel and streams every parked item through it; per-block
-// partial sums are written once at the end (deterministic order).
+// Because the visible layer is one-hot, VH[k,a,j] = sum over the visible
+// positions p whose letter is a of P[k, p-j]: exactly one add per (k,j,p)
+// instead of four masked FMAs.  A tile (whole chains, or one segment of a long
+// chain) is processed in two phases:
+//  A  every thread computes P (and P') of one hidden position and parks the
+//     row in LDS (zero rows pad both ends of every chain segment);
+//  B  each wave owns one accumulator tile acc[M][KT] of one pass
+//     (class x k-tile) for the whole kernel.  It buckets its share of the
+//     visible positions by letter (ballot + popcount: deterministic order) and
+//     lane l then only ever takes positions of letter l&3, adding the M parked
+//     rows p, p-1, .., p-M+1 into its registers.
+// At the end the 16 lanes of each letter are summed with shuffles and every
+// (block, wave) writes its own partial row: fixed summation order.
 // ---------------------------------------------------------------------------
 struct StatsArgs {
   const float* tables;
   const uint32_t* letters;
   int32_t n, L, Lh, LW;
-  int32_t TS;
-  FastDiv divLh, divL;
+  int32_t S;            // chains per tile (1 when a chain is split into segments)
+  int32_t LS;           // hidden positions per segment (= Lh when nseg == 1)
+  int32_t nseg;         // segments per chain
+  int32_t Rrow;         // parked rows per chain segment = LS + 2(M-1)
+  int32_t PB, parts;    // passes per block, position parts per pass (PB*parts == waves per block)
+  int32_t npasses;      // classes * k-tiles
   int32_t want_sparsity;
-  int32_t ntiles;
+  FastDiv divLS, divLvis, divL;   // / LS, / (LS+M-1), / L
   int32_t row, off_vh0, off_vh1, off_h0, off_h1, off_sw, off_sb, off_v;
-  float* partials;     // [gridDim.x][row], zero-initialised by the host
+  float* partials;      // [gridDim.x * parts][row], zero-initialised by the host
 };
 
 template <class C>
 __device__ void stats_body(const StatsArgs& a) {
-  constexpr int KP = C::KP, K = C::K, M = C::M;
-  constexpr int NQC = C::NQC, KC = C::KC, JC = C::JC;
+  constexpr int KP = C::KP, K = C::K, M = C::M, KT = C::KT, NKT = C::NKT;
+  constexpr int CH = 512;                                // positions bucketed at a time per wave
   HIP_DYNAMIC_SHARED(float, smem);
-  const int nthr = blockDim.x;
+  const int nthr = blockDim.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = nthr >> 6;
   float* Tf = smem;
   float* Tr = Tf + C::TAB;
-  float* Pb0 = Tr + (C::DS ? C::TAB : 0);               // [nthr][KP]
-  float* Pb1 = Pb0 + (size_t)nthr * KP;                 // [nthr][KP] (ds)
-  uint32_t* Win = reinterpret_cast<uint32_t*>(Pb1 + (C::DS ? (size_t)nthr * KP : 0));   // [nthr][2]
-  float* red = reinterpret_cast<float*>(Win + 2 * nthr);                                 // [64]
+  float* Pb0 = Tr + (C::DS ? C::TAB : 0);                       // [S*Rrow][KP]
+  float* Pb1 = Pb0 + (size_t)a.S * a.Rrow * KP + KT;            // (ds); KT floats of slack: the last
+  // k-tile may read past KP (those columns have k >= K and are dropped)
+  unsigned short* lists = reinterpret_cast<unsigned short*>(Pb1 + (C::DS ? (size_t)a.S * a.Rrow * KP + KT : 0));
+  unsigned short* mylist = lists + (size_t)wave * 4 * CH;       // [4][CH] per wave
+  float* red = reinterpret_cast<float*>(lists + (size_t)nwaves * 4 * CH);   // [16]
 
   copy_tables<C::TAB>(Tf, a.tables + C::OFF_TF);
   if (C::DS) copy_tables<C::TAB>(Tr, a.tables + C::OFF_TR);
+  // pad rows stay zero for the whole kernel
+  for (int i = threadIdx.x; i < a.S * a.Rrow * KP; i += nthr) {
+    Pb0[i] = 0.f;
+    if (C::DS) Pb1[i] = 0.f;
+  }
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = nthr >> 6;
-  // accumulator tile of this wave: (class, kt, jt)
-  const int tile_id = blockIdx.y * nwaves + wave;
-  const bool active = tile_id < a.ntiles;
-  int t_jt = 0, t_kt = 0, t_kind = 0, t_strand = 0;
+  // this wave's pass (class, k-tile) and its share of the visible positions
+  const int pass = blockIdx.y * a.PB + (wave % a.PB);
+  const int part = wave / a.PB;
+  const bool active = pass < a.npasses;
+  int t_kt = 0, t_kind = 0, t_strand = 0;
   if (active) {
-    int t = tile_id;
-    t_jt = t % C::NTJ; t /= C::NTJ;
-    t_kt = t % C::NTK; t /= C::NTK;
-    // accumulator classes: 0 = vh (forward strand), 1 = vh' (ds only), last = sw (forward, P(1-P))
+    int t = pass;
+    t_kt = t % NKT; t /= NKT;
+    // classes: 0 = vh (forward strand), 1 = vh' (ds only), last = sw (forward, P(1-P))
     t_kind = (a.want_sparsity && t == C::DS + 1) ? 1 : 0;
     t_strand = (!t_kind && t == 1) ? 1 : 0;
   }
-  float acc[4][JC][KC];
+  float acc[M][KT];
 #pragma unroll
-  for (int l = 0; l < 4; ++l)
+  for (int j = 0; j < M; ++j)
 #pragma unroll
-    for (int jj = 0; jj < JC; ++jj)
-#pragma unroll
-      for (int q = 0; q < KC; ++q) acc[l][jj][q] = 0.f;
+    for (int q = 0; q < KT; ++q) acc[j][q] = 0.f;
 
   const bool owner = blockIdx.y == 0;   // h / sb / letter counts are accumulated once
   float hs0[KP], hs1[KP], sb[KP];
@@ -600,84 +617,49 @@ __device__ void stats_body(const StatsArgs& a) {
   for (int q = 0; q < KP; ++q) { hs0[q] = 0.f; hs1[q] = 0.f; sb[q] = 0.f; }
   float vc0 = 0.f, vc1 = 0.f, vc2 = 0.f, vc3 = 0.f;
 
-  const int nseqtiles = (a.n + a.TS - 1) / a.TS;
-  for (int tile = blockIdx.x; tile < nseqtiles; tile += gridDim.x) {
-    const int n0 = tile * a.TS;
-    const int ns = min(a.TS, a.n - n0);
-    const uint32_t items = (uint32_t)ns * (uint32_t)a.Lh;
-    for (uint32_t base = 0; base < items; base += nthr) {
-      __syncthreads();   // tables copied / previous batch consumed
-      const uint32_t i = base + threadIdx.x;
-      float* p0 = Pb0 + (size_t)threadIdx.x * KP;
-      float* p1 = Pb1 + (size_t)threadIdx.x * KP;
-      if (i < items) {
-        const uint32_t nl = fastdiv(i, a.divLh);
-        const int s = (int)(i - nl * (uint32_t)a.Lh);
-        const uint64_t win = letter_window<M>(a.letters + (size_t)(n0 + nl) * a.LW, s);
-        Win[2 * threadIdx.x] = (uint32_t)win;
-        Win[2 * threadIdx.x + 1] = (uint32_t)(win >> 32);
-        float x[KP];
-        conv_gather<C>(Tf, win, x);
+  const int my_class = lane & 3, my_slot = lane >> 2;
+  const int ngroups = (a.n + a.S - 1) / a.S;
+  const int ntiles = ngroups * a.nseg;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int grp = tile / a.nseg, seg = tile - grp * a.nseg;
+    const int n0 = grp * a.S;
+    const int ns = min(a.S, a.n - n0);
+    const int s0 = seg * a.LS;
+    const int len = min(a.LS, a.Lh - s0);          // hidden positions of this segment
+    const int lvis = len + M - 1;                  // visible positions that touch it
+    __syncthreads();                               // previous tile fully consumed / tables + zero rows ready
+    // ---- phase A: park P rows (zero beyond the segment / beyond the last chain) ----
+    for (uint32_t i = threadIdx.x; i < (uint32_t)(a.S * a.LS); i += nthr) {
+      const uint32_t nl = fastdiv(i, a.divLS);
+      const int sr = (int)(i - nl * (uint32_t)a.LS);
+      float* p0 = Pb0 + ((size_t)nl * a.Rrow + (M - 1) + sr) * KP;
+      float* p1 = Pb1 + ((size_t)nl * a.Rrow + (M - 1) + sr) * KP;
+      if ((int)nl < ns && sr < len) {
+        const uint64_t win = letter_window<M>(a.letters + (size_t)(n0 + nl) * a.LW, s0 + sr);
+        float z[KP];
+        conv_gather<C>(Tf, win, z);
 #pragma unroll
         for (int q = 0; q < KP; ++q) {
-          const float p = sigmoid_z(x[q]);
+          const float p = sigmoid_z(z[q]);
           p0[q] = p;
           if (owner) { hs0[q] += p; sb[q] += p * (1.f - p); }
         }
         if (C::DS) {
-          conv_gather<C>(Tr, win, x);
+          conv_gather<C>(Tr, win, z);
 #pragma unroll
           for (int q = 0; q < KP; ++q) {
-            const float p = sigmoid_z(x[q]);
+            const float p = sigmoid_z(z[q]);
             p1[q] = p;
             if (owner) hs1[q] += p;
           }
         }
       } else {
-        Win[2 * threadIdx.x] = 0u;
-        Win[2 * threadIdx.x + 1] = 0u;
 #pragma unroll
         for (int q = 0; q < KP; ++q) { p0[q] = 0.f; if (C::DS) p1[q] = 0.f; }
       }
-      __syncthreads();
-      if (active) {
-        const float* Pb = t_strand ? Pb1 : Pb0;
-        for (int c = 0; c < nwaves; ++c) {
-          const int it = c * 64 + lane;
-          const uint64_t win = (uint64_t)Win[2 * it] | ((uint64_t)Win[2 * it + 1] << 32);
-          float pk[KC];
-          const float4* src = reinterpret_cast<const float4*>(Pb + (size_t)it * KP + t_kt * KC);
-#pragma unroll
-          for (int q = 0; q < NQC; ++q) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t_kt * NQC + q < C::NQ) v = src[q];
-            pk[4 * q] = v.x; pk[4 * q + 1] = v.y; pk[4 * q + 2] = v.z; pk[4 * q + 3] = v.w;
-          }
-          if (t_kind) {
-#pragma unroll
-            for (int q = 0; q < KC; ++q) pk[q] = pk[q] * (1.f - pk[q]);
-          }
-#pragma unroll
-          for (int jj = 0; jj < JC; ++jj) {
-            const int j = t_jt * JC + jj;
-            if (j < M) {
-              const uint32_t l = (uint32_t)(win >> (2 * j)) & 3u;
-              const float m0 = l == 0u ? 1.f : 0.f, m1 = l == 1u ? 1.f : 0.f;
-              const float m2 = l == 2u ? 1.f : 0.f, m3 = l == 3u ? 1.f : 0.f;
-#pragma unroll
-              for (int q = 0; q < KC; ++q) {
-                acc[0][jj][q] = fmaf(m0, pk[q], acc[0][jj][q]);
-                acc[1][jj][q] = fmaf(m1, pk[q], acc[1][jj][q]);
-                acc[2][jj][q] = fmaf(m2, pk[q], acc[2][jj][q]);
-                acc[3][jj][q] = fmaf(m3, pk[q], acc[3][jj][q]);
-              }
-            }
-          }
-        }
-      }
     }
-    // letter counts of the whole visible rows of this tile
-    if (owner) {
+    // letter counts: every visible position exactly once (segment 0 of each chain)
+    if (owner && seg == 0) {
       const uint32_t vitems = (uint32_t)ns * (uint32_t)a.L;
       for (uint32_t i = threadIdx.x; i < vitems; i += nthr) {
         const uint32_t nl = fastdiv(i, a.divL);
@@ -687,25 +669,85 @@ __device__ void stats_body(const StatsArgs& a) {
         vc2 += l == 2u ? 1.f : 0.f; vc3 += l == 3u ? 1.f : 0.f;
       }
     }
+    __syncthreads();
+    // ---- phase B ----
+    if (active) {
+      const float* Pb = (t_strand ? Pb1 : Pb0) + t_kt * KT;
+      const int V = ns * lvis;                                   // flattened visible positions of the tile
+      const int per = (V + a.parts - 1) / a.parts;
+      const int v_lo = part * per, v_hi = min(V, v_lo + per);
+      for (int c0 = v_lo; c0 < v_hi; c0 += CH) {
+        const int c1 = min(v_hi, c0 + CH);
+        // bucket positions c0..c1 by letter; rank = order of appearance
+        int cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0;
+        for (int base = c0; base < c1; base += 64) {
+          const int v = base + lane;
+          const bool valid = v < c1;
+          uint32_t l = 0u;
+          if (valid) {
+            const uint32_t nl = fastdiv((uint32_t)v, a.divLvis);
+            const int pr = v - (int)nl * lvis;
+            const int p = s0 + pr;
+            l = (a.letters[(size_t)(n0 + nl) * a.LW + (p >> 4)] >> (2 * (p & 15))) & 3u;
+          }
+          const unsigned long long b0 = __ballot(valid && l == 0u), b1 = __ballot(valid && l == 1u);
+          const unsigned long long b2 = __ballot(valid && l == 2u), b3 = __ballot(valid && l == 3u);
+          const unsigned long long below = (1ull << lane) - 1ull;
+          if (valid) {
+            const unsigned long long mine = l == 0u ? b0 : l == 1u ? b1 : l == 2u ? b2 : b3;
+            const int basecnt = l == 0u ? cnt0 : l == 1u ? cnt1 : l == 2u ? cnt2 : cnt3;
+            mylist[l * CH + basecnt + __popcll(mine & below)] = (unsigned short)(v - c0);
+          }
+          cnt0 += __popcll(b0); cnt1 += __popcll(b1); cnt2 += __popcll(b2); cnt3 += __popcll(b3);
+        }
+        // the lists are private to this wave: LDS operations of one wave complete in
+        // order, so no workgroup barrier is needed between filling and reading them
+        __builtin_amdgcn_wave_barrier();
+        const int mycnt = my_class == 0 ? cnt0 : my_class == 1 ? cnt1 : my_class == 2 ? cnt2 : cnt3;
+        const int maxcnt = max(max(cnt0, cnt1), max(cnt2, cnt3));
+        for (int e = my_slot; e < maxcnt; e += 16) {
+          if (e < mycnt) {
+            const int v = c0 + (int)mylist[my_class * CH + e];
+            const uint32_t nl = fastdiv((uint32_t)v, a.divLvis);
+            const int pr = v - (int)nl * lvis;
+            // parked row of hidden position (pr - j) sits at index (M-1) + pr - j
+            const float* rowp = Pb + ((size_t)nl * a.Rrow + (M - 1) + pr) * KP;
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+              const float4* r4 = reinterpret_cast<const float4*>(rowp - (size_t)j * KP);
+#pragma unroll
+              for (int q = 0; q < KT / 4; ++q) {
+                float4 t = r4[q];
+                if (t_kind) {
+                  t.x = t.x * (1.f - t.x); t.y = t.y * (1.f - t.y); t.z = t.z * (1.f - t.z); t.w = t.w * (1.f - t.w);
+                }
+                acc[j][4 * q] += t.x; acc[j][4 * q + 1] += t.y; acc[j][4 * q + 2] += t.z; acc[j][4 * q + 3] += t.w;
+              }
+            }
+          }
+        }
+        __builtin_amdgcn_wave_barrier();   // lists are rewritten by the next chunk
+      }
+    }
   }
 
-  float* out = a.partials + (size_t)blockIdx.x * a.row;
-  // accumulator tiles: wave reduction, lane 0 writes (each slot has exactly one writer)
+  float* out = a.partials + ((size_t)blockIdx.x * a.parts + part) * a.row;
+  // lanes of equal letter (lane & 3) -> lanes 0..3, then one writer per slot
   if (active) {
     const int off = t_kind ? a.off_sw : (t_strand ? a.off_vh1 : a.off_vh0);
 #pragma unroll
-    for (int l = 0; l < 4; ++l)
+    for (int j = 0; j < M; ++j)
 #pragma unroll
-      for (int jj = 0; jj < JC; ++jj)
-#pragma unroll
-        for (int q = 0; q < KC; ++q) {
-          const float v = wave_sum(acc[l][jj][q]);
-          const int k = t_kt * KC + q, j = t_jt * JC + jj;
-          if (lane == 0 && k < K && j < M) out[off + (k * 4 + l) * M + j] = v;
-        }
+      for (int q = 0; q < KT; ++q) {
+        float v = acc[j][q];
+        v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+        const int k = t_kt * KT + q;
+        if (lane < 4 && k < K) out[off + (k * 4 + lane) * M + j] = v;
+      }
   }
   if (owner) {
-    // per-thread sums -> wave -> block (through LDS), fixed order
+    // per-thread sums -> wave -> block (through LDS), fixed order; stored in part 0's row
+    float* out0 = a.partials + (size_t)blockIdx.x * a.parts * a.row;
     auto block_sum_store = [&](float v, int dst) {
       v = wave_sum(v);
       __syncthreads();
@@ -714,7 +756,7 @@ __device__ void stats_body(const StatsArgs& a) {
       if (threadIdx.x == 0) {
         float t = 0.f;
         for (int w = 0; w < nwaves; ++w) t += red[w];
-        out[dst] = t;
+        out0[dst] = t;
       }
     };
 #pragma unroll

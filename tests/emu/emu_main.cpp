@@ -154,23 +154,31 @@ int emu_gibbs(int id, const float* tables, uint32_t* hm, uint32_t* hmp, uint32_t
 }
 
 // statistics of one half + deterministic reduction into `sums` (row floats + n)
-int emu_stats(int id, const float* tables, const uint32_t* letters, int n, int L, int LW, int want_sparsity, int TS,
-              int rows, int threads, float* partials, float* sums, int skip_begin, int skip_len) {
+int emu_stats(int id, const float* tables, const uint32_t* letters, int n, int L, int LW, int want_sparsity,
+              int lds_budget, int gx, float* partials, int partials_cap, float* sums, int skip_begin, int skip_len) {
   StatsArgs a;
   a.tables = tables; a.letters = letters; a.n = n; a.L = L; a.LW = LW;
-  a.TS = TS; a.divL = make_fastdiv((uint32_t)L);
+  a.divL = make_fastdiv((uint32_t)L);
   a.want_sparsity = want_sparsity;
   a.partials = partials;
   int row = -1;
   CFG_DISPATCH(id, {
     const ModelShape ms = shape_of<C>();
-    const StatsLayout st = stats_layout(ms, want_sparsity, threads);
-    a.Lh = L - C::M + 1; a.divLh = make_fastdiv((uint32_t)a.Lh);
-    a.ntiles = st.ntiles; a.row = st.row;
+    const int Lh = L - C::M + 1;
+    const StatsLayout st = stats_layout(ms, want_sparsity, Lh, n, lds_budget);
+    a.Lh = Lh;
+    a.S = st.S; a.LS = st.LS; a.nseg = st.nseg; a.Rrow = st.Rrow;
+    a.PB = st.PB; a.parts = st.parts; a.npasses = st.npasses;
+    a.divLS = make_fastdiv((uint32_t)st.LS); a.divLvis = make_fastdiv((uint32_t)(st.LS + C::M - 1));
+    a.row = st.row;
     a.off_vh0 = st.off_vh[0]; a.off_vh1 = st.off_vh[1]; a.off_h0 = st.off_h[0]; a.off_h1 = st.off_h[1];
     a.off_sw = st.off_sw; a.off_sb = st.off_sb; a.off_v = st.off_v;
+    const int ntiles = ((n + st.S - 1) / st.S) * st.nseg;
+    if (gx > ntiles) gx = ntiles;
+    const int rows = gx * st.parts;
+    if ((long)rows * st.row > partials_cap) return -2;
     memset(partials, 0, sizeof(float) * (size_t)rows * st.row);
-    emu::launch([&] { stats_body<C>(a); }, dim3(rows, st.grid_y), dim3(threads), (size_t)st.lds_bytes);
+    emu::launch([&] { stats_body<C>(a); }, dim3(gx, st.grid_y), dim3(st.threads), (size_t)st.lds_bytes);
     // column sums on the host (the reduce kernel itself is emulated by emu_reduce
     // on a small case: one OS thread per GPU thread is too slow for ~2000 columns)
     const int sb = skip_begin < 0 ? st.row : skip_begin, sl = skip_begin < 0 ? 0 : skip_len;

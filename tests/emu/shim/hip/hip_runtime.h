@@ -60,6 +60,34 @@ static inline float __shfl_down(float v, int off, int width = 64) {
   return r;
 }
 
+static inline float __shfl_xor(float v, int mask, int width = 64) {
+  const unsigned lane = emu::t_threadIdx.x & 63u, wave = emu::t_threadIdx.x >> 6;
+  float* s = emu::t_ctx->wave_scratch + wave * 64;
+  s[lane] = v;
+  pthread_barrier_wait(&emu::t_ctx->wave_bar[wave]);
+  const float r = s[(lane ^ (unsigned)mask) & 63u];
+  pthread_barrier_wait(&emu::t_ctx->wave_bar[wave]);
+  (void)width;
+  return r;
+}
+
+// all 64 lanes of the wave must call it (true for the uses in crbm_kernels.h)
+static inline unsigned long long __ballot(int pred) {
+  const unsigned lane = emu::t_threadIdx.x & 63u, wave = emu::t_threadIdx.x >> 6;
+  float* s = emu::t_ctx->wave_scratch + wave * 64;
+  s[lane] = pred ? 1.f : 0.f;
+  pthread_barrier_wait(&emu::t_ctx->wave_bar[wave]);
+  unsigned long long m = 0;
+  for (unsigned i = 0; i < 64; ++i) m |= (unsigned long long)(s[i] != 0.f) << i;
+  pthread_barrier_wait(&emu::t_ctx->wave_bar[wave]);
+  return m;
+}
+// lanes of a wave run in lockstep on the GPU; here they are OS threads
+static inline void __builtin_amdgcn_wave_barrier() {
+  pthread_barrier_wait(&emu::t_ctx->wave_bar[emu::t_threadIdx.x >> 6]);
+}
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+
 // Only used to decide whether a wave takes a slow path that is a no-op for lanes
 // that do not need it, so the lane-local answer is an exact emulation.
 static inline int __any(int pred) { return pred; }
