@@ -120,7 +120,7 @@ struct crbm_handle {
   // launch geometry
   GibbsLayout gl;
   int gibbs_threads = 256, gibbs_grid = 0;
-  int stats_rows = 0, stats_lds_budget = 72 * 1024;
+  int stats_rows = 0, stats_lds_budget = 48 * 1024;
   SumsLayout sl;
   // data parallel
   ncclComm_t comm = nullptr;
@@ -254,7 +254,7 @@ int launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool d
   a.tables = h->d_tables;
   a.letters = d_letters;
   a.n = n; a.L = L; a.Lh = Lh; a.LW = letter_words(L);
-  a.S = st.S; a.LS = st.LS; a.nseg = st.nseg; a.Rrow = st.Rrow;
+  a.S = st.S; a.LS = st.LS; a.nseg = st.nseg; a.Rrow = st.Rrow; a.LWt = st.LWt;
   a.PB = st.PB; a.parts = st.parts; a.npasses = st.npasses;
   a.want_sparsity = want_sp;
   a.divLS = make_fastdiv((uint32_t)st.LS);
@@ -268,6 +268,7 @@ int launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool d
   const int rows = gx * st.parts;
   HIPCHK(h->partials.ensure((size_t)rows * st.row));
   a.partials = h->partials.p;
+  a.debug = env_int("CRBM_STATS_DEBUG", 0);
   HIPCHK(hipMemsetAsync(h->partials.p, 0, (size_t)rows * st.row * sizeof(float), h->stream));
   HIPCHK(jit_launch(h->jk.stats, a, (unsigned)gx, (unsigned)st.grid_y, (unsigned)st.threads,
                     (unsigned)st.lds_bytes, h->stream));
@@ -282,7 +283,7 @@ int launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool d
     r.skip_begin = h->sl.model_skip_begin; r.skip_len = h->sl.model_skip_len;
   }
   r.n_value = (float)n;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((st.row + 3) / 4), dim3(256), 0, h->stream, r);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((st.row + 15) / 16), dim3(1024), 0, h->stream, r);
   HIPCHK(hipGetLastError());
   return CRBM_OK;
 }
@@ -511,7 +512,7 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
 #undef TRY
   hh->tables_dirty = true;
   hh->stats_rows = env_int("CRBM_STATS_ROWS", 2 * hh->num_cu);
-  hh->stats_lds_budget = env_int("CRBM_STATS_LDS", 72 * 1024);
+  hh->stats_lds_budget = env_int("CRBM_STATS_LDS", 48 * 1024);
   *out = hh;
   return CRBM_OK;
 }

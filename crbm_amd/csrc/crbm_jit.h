@@ -69,7 +69,7 @@ inline std::string jit_stub(int K, int M, int DS, int G) {
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_build_tables(crbm::TablesArgs a) { crbm::build_tables_body<ModelCfg>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_hgv(crbm::HgvArgs a) { crbm::hgv_body<ModelCfg>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_gibbs(crbm::GibbsArgs a) { crbm::gibbs_body<ModelCfg>(a); }\n"
-           "extern \"C\" __global__ void __launch_bounds__(512) crbm_stats(crbm::StatsArgs a) { crbm::stats_body<ModelCfg>(a); }\n"
+           "extern \"C\" __global__ void __launch_bounds__(256) crbm_stats(crbm::StatsArgs a) { crbm::stats_body<ModelCfg>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_free_energy(crbm::FeArgs a) { crbm::free_energy_body<ModelCfg>(a); }\n",
            K, M, DS, G);
   return buf;

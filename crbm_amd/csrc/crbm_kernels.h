@@ -89,8 +89,20 @@ __device__ __forceinline__ uint32_t fastdiv(uint32_t i, const FastDiv& f) {
 
 // z = -x*log2(e) (what conv_gather returns): exp(-x) = 2^z
 __device__ __forceinline__ float exp_neg_x(float z) { return __builtin_amdgcn_exp2f(z); }
-__device__ __forceinline__ float sigmoid_z(float z) { return __fdividef(1.0f, 1.0f + exp_neg_x(z)); }
+// v_rcp_f32 (1 ulp); __fdividef expands to a full division sequence under hiprtc
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float sigmoid_z(float z) { return fast_rcp(1.0f + exp_neg_x(z)); }
 __device__ __forceinline__ float x_of_z(float z) { return -0.6931471805599453f * z; }
+
+// sum over the 16 lanes that share lane & 3 (all lanes of the class get the total):
+// two row rotations (DPP, VALU only) + two cross-row exchanges
+__device__ __forceinline__ float class_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));   // row_ror:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));   // row_ror:8
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -129,7 +141,7 @@ __device__ __forceinline__ void sample_hidden(const float (&z)[C::KP], uint32_t 
         const uint32_t one = x2 <= 4096.0f ? 1u : 0u;
         amb |= (x1 <= 4096.0f && !(x2 <= 4096.0f)) ? (1u << i) : 0u;
         mask[k >> 5] |= one << (k & 31);
-        if (WANT_P) p[k] = __fdividef(1.0f, 1.0f + e);
+        if (WANT_P) p[k] = fast_rcp(1.0f + e);
       }
     };
     unit(IC<0>{}); unit(IC<1>{}); unit(IC<2>{}); unit(IC<3>{}); unit(IC<4>{});
@@ -142,7 +154,7 @@ __device__ __forceinline__ void sample_hidden(const float (&z)[C::KP], uint32_t 
         if (k < C::K) {
           if (amb & (1u << i)) {
             // P*4096 - coarse lies in [0,1) up to rounding; compare with fine/4096
-            const float t = __fdividef(4096.0f, 1.0f + exp_neg_x(z[k]));
+            const float t = 4096.0f * fast_rcp(1.0f + exp_neg_x(z[k]));
             const float frac = t - (float)philox_field12<i>(rc);
             const uint32_t one = frac * 4096.0f > (float)philox_field12<i>(rf) ? 1u : 0u;
             mask[k >> 5] |= one << (k & 31);
@@ -546,13 +558,14 @@ __device__ void gibbs_body(const GibbsArgs& a) {
 // chain) is processed in two phases:
 //  A  every thread computes P (and P') of one hidden position and parks the
 //     row in LDS (zero rows pad both ends of every chain segment);
-//  B  each wave owns one accumulator tile acc[M][KT] of one pass
-//     (class x k-tile) for the whole kernel.  It buckets its share of the
-//     visible positions by letter (ballot + popcount: deterministic order) and
-//     lane l then only ever takes positions of letter l&3, adding the M parked
-//     rows p, p-1, .., p-M+1 into its registers.
-// At the end the 16 lanes of each letter are summed with shuffles and every
-// (block, wave) writes its own partial row: fixed summation order.
+//  B  each wave owns one pass (vh, vh' or sw) for its share of the tile's
+//     visible positions.  It buckets them by letter (ballot + popcount:
+//     deterministic order); then the 16 lanes of lane-group g walk the
+//     positions of letter g together, lane j adding parked row p-j into its
+//     K registers: the lane that owns (a, j) accumulates VH[:, a, j] directly,
+//     the 16 rows read by a group are consecutive (no LDS bank conflicts) and
+//     no cross-lane reduction is ever needed.
+// Every (block, wave) writes its own partial row: fixed summation order.
 // ---------------------------------------------------------------------------
 struct StatsArgs {
   const float* tables;
@@ -562,54 +575,56 @@ struct StatsArgs {
   int32_t LS;           // hidden positions per segment (= Lh when nseg == 1)
   int32_t nseg;         // segments per chain
   int32_t Rrow;         // parked rows per chain segment = LS + 2(M-1)
+  int32_t LWt;          // letter words staged per chain: covers LS + M - 1 positions from any 16-aligned start, + 2
   int32_t PB, parts;    // passes per block, position parts per pass (PB*parts == waves per block)
-  int32_t npasses;      // classes * k-tiles
+  int32_t npasses;      // 1 + DS + want_sparsity
   int32_t want_sparsity;
   FastDiv divLS, divLvis, divL;   // / LS, / (LS+M-1), / L
   int32_t row, off_vh0, off_vh1, off_h0, off_h1, off_sw, off_sb, off_v;
   float* partials;      // [gridDim.x * parts][row], zero-initialised by the host
+  int32_t debug;        // profiling only: bit 0 skips phase B, bit 1 skips the phase-A arithmetic
 };
 
 template <class C>
 __device__ void stats_body(const StatsArgs& a) {
-  constexpr int KP = C::KP, K = C::K, M = C::M, KT = C::KT, NKT = C::NKT;
-  constexpr int CH = 512;                                // positions bucketed at a time per wave
+  constexpr int KP = C::KP, K = C::K, M = C::M;
+  constexpr int JCH = (M + 15) / 16;                     // filter columns per lane: j = 16*c + (lane & 15)
+  constexpr int CH = C::STATS_CH;                        // positions bucketed at a time per wave
+  constexpr int UNR = 4;                                 // list entries consumed per iteration
   HIP_DYNAMIC_SHARED(float, smem);
   const int nthr = blockDim.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = nthr >> 6;
   float* Tf = smem;
   float* Tr = Tf + C::TAB;
-  float* Pb0 = Tr + (C::DS ? C::TAB : 0);                       // [S*Rrow][KP]
-  float* Pb1 = Pb0 + (size_t)a.S * a.Rrow * KP + KT;            // (ds); KT floats of slack: the last
-  // k-tile may read past KP (those columns have k >= K and are dropped)
-  unsigned short* lists = reinterpret_cast<unsigned short*>(Pb1 + (C::DS ? (size_t)a.S * a.Rrow * KP + KT : 0));
-  unsigned short* mylist = lists + (size_t)wave * 4 * CH;       // [4][CH] per wave
-  float* red = reinterpret_cast<float*>(lists + (size_t)nwaves * 4 * CH);   // [16]
+  // parked rows [S*Rrow][KP] followed by M all-zero rows (target of the list padding)
+  const int nrows = a.S * a.Rrow + M;
+  float* Pb0 = Tr + (C::DS ? C::TAB : 0);
+  float* Pb1 = Pb0 + (size_t)nrows * KP;                        // (ds)
+  unsigned short* lists = reinterpret_cast<unsigned short*>(Pb1 + (C::DS ? (size_t)nrows * KP : 0));
+  unsigned short* mylist = lists + (size_t)wave * 4 * CH;       // [4][CH] per wave: parked-row index of each position
+  float* xch = reinterpret_cast<float*>(lists + (size_t)nwaves * 4 * CH);   // [nwaves][3*KP+4]
+  uint32_t* lw = reinterpret_cast<uint32_t*>(xch + (size_t)nwaves * (3 * KP + 4));   // [S][LWt] letters of the tile
 
   copy_tables<C::TAB>(Tf, a.tables + C::OFF_TF);
   if (C::DS) copy_tables<C::TAB>(Tr, a.tables + C::OFF_TR);
   // pad rows stay zero for the whole kernel
-  for (int i = threadIdx.x; i < a.S * a.Rrow * KP; i += nthr) {
+  for (int i = threadIdx.x; i < nrows * KP; i += nthr) {
     Pb0[i] = 0.f;
     if (C::DS) Pb1[i] = 0.f;
   }
+  const unsigned short dummy_row = (unsigned short)(a.S * a.Rrow + M - 1);   // rows dummy_row - j are all zero
 
-  // this wave's pass (class, k-tile) and its share of the visible positions
+  // this wave's pass and its share of the visible positions
   const int pass = blockIdx.y * a.PB + (wave % a.PB);
   const int part = wave / a.PB;
   const bool active = pass < a.npasses;
-  int t_kt = 0, t_kind = 0, t_strand = 0;
-  if (active) {
-    int t = pass;
-    t_kt = t % NKT; t /= NKT;
-    // classes: 0 = vh (forward strand), 1 = vh' (ds only), last = sw (forward, P(1-P))
-    t_kind = (a.want_sparsity && t == C::DS + 1) ? 1 : 0;
-    t_strand = (!t_kind && t == 1) ? 1 : 0;
-  }
-  float acc[M][KT];
+  // passes: 0 = vh (forward strand), 1 = vh' (ds only), last = sw (forward, P(1-P))
+  const int t_kind = (active && a.want_sparsity && pass == C::DS + 1) ? 1 : 0;
+  const int t_strand = (active && !t_kind && pass == 1) ? 1 : 0;
+  float acc[JCH][KP];
 #pragma unroll
-  for (int j = 0; j < M; ++j)
+  for (int c = 0; c < JCH; ++c)
 #pragma unroll
-    for (int q = 0; q < KT; ++q) acc[j][q] = 0.f;
+    for (int q = 0; q < KP; ++q) acc[c][q] = 0.f;
 
   const bool owner = blockIdx.y == 0;   // h / sb / letter counts are accumulated once
   float hs0[KP], hs1[KP], sb[KP];
@@ -617,45 +632,60 @@ __device__ void stats_body(const StatsArgs& a) {
   for (int q = 0; q < KP; ++q) { hs0[q] = 0.f; hs1[q] = 0.f; sb[q] = 0.f; }
   float vc0 = 0.f, vc1 = 0.f, vc2 = 0.f, vc3 = 0.f;
 
-  const int my_class = lane & 3, my_slot = lane >> 2;
+  const int grp = lane >> 4, lj = lane & 15;           // letter class of this lane group, its filter column
   const int ngroups = (a.n + a.S - 1) / a.S;
   const int ntiles = ngroups * a.nseg;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int grp = tile / a.nseg, seg = tile - grp * a.nseg;
-    const int n0 = grp * a.S;
+    const int cg = tile / a.nseg, seg = tile - cg * a.nseg;
+    const int n0 = cg * a.S;
     const int ns = min(a.S, a.n - n0);
     const int s0 = seg * a.LS;
     const int len = min(a.LS, a.Lh - s0);          // hidden positions of this segment
     const int lvis = len + M - 1;                  // visible positions that touch it
+    const int w0 = s0 >> 4;                        // first letter word of the segment's window
+    const int pofs = s0 - 16 * w0;                 // position of s0 inside the staged window
     __syncthreads();                               // previous tile fully consumed / tables + zero rows ready
+    // letters of the tile -> LDS (every later letter access is an LDS read)
+    for (int i = threadIdx.x; i < ns * a.LWt; i += nthr) {
+      const int nl = i / a.LWt, w = i - nl * a.LWt;
+      lw[i] = (w0 + w < a.LW) ? a.letters[(size_t)(n0 + nl) * a.LW + w0 + w] : 0u;
+    }
+    __syncthreads();
     // ---- phase A: park P rows (zero beyond the segment / beyond the last chain) ----
     for (uint32_t i = threadIdx.x; i < (uint32_t)(a.S * a.LS); i += nthr) {
       const uint32_t nl = fastdiv(i, a.divLS);
       const int sr = (int)(i - nl * (uint32_t)a.LS);
       float* p0 = Pb0 + ((size_t)nl * a.Rrow + (M - 1) + sr) * KP;
       float* p1 = Pb1 + ((size_t)nl * a.Rrow + (M - 1) + sr) * KP;
-      if ((int)nl < ns && sr < len) {
-        const uint64_t win = letter_window<M>(a.letters + (size_t)(n0 + nl) * a.LW, s0 + sr);
+      if ((int)nl < ns && sr < len && !(a.debug & 2)) {
+        const uint64_t win = letter_window<M>(lw + (size_t)nl * a.LWt, pofs + sr);
         float z[KP];
         conv_gather<C>(Tf, win, z);
 #pragma unroll
         for (int q = 0; q < KP; ++q) {
-          const float p = sigmoid_z(z[q]);
-          p0[q] = p;
-          if (owner) { hs0[q] += p; sb[q] += p * (1.f - p); }
+          z[q] = sigmoid_z(z[q]);
+          if (owner) { hs0[q] += z[q]; sb[q] += z[q] * (1.f - z[q]); }
         }
+#pragma unroll
+        for (int q = 0; q < KP / 4; ++q)
+          reinterpret_cast<float4*>(p0)[q] = make_float4(z[4 * q], z[4 * q + 1], z[4 * q + 2], z[4 * q + 3]);
         if (C::DS) {
           conv_gather<C>(Tr, win, z);
 #pragma unroll
           for (int q = 0; q < KP; ++q) {
-            const float p = sigmoid_z(z[q]);
-            p1[q] = p;
-            if (owner) hs1[q] += p;
+            z[q] = sigmoid_z(z[q]);
+            if (owner) hs1[q] += z[q];
           }
+#pragma unroll
+          for (int q = 0; q < KP / 4; ++q)
+            reinterpret_cast<float4*>(p1)[q] = make_float4(z[4 * q], z[4 * q + 1], z[4 * q + 2], z[4 * q + 3]);
         }
       } else {
 #pragma unroll
-        for (int q = 0; q < KP; ++q) { p0[q] = 0.f; if (C::DS) p1[q] = 0.f; }
+        for (int q = 0; q < KP / 4; ++q) {
+          reinterpret_cast<float4*>(p0)[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (C::DS) reinterpret_cast<float4*>(p1)[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
       }
     }
     // letter counts: every visible position exactly once (segment 0 of each chain)
@@ -664,31 +694,35 @@ __device__ void stats_body(const StatsArgs& a) {
       for (uint32_t i = threadIdx.x; i < vitems; i += nthr) {
         const uint32_t nl = fastdiv(i, a.divL);
         const int p = (int)(i - nl * (uint32_t)a.L);
-        const uint32_t l = (a.letters[(size_t)(n0 + nl) * a.LW + (p >> 4)] >> (2 * (p & 15))) & 3u;
+        // whole rows are staged when a chain is one segment; otherwise read the row from global memory
+        const uint32_t word = a.nseg == 1 ? lw[(size_t)nl * a.LWt + (p >> 4)] : a.letters[(size_t)(n0 + nl) * a.LW + (p >> 4)];
+        const uint32_t l = (word >> (2 * (p & 15))) & 3u;
         vc0 += l == 0u ? 1.f : 0.f; vc1 += l == 1u ? 1.f : 0.f;
         vc2 += l == 2u ? 1.f : 0.f; vc3 += l == 3u ? 1.f : 0.f;
       }
     }
     __syncthreads();
     // ---- phase B ----
-    if (active) {
-      const float* Pb = (t_strand ? Pb1 : Pb0) + t_kt * KT;
+    if (active && !(a.debug & 1)) {
+      const float* Pb = t_strand ? Pb1 : Pb0;
       const int V = ns * lvis;                                   // flattened visible positions of the tile
       const int per = (V + a.parts - 1) / a.parts;
       const int v_lo = part * per, v_hi = min(V, v_lo + per);
       for (int c0 = v_lo; c0 < v_hi; c0 += CH) {
         const int c1 = min(v_hi, c0 + CH);
-        // bucket positions c0..c1 by letter; rank = order of appearance
+        // bucket positions c0..c1 by letter; rank = order of appearance; the entry
+        // is the parked-row index of the hidden position that pairs with j = 0
         int cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0;
         for (int base = c0; base < c1; base += 64) {
           const int v = base + lane;
           const bool valid = v < c1;
-          uint32_t l = 0u;
+          uint32_t l = 0u, rowidx = 0u;
           if (valid) {
             const uint32_t nl = fastdiv((uint32_t)v, a.divLvis);
             const int pr = v - (int)nl * lvis;
-            const int p = s0 + pr;
-            l = (a.letters[(size_t)(n0 + nl) * a.LW + (p >> 4)] >> (2 * (p & 15))) & 3u;
+            const int p = pofs + pr;
+            l = (lw[(size_t)nl * a.LWt + (p >> 4)] >> (2 * (p & 15))) & 3u;
+            rowidx = nl * (uint32_t)a.Rrow + (uint32_t)(M - 1 + pr);
           }
           const unsigned long long b0 = __ballot(valid && l == 0u), b1 = __ballot(valid && l == 1u);
           const unsigned long long b2 = __ballot(valid && l == 2u), b3 = __ballot(valid && l == 3u);
@@ -696,79 +730,100 @@ __device__ void stats_body(const StatsArgs& a) {
           if (valid) {
             const unsigned long long mine = l == 0u ? b0 : l == 1u ? b1 : l == 2u ? b2 : b3;
             const int basecnt = l == 0u ? cnt0 : l == 1u ? cnt1 : l == 2u ? cnt2 : cnt3;
-            mylist[l * CH + basecnt + __popcll(mine & below)] = (unsigned short)(v - c0);
+            mylist[l * CH + basecnt + __popcll(mine & below)] = (unsigned short)rowidx;
           }
           cnt0 += __popcll(b0); cnt1 += __popcll(b1); cnt2 += __popcll(b2); cnt3 += __popcll(b3);
+        }
+        // pad every list to a common multiple of UNR with the all-zero row: the walk
+        // below then needs no per-entry guard and keeps UNR rows in flight per lane
+        const int maxcnt = max(max(cnt0, cnt1), max(cnt2, cnt3));
+        const int padded = (maxcnt + UNR - 1) / UNR * UNR;
+        {
+          const int mycnt = grp == 0 ? cnt0 : grp == 1 ? cnt1 : grp == 2 ? cnt2 : cnt3;
+          for (int e = mycnt + lj; e < padded; e += 16) mylist[grp * CH + e] = dummy_row;
         }
         // the lists are private to this wave: LDS operations of one wave complete in
         // order, so no workgroup barrier is needed between filling and reading them
         __builtin_amdgcn_wave_barrier();
-        const int mycnt = my_class == 0 ? cnt0 : my_class == 1 ? cnt1 : my_class == 2 ? cnt2 : cnt3;
-        const int maxcnt = max(max(cnt0, cnt1), max(cnt2, cnt3));
-        for (int e = my_slot; e < maxcnt; e += 16) {
-          if (e < mycnt) {
-            const int v = c0 + (int)mylist[my_class * CH + e];
-            const uint32_t nl = fastdiv((uint32_t)v, a.divLvis);
-            const int pr = v - (int)nl * lvis;
-            // parked row of hidden position (pr - j) sits at index (M-1) + pr - j
-            const float* rowp = Pb + ((size_t)nl * a.Rrow + (M - 1) + pr) * KP;
+        auto consume = [&](auto KIND) {
+          constexpr bool SPARSITY = decltype(KIND)::value != 0;
+          for (int e = 0; e < padded; e += UNR) {
+            int r[UNR];
 #pragma unroll
-            for (int j = 0; j < M; ++j) {
-              const float4* r4 = reinterpret_cast<const float4*>(rowp - (size_t)j * KP);
+            for (int u = 0; u < UNR; ++u) r[u] = (int)mylist[grp * CH + e + u];   // same entries for the 16 lanes of the group
 #pragma unroll
-              for (int q = 0; q < KT / 4; ++q) {
-                float4 t = r4[q];
-                if (t_kind) {
-                  t.x = t.x * (1.f - t.x); t.y = t.y * (1.f - t.y); t.z = t.z * (1.f - t.z); t.w = t.w * (1.f - t.w);
+            for (int c = 0; c < JCH; ++c) {
+              const int j = 16 * c + lj;
+              if (j < M) {
+                float4 t[UNR][KP / 4];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                  const float4* r4 = reinterpret_cast<const float4*>(Pb + (size_t)(r[u] - j) * KP);
+#pragma unroll
+                  for (int q = 0; q < KP / 4; ++q) t[u][q] = r4[q];
                 }
-                acc[j][4 * q] += t.x; acc[j][4 * q + 1] += t.y; acc[j][4 * q + 2] += t.z; acc[j][4 * q + 3] += t.w;
+#pragma unroll
+                for (int u = 0; u < UNR; ++u)
+#pragma unroll
+                  for (int q = 0; q < KP / 4; ++q) {
+                    float4 v = t[u][q];
+                    if (SPARSITY) {
+                      v.x = v.x * (1.f - v.x); v.y = v.y * (1.f - v.y); v.z = v.z * (1.f - v.z); v.w = v.w * (1.f - v.w);
+                    }
+                    acc[c][4 * q] += v.x; acc[c][4 * q + 1] += v.y; acc[c][4 * q + 2] += v.z; acc[c][4 * q + 3] += v.w;
+                  }
               }
             }
           }
-        }
+        };
+        if (t_kind) consume(IC<1>{}); else consume(IC<0>{});
         __builtin_amdgcn_wave_barrier();   // lists are rewritten by the next chunk
       }
     }
   }
 
+  // lane (grp, lj) holds the sums for letter a = grp and filter columns j = 16c + lj
   float* out = a.partials + ((size_t)blockIdx.x * a.parts + part) * a.row;
-  // lanes of equal letter (lane & 3) -> lanes 0..3, then one writer per slot
-  if (active) {
+  if (active && !(a.debug & 4)) {
     const int off = t_kind ? a.off_sw : (t_strand ? a.off_vh1 : a.off_vh0);
 #pragma unroll
-    for (int j = 0; j < M; ++j)
+    for (int c = 0; c < JCH; ++c) {
+      const int j = 16 * c + lj;
+      if (j < M) {
 #pragma unroll
-      for (int q = 0; q < KT; ++q) {
-        float v = acc[j][q];
-        v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
-        const int k = t_kt * KT + q;
-        if (lane < 4 && k < K) out[off + (k * 4 + lane) * M + j] = v;
+        for (int q = 0; q < K; ++q) out[off + (q * 4 + grp) * M + j] = acc[c][q];
       }
-  }
-  if (owner) {
-    // per-thread sums -> wave -> block (through LDS), fixed order; stored in part 0's row
-    float* out0 = a.partials + (size_t)blockIdx.x * a.parts * a.row;
-    auto block_sum_store = [&](float v, int dst) {
-      v = wave_sum(v);
-      __syncthreads();
-      if (lane == 0) red[wave] = v;
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        float t = 0.f;
-        for (int w = 0; w < nwaves; ++w) t += red[w];
-        out0[dst] = t;
-      }
-    };
-#pragma unroll
-    for (int q = 0; q < K; ++q) {
-      block_sum_store(hs0[q], a.off_h0 + q);
-      if (C::DS) block_sum_store(hs1[q], a.off_h1 + q);
-      if (a.want_sparsity) block_sum_store(sb[q], a.off_sb + q);
     }
-    block_sum_store(vc0, a.off_v + 0);
-    block_sum_store(vc1, a.off_v + 1);
-    block_sum_store(vc2, a.off_v + 2);
-    block_sum_store(vc3, a.off_v + 3);
+  }
+  if (owner && !(a.debug & 8)) {
+    // per-thread sums -> wave (shuffles) -> block (one LDS exchange), fixed order;
+    // stored in part 0's row by one thread per value
+    float* out0 = a.partials + (size_t)blockIdx.x * a.parts * a.row;
+    constexpr int NV = 3 * KP + 4;
+#pragma unroll
+    for (int q = 0; q < KP; ++q) {
+      const float s0v = wave_sum(hs0[q]), s1v = wave_sum(hs1[q]), s2v = wave_sum(sb[q]);
+      if (lane == 0) { xch[wave * NV + q] = s0v; xch[wave * NV + KP + q] = s1v; xch[wave * NV + 2 * KP + q] = s2v; }
+    }
+    {
+      const float c0v = wave_sum(vc0), c1v = wave_sum(vc1), c2v = wave_sum(vc2), c3v = wave_sum(vc3);
+      if (lane == 0) {
+        xch[wave * NV + 3 * KP] = c0v; xch[wave * NV + 3 * KP + 1] = c1v;
+        xch[wave * NV + 3 * KP + 2] = c2v; xch[wave * NV + 3 * KP + 3] = c3v;
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NV; i += nthr) {
+      float t = 0.f;
+      for (int w = 0; w < nwaves; ++w) t += xch[w * NV + i];
+      const int vg = i / KP, q = i - vg * KP;
+      if (i >= 3 * KP) out0[a.off_v + (i - 3 * KP)] = t;
+      else if (q < K) {
+        if (vg == 0) out0[a.off_h0 + q] = t;
+        else if (vg == 1) { if (C::DS) out0[a.off_h1 + q] = t; }
+        else if (a.want_sparsity) out0[a.off_sb + q] = t;
+      }
+    }
   }
 }
 
@@ -1012,8 +1067,9 @@ __global__ void __launch_bounds__(256) vgh_dense_kernel(VghArgs a) {
   }
 }
 
-// sums[dst(r)] = sum over partial rows of column r, fixed order (one wave per
-// column, lanes stride over rows, then a wave reduction).
+// sums[dst(r)] = sum over partial rows of column r in a fixed order.  Block =
+// 16 columns x 64 row groups: each thread adds the rows of its group (64-byte
+// segments per row), the 64 groups are combined through LDS.
 struct ReduceArgs {
   const float* partials;
   float* sums;
@@ -1022,19 +1078,24 @@ struct ReduceArgs {
   float n_value;                  // written after the last kept column
 };
 
-__global__ void __launch_bounds__(256) reduce_partials_kernel(ReduceArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (r < a.row) {
+__global__ void __launch_bounds__(1024) reduce_partials_kernel(ReduceArgs a) {
+  __shared__ float part[64][16];
+  const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int r = blockIdx.x * 16 + col;
+  float t = 0.f;
+  if (r < a.row)
+    for (int i = grp; i < a.nrows; i += 64) t += a.partials[(size_t)i * a.row + r];
+  part[grp][col] = t;
+  __syncthreads();
+  if (grp == 0 && r < a.row) {
     const bool skipped = r >= a.skip_begin && r < a.skip_begin + a.skip_len;
     if (!skipped) {
-      float t = 0.f;
-      for (int i = lane; i < a.nrows; i += 64) t += a.partials[(size_t)i * a.row + r];
-      t = wave_sum(t);
-      if (lane == 0) a.sums[r < a.skip_begin ? r : r - a.skip_len] = t;
+      float s = 0.f;
+      for (int g = 0; g < 64; ++g) s += part[g][col];
+      a.sums[r < a.skip_begin ? r : r - a.skip_len] = s;
     }
   }
-  if (r == 0 && lane == 0) a.sums[a.row - a.skip_len] = a.n_value;
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.sums[a.row - a.skip_len] = a.n_value;
 }
 
 // ---------------------------------------------------------------------------

@@ -63,12 +63,9 @@ struct Cfg {
   static constexpr int OFF_WT = OFF_TV + TV * (1 + DS);
   static constexpr int OFF_C = OFF_WT + WT;
   static constexpr int TABLES = OFF_C + 4;                // multiple of 4 floats
+  static constexpr int STATS_CH = 256;                    // positions a statistics wave buckets at a time
   static constexpr int OFF_TR = DS ? TAB : TABLES;
   static constexpr int TABLES_ALL = DS ? TABLES : TABLES + TAB;
-  // statistics kernel: one wave owns acc[M][KT]; KT motifs per pass (multiple of 4, M*KT <= 208)
-  static constexpr int KT_FIT = ((208 / M) / 4) * 4;
-  static constexpr int KT = KT_FIT < 4 ? 4 : (KT_FIT > KP ? KP : KT_FIT);
-  static constexpr int NKT = cdiv(KP, KT);
 };
 
 // Host-side mirror of Cfg (runtime values, same arithmetic).
@@ -76,7 +73,6 @@ struct ModelShape {
   int K, M, DS, G;
   int NQ, KP, NW, NG, ROWS, TAB, NCH, DENSE, TV, WT, NGRP;
   int OFF_TF, OFF_TR, OFF_TV, OFF_TVR, OFF_WT, OFF_C, TABLES, TABLES_ALL;
-  int KT, NKT;
 };
 inline ModelShape model_shape(int K, int M, int DS, int G) {
   ModelShape s;
@@ -91,9 +87,6 @@ inline ModelShape model_shape(int K, int M, int DS, int G) {
   s.OFF_TF = 0; s.OFF_TV = s.TAB * (1 + DS); s.OFF_TVR = s.OFF_TV + s.TV;
   s.OFF_WT = s.OFF_TV + s.TV * (1 + DS); s.OFF_C = s.OFF_WT + s.WT; s.TABLES = s.OFF_C + 4;
   s.OFF_TR = DS ? s.TAB : s.TABLES; s.TABLES_ALL = DS ? s.TABLES : s.TABLES + s.TAB;
-  const int kt_fit = ((208 / M) / 4) * 4;
-  s.KT = kt_fit < 4 ? 4 : (kt_fit > s.KP ? s.KP : kt_fit);
-  s.NKT = cdiv(s.KP, s.KT);
   return s;
 }
 
@@ -127,11 +120,11 @@ inline GibbsLayout gibbs_layout(const ModelShape& ms, int Lf, int S) {
 }
 
 // ---- statistics kernel ----------------------------------------------------------
-// A pass = (class, k-tile); classes: vh, vh' (ds), sw (sparsity).  One wave owns
-// one pass for one share ("part") of the visible positions of every tile.
+// A pass = one accumulator class: vh, vh' (ds), sw (sparsity).  One wave owns one
+// pass for one share ("part") of the visible positions of every tile.
 struct StatsLayout {
   int npasses, PB, parts, threads, grid_y;
-  int S, LS, nseg, Rrow;  // chains per tile, hidden positions per segment, segments per chain, parked rows
+  int S, LS, nseg, Rrow, LWt;  // chains per tile, hidden positions per segment, segments per chain, parked rows, staged letter words
   int row;                // floats per partial row: 3*KAM + 3K + 4
   int off_vh[2], off_h[2], off_sw, off_sb, off_v;
   int lds_bytes;
@@ -139,34 +132,36 @@ struct StatsLayout {
 inline StatsLayout stats_layout(const ModelShape& ms, int want_sparsity, int Lh, int n, int lds_budget) {
   StatsLayout s;
   const int K = ms.K, M = ms.M, KAM = K * 4 * M;
-  s.npasses = (1 + ms.DS + want_sparsity) * ms.NKT;
-  // waves per block: 4 (256 threads) or 8 (512 threads, more than 4 passes)
-  const int waves = s.npasses > 4 ? 8 : 4;
+  s.npasses = 1 + ms.DS + want_sparsity;
+  const int waves = 4;
   s.threads = 64 * waves;
-  s.PB = s.npasses >= waves ? waves : (s.npasses <= 1 ? 1 : (s.npasses == 2 ? 2 : 4));
+  s.PB = s.npasses <= 1 ? 1 : (s.npasses == 2 ? 2 : 4);
   s.parts = waves / s.PB;
-  s.grid_y = (s.npasses + s.PB - 1) / s.PB;
-  const int CH = 512;
-  const long fixed = (long)(1 + ms.DS) * (ms.TAB + ms.KT) * 4 + (long)waves * 4 * CH * 2 + 64;
+  s.grid_y = 1;
+  const int CH = 256;   // Cfg::STATS_CH
+  long fixed = (long)(1 + ms.DS) * (ms.TAB + M * ms.KP) * 4 + (long)waves * 4 * CH * 2 + (long)waves * (3 * ms.KP + 4) * 4;
+  fixed += 16L * 4 * ((Lh + M - 1 + 15 + 15) / 16 + 3);      // staged letters for up to 16 chains (upper bound)
   const long per_row = (long)(1 + ms.DS) * ms.KP * 4;
+  if (lds_budget < fixed + 24 * 1024) lds_budget = (int)(fixed + 24 * 1024);   // big tables: trade occupancy for segment length
+  if (lds_budget > 156 * 1024) lds_budget = 156 * 1024;
   long rows = (lds_budget - fixed) / per_row;                 // parked rows that fit
   if (rows < 2 * (M - 1) + 8) rows = 2 * (M - 1) + 8;
+  if (rows > 65000) rows = 65000;                             // 16-bit parked-row indices in the lists
   if (rows >= Lh + 2 * (M - 1)) {                             // whole chains
     s.LS = Lh; s.nseg = 1;
     s.Rrow = Lh + 2 * (M - 1);
     s.S = (int)(rows / s.Rrow);
     if (s.S > 16) s.S = 16;
     if (s.S > n) s.S = n > 0 ? n : 1;
-    if ((long)s.S * (Lh + M - 1) > 60000) s.S = 60000 / (Lh + M - 1);   // 16-bit list entries
     if (s.S < 1) s.S = 1;
   } else {                                                    // one segment of one chain
     s.S = 1;
     s.LS = (int)rows - 2 * (M - 1);
-    if (s.LS + M - 1 > 60000) s.LS = 60000 - (M - 1);
     s.nseg = (Lh + s.LS - 1) / s.LS;
     s.LS = (Lh + s.nseg - 1) / s.nseg;                        // balance the segments
     s.Rrow = s.LS + 2 * (M - 1);
   }
+  s.LWt = (s.LS + M - 1 + 15 + 15) / 16 + 3;
   s.off_vh[0] = 0;
   s.off_vh[1] = KAM;
   s.off_h[0] = 2 * KAM;

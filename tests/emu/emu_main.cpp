@@ -155,19 +155,25 @@ int emu_gibbs(int id, const float* tables, uint32_t* hm, uint32_t* hmp, uint32_t
 
 // statistics of one half + deterministic reduction into `sums` (row floats + n)
 int emu_stats(int id, const float* tables, const uint32_t* letters, int n, int L, int LW, int want_sparsity,
-              int lds_budget, int gx, float* partials, int partials_cap, float* sums, int skip_begin, int skip_len) {
+              int force_ls, int gx, float* partials, int partials_cap, float* sums, int skip_begin, int skip_len) {
   StatsArgs a;
   a.tables = tables; a.letters = letters; a.n = n; a.L = L; a.LW = LW;
   a.divL = make_fastdiv((uint32_t)L);
   a.want_sparsity = want_sparsity;
   a.partials = partials;
+  a.debug = 0;
   int row = -1;
   CFG_DISPATCH(id, {
     const ModelShape ms = shape_of<C>();
     const int Lh = L - C::M + 1;
-    const StatsLayout st = stats_layout(ms, want_sparsity, Lh, n, lds_budget);
+    StatsLayout st = stats_layout(ms, want_sparsity, Lh, n, 48 * 1024);
+    if (force_ls > 0) {   // cut every chain into segments of force_ls hidden positions
+      st.S = 1; st.LS = force_ls; st.nseg = (Lh + force_ls - 1) / force_ls;
+      st.Rrow = st.LS + 2 * (C::M - 1);
+      st.LWt = (st.LS + C::M - 1 + 30) / 16 + 3;
+    }
     a.Lh = Lh;
-    a.S = st.S; a.LS = st.LS; a.nseg = st.nseg; a.Rrow = st.Rrow;
+    a.S = st.S; a.LS = st.LS; a.nseg = st.nseg; a.Rrow = st.Rrow; a.LWt = st.LWt;
     a.PB = st.PB; a.parts = st.parts; a.npasses = st.npasses;
     a.divLS = make_fastdiv((uint32_t)st.LS); a.divLvis = make_fastdiv((uint32_t)(st.LS + C::M - 1));
     a.row = st.row;
@@ -196,7 +202,7 @@ int emu_stats(int id, const float* tables, const uint32_t* letters, int n, int L
 
 int emu_reduce(const float* partials, float* sums, int nrows, int row, int skip_begin, int skip_len, float n_value) {
   ReduceArgs r{partials, sums, nrows, row, skip_begin, skip_len, n_value};
-  emu::launch([&] { reduce_partials_kernel(r); }, dim3((row + 1) / 2), dim3(128), 0);
+  emu::launch([&] { reduce_partials_kernel(r); }, dim3((row + 15) / 16), dim3(1024), 0);
   return 0;
 }
 

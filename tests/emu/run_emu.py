@@ -269,17 +269,16 @@ def test_train_step():
         letters, _ = encode(D)
         threads = 128
         row = 3 * K * 4 * M + 3 * K + 4
-        partials = np.zeros(16 * row, dtype=np.float32)
+        partials = np.zeros(32 * row, dtype=np.float32)
         tables = build_tables(cid, o)
-        # a small LDS budget forces the data half through the segmented path
-        # (chains cut into several hidden segments), the model half uses whole chains
-        small = 4 * (info["TABLES"] + 4 * 512 * 4) + 4 * (2 if ds else 1) * (4 * ((K + 3) // 4)) * (2 * (M - 1) + 9)
-        r = lib.emu_stats(cid, fp(tables), up(letters), n, L, lib.emu_letter_words(L), 1, small, 3,
+        # the data half goes through the segmented path (chains cut into segments of
+        # 8 hidden positions), the model half uses whole chains
+        r = lib.emu_stats(cid, fp(tables), up(letters), n, L, lib.emu_letter_words(L), 1, 8, 3,
                           fp(partials), partials.size, fp(sums[data_off:]), -1, 0)
         assert r == row, r
         _, _, v, vout, lws = run_gibbs(cid, o, tables, 2, o.cd_k, 2, threads)
         Lv = Lf + M - 1
-        r = lib.emu_stats(cid, fp(tables), up(vout), B, Lv, lws, 0, 72 * 1024, 2,
+        r = lib.emu_stats(cid, fp(tables), up(vout), B, Lv, lws, 0, 0, 2,
                           fp(partials), partials.size, fp(sums[model_off:]), skipb, skipl)
         assert r == row, r
         assert sums[n_d] == n and sums[n_m] == B

@@ -16,6 +16,7 @@
 #define __host__
 #define __forceinline__ inline
 #define __launch_bounds__(...)
+#define __shared__ static   /* blocks run one at a time in the emulator */
 
 struct dim3 {
   unsigned x, y, z;
@@ -71,6 +72,21 @@ static inline float __shfl_xor(float v, int mask, int width = 64) {
   return r;
 }
 
+// DPP row rotation (ctrl 0x120 + n = row_ror:n): lane l of a 16-lane row reads lane (l - n) mod 16
+static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+  const unsigned lane = emu::t_threadIdx.x & 63u, wave = emu::t_threadIdx.x >> 6;
+  float* s = emu::t_ctx->wave_scratch + wave * 64;
+  memcpy(&s[lane], &src, 4);
+  pthread_barrier_wait(&emu::t_ctx->wave_bar[wave]);
+  const unsigned n = (unsigned)ctrl - 0x120u;
+  const unsigned from = (lane & ~15u) | ((lane - n) & 15u);
+  int r;
+  memcpy(&r, &s[from], 4);
+  pthread_barrier_wait(&emu::t_ctx->wave_bar[wave]);
+  (void)old; (void)row_mask; (void)bank_mask; (void)bound_ctrl;
+  return r;
+}
+
 // all 64 lanes of the wave must call it (true for the uses in crbm_kernels.h)
 static inline unsigned long long __ballot(int pred) {
   const unsigned lane = emu::t_threadIdx.x & 63u, wave = emu::t_threadIdx.x >> 6;
@@ -100,6 +116,7 @@ static inline int __ffs(uint32_t v) { return __builtin_ffs((int)v); }
 static inline uint32_t __umulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
 #define __expf(x) expf(x)
 static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
+static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 static inline float __fdividef(float a, float b) { return a / b; }
 using std::max;
 using std::min;
