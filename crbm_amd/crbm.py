@@ -229,6 +229,42 @@ class CRBM(object):
         obj.c.set_value(c)
         return obj
 
+    def saveState(self, filename):
+        """Full training state: the reference tuple of
+        saveModel plus velocities, persistent chains and the sampler counters,
+        so that training resumes exactly.  A joblib file whose first two
+        entries are the reference's (numpyParams, hyperparams)."""
+        numpyParams = (self.motifs.get_value(), self.bias.get_value(), self.c.get_value())
+        hyperparams = (self.num_motifs, self.motif_length, self.input_dims, self.doublestranded,
+                       self.batchsize, self.learning_rate, self.momentum, self.rho, self.lambda_rate,
+                       self.pooling, self.cd_k, self.epochs, self.spmethod)
+        h = self._h()
+        seed, gstep, estep = ctypes.c_uint64(), ctypes.c_uint32(), ctypes.c_uint32()
+        self._check(self._lib.crbm_get_rng(h, ctypes.byref(seed), ctypes.byref(gstep), ctypes.byref(estep)))
+        extra = {"velocities": self.get_velocities(), "fantasy": self.get_fantasy(),
+                 "fantasy_hidden_len": self.fantasy_hidden_len,
+                 "rng": (int(seed.value), int(gstep.value), int(estep.value))}
+        joblib.dump((numpyParams, hyperparams, extra), filename, protocol=2)
+
+    @classmethod
+    def loadState(cls, filename):
+        numpyParams, hyperparams, extra = joblib.load(filename)
+        (num_motifs, motif_length, input_dims, doublestranded, batchsize, learning_rate,
+         momentum, rho, lambda_rate, pooling, cd_k, epochs, spmethod) = hyperparams
+        seed, gstep, estep = extra["rng"]
+        obj = cls(num_motifs, motif_length, epochs=epochs, input_dims=input_dims,
+                  doublestranded=doublestranded, batchsize=batchsize, learning_rate=learning_rate,
+                  momentum=momentum, pooling=pooling, cd_k=cd_k, rho=rho, lambda_rate=lambda_rate,
+                  fantasy_hidden_len=extra["fantasy_hidden_len"], seed=seed)
+        motifs, bias, c = numpyParams
+        obj.motifs.set_value(motifs)
+        obj.bias.set_value(bias)
+        obj.c.set_value(c)
+        obj.set_velocities(*extra["velocities"])
+        obj.set_fantasy(*extra["fantasy"])
+        obj.set_rng(seed, gstep, estep)
+        return obj
+
     # ------------------------------------------- graph builders as plain calls
     def _hgv(self, data, flip, want, rng_step=0):
         data = self._data(data)

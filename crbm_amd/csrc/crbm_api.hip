@@ -427,7 +427,7 @@ int crbm_precompile(const crbm_config* cfg) {
   if (rc) return rc;
   const int ds = cfg->doublestranded ? 1 : 0;
   int G = env_int("CRBM_GROUP", 0);
-  if (G < 1 || G > 4) G = choose_group(cfg->num_motifs, cfg->motif_length, ds, env_int("CRBM_TABLE_BUDGET", 48 * 1024));
+  if (G < 1 || G > 4) G = choose_group(cfg->num_motifs, cfg->motif_length, ds, env_int("CRBM_TABLE_BUDGET", 24 * 1024));
   const ModelShape ms = model_shape(cfg->num_motifs, cfg->motif_length, ds, G);
   std::vector<char> code;
   bool cached = false;
@@ -460,7 +460,7 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
   hh->sl = sums_layout(hh->K, hh->M);
   // gather-table group size, derived shapes
   hh->G = env_int("CRBM_GROUP", 0);
-  if (hh->G < 1 || hh->G > 4) hh->G = choose_group(hh->K, hh->M, hh->ds, env_int("CRBM_TABLE_BUDGET", 48 * 1024));
+  if (hh->G < 1 || hh->G > 4) hh->G = choose_group(hh->K, hh->M, hh->ds, env_int("CRBM_TABLE_BUDGET", 24 * 1024));
   hh->ms = model_shape(hh->K, hh->M, hh->ds, hh->G);
   hh->NW = hh->ms.NW;
   auto bail = [&](int code) { crbm_destroy(hh); return code; };

@@ -90,12 +90,15 @@ inline ModelShape model_shape(int K, int M, int DS, int G) {
   return s;
 }
 
-// Largest G whose gather table(s) fit the LDS budget.
+// Letters per gather-table group: the largest G whose table(s) stay small
+// enough (budget) to leave the CU several resident blocks; failing that G = 2
+// if it fits twice the budget, else G = 1.
 inline int choose_group(int K, int M, int ds, int budget_bytes) {
   const int KP = 4 * cdiv(K, 4);
+  auto bytes = [&](int G) { return (1 + ds) * cdiv(M, G) * cpow4(G) * KP * 4; };
   for (int G = 4; G >= 2; --G)
-    if ((1 + ds) * cdiv(M, G) * cpow4(G) * KP * 4 <= budget_bytes) return G;
-  return 1;
+    if (bytes(G) <= budget_bytes) return G;
+  return bytes(2) <= 2 * budget_bytes ? 2 : 1;
 }
 
 // ---- Gibbs kernel -------------------------------------------------------------

@@ -390,3 +390,52 @@ def test_large_config_train_and_chain(K, M, ds, L, chains):
     o = OracleCRBM(K, M, doublestranded=ds, batchsize=4, cd_k=2, fantasy_hidden_len=Lf, seed=3, W=W)
     o.gibbs_steps(2)                       # the chain of step 1 does not depend on the data
     assert (h1[:4] != o.fantasy_h).mean() < 1e-4
+
+
+def test_full_size_statistics_are_additive():
+    """Config #2 at 8192 data rows: the packed raw sums of a batch equal the sum
+    of the raw sums of its two halves (what the RCCL all-reduce relies on), and
+    the letter counts / normalisers are exact."""
+    from crbm_amd._lib import fptr
+    n, L = 8192, 200
+    D = synthetic_onehot(n, L, seed=77)
+
+    def local(rows, offset, chains):
+        m = _cfg2_model(chains, offset)
+        cnt = m._lib.crbm_sums_count(m._handle)
+        buf = np.zeros(cnt, dtype=np.float32)
+        m._call("crbm_train_local", fptr(np.ascontiguousarray(rows)), rows.shape[0], L, fptr(buf))
+        return buf
+
+    whole = local(D, 0, 512)
+    lo = local(D[:n // 2], 0, 256)
+    hi = local(D[n // 2:], 256, 256)
+    both = lo.astype(np.float64) + hi
+    np.testing.assert_allclose(whole, both, rtol=2e-5, atol=1e-3)
+    K, M = 10, 15
+    KAM = K * 4 * M
+    v_d = whole[3 * KAM + 3 * K:3 * KAM + 3 * K + 4]
+    np.testing.assert_array_equal(v_d, D.sum(axis=(0, 1, 3)))           # exact letter counts
+    assert whole[3 * KAM + 3 * K + 4] == n                               # n_d
+    # sum_a VH[k,a,j] == sum_s P[k,s] for every j (one-hot columns), interior columns only differ by edges
+    vh = whole[:KAM].reshape(K, 4, M)
+    h = whole[2 * KAM:2 * KAM + K]
+    np.testing.assert_allclose(vh.sum(axis=1), np.repeat(h[:, None], M, axis=1), rtol=1e-4)
+
+
+def test_full_state_checkpoint_roundtrip(tmp_path):
+    """velocities, chains and the sampler counter survive a
+    save/load, so training resumes bit-identically (the reference's
+    saveModel/loadModel resets them, convRBM.py:226-235)."""
+    from crbm_amd import CRBM
+    D = synthetic_onehot(64, 80, seed=3)
+    a, _ = make_pair(6, 9, ds=True, batchsize=32, Lf=40, cd_k=2, bshift=4.0)
+    a._trainingFct(D)
+    fn = str(tmp_path / "state.pkl")
+    a.saveState(fn)
+    b = CRBM.loadState(fn)
+    a._trainingFct(D)
+    b._trainingFct(D)
+    np.testing.assert_array_equal(a.motifs.get_value(), b.motifs.get_value())
+    np.testing.assert_array_equal(a.get_fantasy()[0], b.get_fantasy()[0])
+    np.testing.assert_array_equal(a.get_velocities()[0], b.get_velocities()[0])
