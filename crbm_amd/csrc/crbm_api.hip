@@ -812,35 +812,46 @@ int crbm_v_given_h(crbm_handle* h, const float* hid, const float* hid_prime, int
 }
 
 // ---- evaluation --------------------------------------------------------------
+// sequences per slab so that the staged fp32 input plus the dense outputs of
+// one slab stay around 256 MB (inference over data sets far larger than HBM
+// scratch: SURVEY 8(f)-1)
+static int slab_rows(int n, size_t bytes_per_row) {
+  const size_t budget = (size_t)env_int("CRBM_SLAB_BYTES", 256 << 20);
+  size_t rows = budget / std::max<size_t>(bytes_per_row, 1);
+  if (rows < 1) rows = 1;
+  return (int)std::min<size_t>(rows, (size_t)n);
+}
+
 int crbm_hit_probs(crbm_handle* h, const float* v, int32_t n, int32_t L, float* out) {
   ENTER();
   ARGCHK(v && out, "null argument");
   int rc = check_data_shape(h, n, L);
   if (rc) return rc;
-  const size_t count = (size_t)n * h->K * (L - h->M + 1);
-  HIPCHK(h->letters.ensure((size_t)n * letter_words(L)));
-  rc = encode_host(h, v, n, L, h->letters.p);
-  if (rc) return rc;
-  HIPCHK(h->out_b.ensure(count));
-  // convRBM.py:507-514: doublestranded -> sigma(x); single-stranded -> sigma(x + x')
-  rc = launch_hgv(h, h->letters.p, n, L, h->ds ? 0 : 2, nullptr, h->out_b.p, nullptr, nullptr, KIND_API_H, 0, 0);
-  if (rc) return rc;
-  rc = copy_out(h, out, h->out_b.p, count);
-  if (rc) return rc;
-  HIPCHK(hipStreamSynchronize(h->stream));
+  const int Lh = L - h->M + 1;
+  const size_t per_seq_out = (size_t)h->K * Lh;
+  const int slab = slab_rows(n, ((size_t)4 * L + per_seq_out) * sizeof(float));
+  HIPCHK(h->letters.ensure((size_t)slab * letter_words(L)));
+  HIPCHK(h->out_b.ensure((size_t)slab * per_seq_out));
+  for (int start = 0; start < n; start += slab) {
+    const int cnt = std::min(slab, n - start);
+    rc = encode_host(h, v + (size_t)start * 4 * L, cnt, L, h->letters.p);
+    if (rc) return rc;
+    // convRBM.py:507-514: doublestranded -> sigma(x); single-stranded -> sigma(x + x')
+    rc = launch_hgv(h, h->letters.p, cnt, L, h->ds ? 0 : 2, nullptr, h->out_b.p, nullptr, nullptr, KIND_API_H, 0, 0);
+    if (rc) return rc;
+    rc = copy_out(h, out + (size_t)start * per_seq_out, h->out_b.p, (size_t)cnt * per_seq_out);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
   return CRBM_OK;
 }
 
-static int free_energy_common(crbm_handle* h, const float* v, int n, int L, float* fe, float* fem) {
-  int rc = check_data_shape(h, n, L);
-  if (rc) return rc;
-  HIPCHK(h->letters.ensure((size_t)n * letter_words(L)));
-  rc = encode_host(h, v, n, L, h->letters.p);
+// one slab: letters must already be in h->letters
+static int free_energy_slab(crbm_handle* h, int n, int L, float* fe, float* fem) {
+  int rc = ensure_tables(h);
   if (rc) return rc;
   HIPCHK(h->out_a.ensure((size_t)n));
   HIPCHK(h->out_b.ensure((size_t)n * h->K));
-  rc = ensure_tables(h);
-  if (rc) return rc;
   FeArgs a;
   a.tables = h->d_tables;
   a.letters = h->letters.p;
@@ -851,6 +862,21 @@ static int free_energy_common(crbm_handle* h, const float* v, int n, int L, floa
   if (fe && (rc = copy_out(h, fe, h->out_a.p, (size_t)n))) return rc;
   if (fem && (rc = copy_out(h, fem, h->out_b.p, (size_t)n * h->K))) return rc;
   HIPCHK(hipStreamSynchronize(h->stream));
+  return CRBM_OK;
+}
+
+static int free_energy_common(crbm_handle* h, const float* v, int n, int L, float* fe, float* fem) {
+  int rc = check_data_shape(h, n, L);
+  if (rc) return rc;
+  const int slab = slab_rows(n, ((size_t)4 * L + h->K + 1) * sizeof(float));
+  HIPCHK(h->letters.ensure((size_t)slab * letter_words(L)));
+  for (int start = 0; start < n; start += slab) {
+    const int cnt = std::min(slab, n - start);
+    rc = encode_host(h, v + (size_t)start * 4 * L, cnt, L, h->letters.p);
+    if (rc) return rc;
+    rc = free_energy_slab(h, cnt, L, fe ? fe + start : nullptr, fem ? fem + (size_t)start * h->K : nullptr);
+    if (rc) return rc;
+  }
   return CRBM_OK;
 }
 
@@ -869,16 +895,27 @@ int crbm_free_energy_per_motif(crbm_handle* h, const float* v, int32_t n, int32_
 int crbm_eval_data(crbm_handle* h, const float* v, int32_t n, int32_t L, float* mfe, float* nmh) {
   ENTER();
   ARGCHK(v && mfe && nmh, "null argument");
-  std::vector<float> fe((size_t)std::max(n, 1));
-  int rc = free_energy_common(h, v, n, L, fe.data(), nullptr);
+  int rc = check_data_shape(h, n, L);
   if (rc) return rc;
+  const int slab = slab_rows(n, ((size_t)4 * L + h->K + 1) * sizeof(float));
+  HIPCHK(h->letters.ensure((size_t)slab * letter_words(L)));
+  std::vector<float> fe((size_t)slab);
   double tot = 0.0;
-  for (int i = 0; i < n; ++i) tot += fe[i];
-  *mfe = (float)(tot / n);                       // convRBM.py:636-638
-  // mean of a fresh forward-strand sample (convRBM.py:469-472); letters are still resident
   HIPCHK(hipMemsetAsync(h->d_ones, 0, sizeof(unsigned long long), h->stream));
-  rc = launch_hgv(h, h->letters.p, n, L, 0, nullptr, nullptr, nullptr, h->d_ones, KIND_EVAL_H, h->eval_step, 0);
-  if (rc) return rc;
+  for (int start = 0; start < n; start += slab) {
+    const int cnt = std::min(slab, n - start);
+    rc = encode_host(h, v + (size_t)start * 4 * L, cnt, L, h->letters.p);
+    if (rc) return rc;
+    rc = free_energy_slab(h, cnt, L, fe.data(), nullptr);
+    if (rc) return rc;
+    for (int i = 0; i < cnt; ++i) tot += fe[i];
+    // mean of a fresh forward-strand sample (convRBM.py:469-472); rows keep their global index
+    rc = launch_hgv(h, h->letters.p, cnt, L, 0, nullptr, nullptr, nullptr, h->d_ones, KIND_EVAL_H, h->eval_step,
+                    (uint32_t)start);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  *mfe = (float)(tot / n);                       // convRBM.py:636-638
   h->eval_step += 1;
   unsigned long long ones = 0;
   HIPCHK(hipMemcpyAsync(&ones, h->d_ones, sizeof(ones), hipMemcpyDeviceToHost, h->stream));

@@ -439,3 +439,21 @@ def test_full_state_checkpoint_roundtrip(tmp_path):
     np.testing.assert_array_equal(a.motifs.get_value(), b.motifs.get_value())
     np.testing.assert_array_equal(a.get_fantasy()[0], b.get_fantasy()[0])
     np.testing.assert_array_equal(a.get_velocities()[0], b.get_velocities()[0])
+
+
+def test_inference_streams_in_slabs(monkeypatch):
+    """hit probabilities / free energy / evaluateData over inputs
+    larger than the staging budget are processed slab by slab with identical
+    results (rows keep their global sampler index)."""
+    data = synthetic_onehot(300, 120, seed=21)
+    a, _ = make_pair(10, 15, ds=True, bshift=4.0)
+    ref_hit, ref_fe, ref_fem = a.motifHitProbs(data), a.freeEnergy(data), a.freeEnergy(data, True)
+    ref_eval = a._evaluateData(data)
+    monkeypatch.setenv("CRBM_SLAB_BYTES", str(64 * 1024))        # ~ 12 sequences per slab
+    b, _ = make_pair(10, 15, ds=True, bshift=4.0)
+    np.testing.assert_array_equal(b.motifHitProbs(data), ref_hit)
+    np.testing.assert_array_equal(b.freeEnergy(data), ref_fe)
+    np.testing.assert_array_equal(b.freeEnergy(data, True), ref_fem)
+    got = b._evaluateData(data)
+    np.testing.assert_allclose(got[0], ref_eval[0], rtol=1e-6)
+    assert got[1] == ref_eval[1]
