@@ -6,5 +6,6 @@ behind the C-ABI in include/crbm_amd.h.
 """
 from .crbm import CRBM  # noqa: F401
 from . import dist  # noqa: F401
+from .sequences import seqsToCodes, codesToOneHot, seqToOneHot  # noqa: F401
 
 __version__ = "0.1.0"

@@ -72,6 +72,7 @@ SIGNATURES = {
     "crbm_set_shard": (_I32, [_H, _U32]),
     "crbm_train_step": (_I32, [_H, _F, _I32, _I32]),
     "crbm_dataset_upload": (_I32, [_H, _F, _I32, _I32]),
+    "crbm_dataset_upload_codes": (_I32, [_H, _U8P, _I32, _I32]),
     "crbm_train_step_resident": (_I32, [_H, _I32, _I32]),
     "crbm_gibbs_steps": (_I32, [_H, _I32]),
     "crbm_gibbs_steps_async": (_I32, [_H, _I32]),

@@ -688,6 +688,28 @@ int crbm_dataset_upload(crbm_handle* h, const float* data, int32_t n, int32_t L)
   return CRBM_OK;
 }
 
+int crbm_dataset_upload_codes(crbm_handle* h, const uint8_t* codes, int32_t n, int32_t L) {
+  ENTER();
+  ARGCHK(codes, "null argument");
+  int rc = check_data_shape(h, n, L);
+  if (rc) return rc;
+  const int LW = letter_words(L);
+  HIPCHK(h->dataset.ensure((size_t)n * LW));
+  const size_t bytes = (size_t)n * L;
+  HIPCHK(h->stage.ensure((bytes + 3) / 4));
+  HIPCHK(hipMemcpyAsync(h->stage.p, codes, bytes, hipMemcpyHostToDevice, h->stream));
+  EncodeCodesArgs a;
+  a.codes = reinterpret_cast<const unsigned char*>(h->stage.p);
+  a.letters = h->dataset.p; a.flags = h->d_flags;
+  a.n = n; a.L = L; a.LW = LW;
+  hipLaunchKernelGGL(encode_codes_kernel, dim3(grid_for((long)n * LW, 256, h->num_cu * 8)), dim3(256), 0, h->stream, a);
+  HIPCHK(hipGetLastError());
+  rc = check_flags(h);
+  if (rc) return rc;
+  h->dataset_n = n; h->dataset_L = L;
+  return CRBM_OK;
+}
+
 int crbm_train_step_resident(crbm_handle* h, int32_t start, int32_t end) {
   ENTER();
   ARGCHK(h->dataset_n > 0, "no resident data set (call crbm_dataset_upload)");

@@ -926,6 +926,36 @@ __global__ void encode_onehot_kernel(EncodeArgs a) {
   }
 }
 
+// letter codes (one byte per base: 0..3 = A,C,G,T as in sequences.py:9-17) -> packed
+// letters [n][LW]; flags[0] |= 1 on any other code.
+struct EncodeCodesArgs {
+  const unsigned char* codes;   // [n][L]
+  uint32_t* letters;
+  uint32_t* flags;
+  int32_t n, L, LW;
+};
+
+__global__ void encode_codes_kernel(EncodeCodesArgs a) {
+  const long total = (long)a.n * a.LW;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int nn = (int)(i / a.LW);
+    const int w = (int)(i - (long)nn * a.LW);
+    uint32_t word = 0;
+    bool bad = false;
+    const unsigned char* base = a.codes + (size_t)nn * a.L;
+    for (int t = 0; t < 16; ++t) {
+      const int p = w * 16 + t;
+      if (p < a.L) {
+        const uint32_t c = base[p];
+        bad |= c > 3u;
+        word |= (c & 3u) << (2 * t);
+      }
+    }
+    a.letters[i] = word;
+    if (bad) atomicOr(a.flags, 1u);
+  }
+}
+
 // packed letters -> one-hot fp32 (n,1,4,L)
 struct DecodeArgs {
   const uint32_t* letters;

@@ -110,6 +110,10 @@ int crbm_train_step(crbm_handle* h, const float* D, int32_t n, int32_t L);
  * crbm_dataset_upload (fit() uploads once, convRBM.py:612-615 then only
  * passes slice bounds). */
 int crbm_dataset_upload(crbm_handle* h, const float* data, int32_t n, int32_t L);
+/* Same from letter codes, one byte per base (0..3 = A,C,G,T: the map of
+ * sequences.py:9-17), shape (n,L): 16x less host->device traffic than the
+ * float one-hot array that sequences.py:101-117 builds. */
+int crbm_dataset_upload_codes(crbm_handle* h, const uint8_t* codes, int32_t n, int32_t L);
 int crbm_train_step_resident(crbm_handle* h, int32_t start, int32_t end);
 /* The persistent chain alone (convRBM.py:397-408): k Gibbs steps on all
  * fantasy chains, parameters frozen.  Benchmark entry. */

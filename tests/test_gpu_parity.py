@@ -267,6 +267,10 @@ def test_training_fit(ds, capsys):
     data = synthetic_onehot(100, 200, seed=12)
     model = CRBM(num_motifs=10, motif_length=15, doublestranded=ds, epochs=1, seed=1)
     w0 = model.motifs.get_value()
+    bad = data.copy()
+    bad[3, 0, :, 7] = 0.25
+    with pytest.raises(Exception, match="one-hot"):
+        model.fit(bad)
     model.fit(data)
     model.trainModel(data, data[:10])
     out = capsys.readouterr().out

@@ -95,3 +95,19 @@ def test_fails_loudly_without_gpu():
         m.motifHitProbs(np.zeros((1, 1, 4, 20), dtype=np.float32))
     with pytest.raises(Exception):
         m.fit(np.zeros((2, 1, 4, 20), dtype=np.float32))
+
+
+def test_sequence_helpers():
+    from crbm_amd import seqsToCodes, codesToOneHot, seqToOneHot
+    seqs = ["ACGTac", "ttGGca"]
+    codes = seqsToCodes(seqs)
+    np.testing.assert_array_equal(codes, [[0, 1, 2, 3, 0, 1], [3, 3, 2, 2, 1, 0]])
+    oh = seqToOneHot(seqs)
+    assert oh.shape == (2, 1, 4, 6) and oh.dtype == np.float32          # sequences.py:114-117
+    np.testing.assert_array_equal(oh.sum(axis=2), 1.0)
+    assert oh[0, 0, 3, 3] == 1 and oh[1, 0, 0, 5] == 1                   # letter map sequences.py:9-17
+    np.testing.assert_array_equal(codesToOneHot(codes), oh)
+    with pytest.raises(Exception):
+        seqsToCodes(["ACGN"])
+    with pytest.raises(Exception):
+        seqsToCodes(["ACG", "AC"])
