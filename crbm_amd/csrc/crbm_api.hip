@@ -392,7 +392,7 @@ GibbsGeom choose_gibbs_geometry(const ModelShape& ms, int Lf, int B, int num_cu)
     for (int S = 1; S <= std::min(B, 64); ++S) {
       if (forceS > 0 && S != forceS) continue;
       const GibbsLayout gl = gibbs_layout(ms, Lf, S);
-      if (gl.lds_bytes > 100 * 1024 && !(forceS > 0)) continue;
+      if (gl.lds_bytes > 150 * 1024 && !(forceS > 0)) continue;
       if (gl.lds_bytes > 160 * 1024 || (long)S * gl.Lrow * ms.NW >= (1 << 20)) continue;
       // lanes are used at wave granularity (an idle wave of a pass costs nothing);
       // h|v costs ~1.5x v|h per 4-position block

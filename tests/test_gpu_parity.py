@@ -461,3 +461,29 @@ def test_inference_streams_in_slabs(monkeypatch):
     got = b._evaluateData(data)
     np.testing.assert_allclose(got[0], ref_eval[0], rtol=1e-6)
     assert got[1] == ref_eval[1]
+
+
+@pytest.mark.parametrize("K,M,ds,L,n", [(1, 1, False, 7, 3), (1, 1, True, 1, 2), (5, 8, True, 8, 4),
+                                        (64, 32, True, 45, 3), (33, 17, False, 300, 5), (16, 16, True, 64, 6)])
+def test_edge_shapes(K, M, ds, L, n):
+    """Smallest and largest supported models, L == M (a single hidden position),
+    mask-word and 64-bit-window boundaries: activations, hit probabilities,
+    free energy, a Gibbs chain and a training step against the oracle."""
+    Lf = max(1, L - M + 1)
+    model, o = make_pair(K, M, ds=ds, batchsize=4, Lf=Lf, cd_k=2, bshift=3.0, wscale=0.7)
+    D = synthetic_onehot(n, L, seed=K + M)
+    np.testing.assert_allclose(model._bottomUpActivity(D), o._bottomUpActivity(D), rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(model._bottomUpActivity(D, True), o._bottomUpActivity(D, True), rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(model.motifHitProbs(D), o.motifHitProbs(D), rtol=RTOL, atol=1e-7)
+    np.testing.assert_allclose(model.freeEnergy(D), o.freeEnergy(D), rtol=RTOL, atol=1e-6)
+    model.gibbsSteps(2)
+    o.gibbs_steps(2)
+    h, hp = model.get_fantasy()
+    assert (h != o.fantasy_h).mean() < 1e-3
+    if ds:
+        assert (hp != o.fantasy_h_prime).mean() < 1e-3
+    model._trainingFct(D)
+    o.train_step(D)
+    np.testing.assert_allclose(model.motifs.get_value(), o.W, rtol=RTOL, atol=5e-6)
+    np.testing.assert_allclose(model.bias.get_value(), o.b, rtol=RTOL, atol=5e-6)
+    np.testing.assert_allclose(model.c.get_value(), o.c, rtol=RTOL, atol=5e-6)
