@@ -98,7 +98,9 @@ struct crbm_handle {
   int Lf = 0, Lv = 0, B = 0;
   int device = 0, num_cu = 256;
   hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipStream_t stream2 = nullptr;          // model phase of a training step runs beside the data phase
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
+  bool overlap = true;
   ModelShape ms;
   JitKernels jk;            // kernels specialised for this model (hiprtc)
   float* d_tables = nullptr;   // precomputed LDS images (gather / top-down tables, c)
@@ -111,7 +113,7 @@ struct crbm_handle {
   unsigned long long* d_ones = nullptr;
   DevBuf<float> stage, stage2, out_a, out_b, out_c;
   DevBuf<uint32_t> letters, dataset, masks_tmp;
-  DevBuf<float> partials;
+  DevBuf<float> partials, partials2;
   float* d_sums = nullptr;
   int dataset_n = 0, dataset_L = 0;
   // sampler
@@ -223,7 +225,8 @@ int launch_hgv(crbm_handle* h, const uint32_t* d_letters, int n, int L, int mode
   return CRBM_OK;
 }
 
-int launch_gibbs(crbm_handle* h, int steps) {
+int launch_gibbs(crbm_handle* h, int steps, hipStream_t s = nullptr) {
+  if (!s) s = h->stream;
   int rc = ensure_tables(h);
   if (rc) return rc;
   GibbsArgs a;
@@ -238,13 +241,15 @@ int launch_gibbs(crbm_handle* h, int steps) {
   a.steps = steps;
   a.rng = rng_view(h, h->gibbs_step, h->chain_offset);
   HIPCHK(jit_launch(h->jk.gibbs, a, (unsigned)h->gibbs_grid, 1, (unsigned)h->gibbs_threads,
-                    (unsigned)h->gl.lds_bytes, h->stream));
+                    (unsigned)h->gl.lds_bytes, s));
   h->gibbs_step += (uint32_t)steps;
   return CRBM_OK;
 }
 
 // raw statistic sums of (letters, n, L) -> sums half (data or model)
-int launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool data_half) {
+int launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool data_half, hipStream_t s = nullptr) {
+  if (!s) s = h->stream;
+  DevBuf<float>& pbuf = data_half ? h->partials : h->partials2;
   int rc = ensure_tables(h);
   if (rc) return rc;
   const int want_sp = data_half ? 1 : 0;
@@ -264,17 +269,20 @@ int launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool d
   a.off_vh0 = st.off_vh[0]; a.off_vh1 = st.off_vh[1]; a.off_h0 = st.off_h[0]; a.off_h1 = st.off_h[1];
   a.off_sw = st.off_sw; a.off_sb = st.off_sb; a.off_v = st.off_v;
   const int ntiles = ((n + st.S - 1) / st.S) * st.nseg;
-  const int gx = std::max(1, std::min(ntiles, h->stats_rows));
+  // persistent rows: one resident wave of blocks (as many per CU as their LDS allows)
+  const int per_cu = std::max(1, std::min(8, (160 * 1024) / std::max(1, st.lds_bytes)));
+  const int cap = h->stats_rows > 0 ? h->stats_rows : h->num_cu * per_cu;
+  const int gx = std::max(1, std::min(ntiles, cap));
   const int rows = gx * st.parts;
-  HIPCHK(h->partials.ensure((size_t)rows * st.row));
-  a.partials = h->partials.p;
+  HIPCHK(pbuf.ensure((size_t)rows * st.row));
+  a.partials = pbuf.p;
   a.debug = env_int("CRBM_STATS_DEBUG", 0);
-  HIPCHK(hipMemsetAsync(h->partials.p, 0, (size_t)rows * st.row * sizeof(float), h->stream));
   HIPCHK(jit_launch(h->jk.stats, a, (unsigned)gx, (unsigned)st.grid_y, (unsigned)st.threads,
-                    (unsigned)st.lds_bytes, h->stream));
+                    (unsigned)st.lds_bytes, s));
   ReduceArgs r;
-  r.partials = h->partials.p;
+  r.partials = pbuf.p;
   r.nrows = rows; r.row = st.row;
+  r.parts = st.parts; r.K = h->K; r.KAM = h->KAM; r.ds = h->ds; r.want_sparsity = want_sp;
   if (data_half) {
     r.sums = h->d_sums + h->sl.data_off;
     r.skip_begin = st.row; r.skip_len = 0;
@@ -283,7 +291,7 @@ int launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool d
     r.skip_begin = h->sl.model_skip_begin; r.skip_len = h->sl.model_skip_len;
   }
   r.n_value = (float)n;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((st.row + 15) / 16), dim3(1024), 0, h->stream, r);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((st.row + 15) / 16), dim3(1024), 0, s, r);
   HIPCHK(hipGetLastError());
   return CRBM_OK;
 }
@@ -302,18 +310,30 @@ int launch_update(crbm_handle* h, int L_data) {
   return CRBM_OK;
 }
 
-// data statistics + k Gibbs steps + model statistics -> d_sums (local)
+// data statistics + k Gibbs steps + model statistics -> d_sums (local).  The two
+// halves are independent given (W,b,c): the model half (chain + its statistics)
+// runs on a second stream beside the data half and is joined before the update.
 int train_local_dev(crbm_handle* h, const uint32_t* d_letters, int n, int L) {
-  int rc = CRBM_OK;
+  int rc = ensure_tables(h);
+  if (rc) return rc;
+  hipStream_t sm = h->overlap ? h->stream2 : h->stream;
+  if (h->overlap) {
+    HIPCHK(hipEventRecord(h->ev_fork, h->stream));          // tables ready, earlier work on the chains done
+    HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+  }
+  rc = launch_gibbs(h, h->cfg.cd_k, sm);
+  if (rc) return rc;
+  rc = launch_stats(h, h->d_vf, h->B, h->Lv, false, sm);
+  if (rc) return rc;
+  if (h->overlap) HIPCHK(hipEventRecord(h->ev_join, h->stream2));
   if (n > 0) {
     rc = launch_stats(h, d_letters, n, L, true);
+    if (rc) return rc;
   } else {   // a rank may own no rows of a short last mini-batch: contribute zeros
     HIPCHK(hipMemsetAsync(h->d_sums + h->sl.data_off, 0, (size_t)(h->sl.n_d + 1 - h->sl.data_off) * sizeof(float), h->stream));
   }
-  if (rc) return rc;
-  rc = launch_gibbs(h, h->cfg.cd_k);
-  if (rc) return rc;
-  return launch_stats(h, h->d_vf, h->B, h->Lv, false);
+  if (h->overlap) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+  return CRBM_OK;
 }
 
 int train_core(crbm_handle* h, const uint32_t* d_letters, int n, int L) {
@@ -491,8 +511,12 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
     }
   }
   TRY(hipStreamCreateWithFlags(&hh->stream, hipStreamNonBlocking));
+  TRY(hipStreamCreateWithFlags(&hh->stream2, hipStreamNonBlocking));
   TRY(hipEventCreate(&hh->ev0));
   TRY(hipEventCreate(&hh->ev1));
+  TRY(hipEventCreateWithFlags(&hh->ev_fork, hipEventDisableTiming));
+  TRY(hipEventCreateWithFlags(&hh->ev_join, hipEventDisableTiming));
+  hh->overlap = env_int("CRBM_OVERLAP", 1) != 0;
   const size_t kam = (size_t)hh->KAM, k = (size_t)hh->K;
   TRY(hipMalloc((void**)&hh->dW, kam * 4)); TRY(hipMalloc((void**)&hh->dvW, kam * 4));
   TRY(hipMalloc((void**)&hh->db, k * 4));   TRY(hipMalloc((void**)&hh->dvb, k * 4));
@@ -511,7 +535,7 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
   TRY(hipMalloc((void**)&hh->d_sums, (size_t)hh->sl.count * 4)); TRY(hipMemset(hh->d_sums, 0, (size_t)hh->sl.count * 4));
 #undef TRY
   hh->tables_dirty = true;
-  hh->stats_rows = env_int("CRBM_STATS_ROWS", 2 * hh->num_cu);
+  hh->stats_rows = env_int("CRBM_STATS_ROWS", 0);   // 0: one resident wave of blocks
   hh->stats_lds_budget = env_int("CRBM_STATS_LDS", 48 * 1024);
   *out = hh;
   return CRBM_OK;
@@ -521,15 +545,19 @@ int crbm_destroy(crbm_handle* h) {
   if (!h) return CRBM_OK;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->stream2) (void)hipStreamSynchronize(h->stream2);
   if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
   void* ptrs[] = {h->dW, h->db, h->dc, h->dvW, h->dvb, h->dvc, h->d_hm, h->d_hmp, h->d_vf, h->d_flags, h->d_ones, h->d_sums, h->d_tables};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   h->stage.release(); h->stage2.release(); h->out_a.release(); h->out_b.release(); h->out_c.release();
-  h->letters.release(); h->dataset.release(); h->masks_tmp.release(); h->partials.release();
+  h->letters.release(); h->dataset.release(); h->masks_tmp.release(); h->partials.release(); h->partials2.release();
   if (h->jk.module) (void)hipModuleUnload(h->jk.module);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  if (h->stream2) (void)hipStreamDestroy(h->stream2);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return CRBM_OK;
@@ -1054,7 +1082,8 @@ int crbm_get_launch_info(const crbm_handle* h, crbm_launch_info* out) {
   out->nq = h->ms.NQ; out->group = h->G;
   out->gibbs_grid = h->gibbs_grid; out->gibbs_block = h->gibbs_threads;
   out->gibbs_seqs_per_tile = h->gl.S; out->gibbs_lds_bytes = h->gl.lds_bytes;
-  out->stats_grid_x = h->stats_rows; out->stats_grid_y = st.grid_y;
+  out->stats_grid_x = h->stats_rows > 0 ? h->stats_rows : h->num_cu * std::max(1, std::min(8, (160 * 1024) / std::max(1, st.lds_bytes)));
+  out->stats_grid_y = st.grid_y;
   out->stats_block = st.threads; out->stats_lds_bytes = st.lds_bytes;
   return CRBM_OK;
 }

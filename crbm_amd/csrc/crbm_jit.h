@@ -85,8 +85,13 @@ inline int jit_compile(int K, int M, int DS, int G, std::vector<char>* code, boo
     return -1;
   }
   const std::string stub = jit_stub(K, M, DS, G);
-  const std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
-                                         "-I" + dir, "-I/opt/rocm/include"};
+  std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+                                   "-I" + dir, "-I/opt/rocm/include"};
+  if (const char* e = getenv("CRBM_JIT_DEFINES")) {   // tuning knobs, e.g. "-DCRBM_STATS_UNR=8"
+    std::istringstream ss(e);
+    std::string tok;
+    while (ss >> tok) opts.push_back(tok);
+  }
   int rtc_major = 0, rtc_minor = 0;
   hiprtcVersion(&rtc_major, &rtc_minor);
   uint64_t h = jit_fnv1a(stub);

@@ -581,7 +581,7 @@ struct StatsArgs {
   int32_t want_sparsity;
   FastDiv divLS, divLvis, divL;   // / LS, / (LS+M-1), / L
   int32_t row, off_vh0, off_vh1, off_h0, off_h1, off_sw, off_sb, off_v;
-  float* partials;      // [gridDim.x * parts][row], zero-initialised by the host
+  float* partials;      // [gridDim.x * parts][row]; columns nobody writes are never read (reduce_partials_kernel)
   int32_t debug;        // profiling only: bit 0 skips phase B, bit 1 skips the phase-A arithmetic
 };
 
@@ -590,7 +590,7 @@ __device__ void stats_body(const StatsArgs& a) {
   constexpr int KP = C::KP, K = C::K, M = C::M;
   constexpr int JCH = (M + 15) / 16;                     // filter columns per lane: j = 16*c + (lane & 15)
   constexpr int CH = C::STATS_CH;                        // positions bucketed at a time per wave
-  constexpr int UNR = 4;                                 // list entries consumed per iteration
+  constexpr int UNR = C::STATS_UNR;                      // list entries consumed per iteration
   HIP_DYNAMIC_SHARED(float, smem);
   const int nthr = blockDim.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = nthr >> 6;
   float* Tf = smem;
@@ -1099,11 +1099,16 @@ __global__ void __launch_bounds__(256) vgh_dense_kernel(VghArgs a) {
 
 // sums[dst(r)] = sum over partial rows of column r in a fixed order.  Block =
 // 16 columns x 64 row groups: each thread adds the rows of its group (64-byte
-// segments per row), the 64 groups are combined through LDS.
+// segments per row), the 64 groups are combined through LDS.  The partial
+// buffer is never cleared: the kernel knows which columns a statistics launch
+// wrote (pass columns: every row; h/sb/v: the first row of each block only)
+// and yields 0 for the classes that launch did not compute.
 struct ReduceArgs {
   const float* partials;
   float* sums;
   int32_t nrows, row;
+  int32_t parts;                  // rows per block of the statistics launch
+  int32_t K, KAM, ds, want_sparsity;
   int32_t skip_begin, skip_len;   // columns [skip_begin, skip_begin+skip_len) are dropped
   float n_value;                  // written after the last kept column
 };
@@ -1113,8 +1118,22 @@ __global__ void __launch_bounds__(1024) reduce_partials_kernel(ReduceArgs a) {
   const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
   const int r = blockIdx.x * 16 + col;
   float t = 0.f;
-  if (r < a.row)
-    for (int i = grp; i < a.nrows; i += 64) t += a.partials[(size_t)i * a.row + r];
+  if (r < a.row) {
+    // column classes of a partial row: [vh KAM][vh' KAM][h K][h' K][sw KAM][sb K][v 4]
+    const int K = a.K, KAM = a.KAM;
+    bool valid, owner;
+    if (r < KAM) { valid = true; owner = false; }
+    else if (r < 2 * KAM) { valid = a.ds != 0; owner = false; }
+    else if (r < 2 * KAM + K) { valid = true; owner = true; }
+    else if (r < 2 * KAM + 2 * K) { valid = a.ds != 0; owner = true; }
+    else if (r < 3 * KAM + 2 * K) { valid = a.want_sparsity != 0; owner = false; }
+    else if (r < 3 * KAM + 3 * K) { valid = a.want_sparsity != 0; owner = true; }
+    else { valid = true; owner = true; }
+    if (valid) {
+      const int step = owner ? a.parts : 1;     // h/sb/v live in the first row of each block
+      for (int i = grp * step; i < a.nrows; i += 64 * step) t += a.partials[(size_t)i * a.row + r];
+    }
+  }
   part[grp][col] = t;
   __syncthreads();
   if (grp == 0 && r < a.row) {

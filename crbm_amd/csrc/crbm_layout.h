@@ -64,6 +64,10 @@ struct Cfg {
   static constexpr int OFF_C = OFF_WT + WT;
   static constexpr int TABLES = OFF_C + 4;                // multiple of 4 floats
   static constexpr int STATS_CH = 256;                    // positions a statistics wave buckets at a time
+#ifndef CRBM_STATS_UNR
+#define CRBM_STATS_UNR 4
+#endif
+  static constexpr int STATS_UNR = (KP <= 16) ? CRBM_STATS_UNR : 2;   // parked rows in flight per lane
   static constexpr int OFF_TR = DS ? TAB : TABLES;
   static constexpr int TABLES_ALL = DS ? TABLES : TABLES + TAB;
 };

@@ -183,15 +183,26 @@ int emu_stats(int id, const float* tables, const uint32_t* letters, int n, int L
     if (gx > ntiles) gx = ntiles;
     const int rows = gx * st.parts;
     if ((long)rows * st.row > partials_cap) return -2;
-    memset(partials, 0, sizeof(float) * (size_t)rows * st.row);
+    for (size_t i = 0; i < (size_t)rows * st.row; ++i) partials[i] = 1e30f;   // never cleared on the GPU either
     emu::launch([&] { stats_body<C>(a); }, dim3(gx, st.grid_y), dim3(st.threads), (size_t)st.lds_bytes);
-    // column sums on the host (the reduce kernel itself is emulated by emu_reduce
-    // on a small case: one OS thread per GPU thread is too slow for ~2000 columns)
+    // column sums on the host, same validity rules as reduce_partials_kernel (which
+    // is emulated by emu_reduce on a small case: one OS thread per GPU thread is
+    // too slow for ~2000 columns)
     const int sb = skip_begin < 0 ? st.row : skip_begin, sl = skip_begin < 0 ? 0 : skip_len;
+    const int KAM = C::K * 4 * C::M, K = C::K;
     for (int r = 0; r < st.row; ++r) {
       if (r >= sb && r < sb + sl) continue;
+      bool valid, owner;
+      if (r < KAM) { valid = true; owner = false; }
+      else if (r < 2 * KAM) { valid = C::DS != 0; owner = false; }
+      else if (r < 2 * KAM + K) { valid = true; owner = true; }
+      else if (r < 2 * KAM + 2 * K) { valid = C::DS != 0; owner = true; }
+      else if (r < 3 * KAM + 2 * K) { valid = want_sparsity != 0; owner = false; }
+      else if (r < 3 * KAM + 3 * K) { valid = want_sparsity != 0; owner = true; }
+      else { valid = true; owner = true; }
       float t = 0.f;
-      for (int i = 0; i < rows; ++i) t += partials[(size_t)i * st.row + r];
+      if (valid)
+        for (int i = 0; i < rows; i += owner ? st.parts : 1) t += partials[(size_t)i * st.row + r];
       sums[r < sb ? r : r - sl] = t;
     }
     sums[st.row - sl] = (float)n;
@@ -200,8 +211,10 @@ int emu_stats(int id, const float* tables, const uint32_t* letters, int n, int L
   return row;
 }
 
-int emu_reduce(const float* partials, float* sums, int nrows, int row, int skip_begin, int skip_len, float n_value) {
-  ReduceArgs r{partials, sums, nrows, row, skip_begin, skip_len, n_value};
+int emu_reduce(const float* partials, float* sums, int nrows, int row, int parts, int K, int KAM, int ds, int want,
+               int skip_begin, int skip_len, float n_value) {
+  // a synthetic layout: K = 1, KAM = 2 -> row = 3*2 + 3 + 4 = 13 columns when row == 13
+  ReduceArgs r{partials, sums, nrows, row, parts, K, KAM, ds, want, skip_begin, skip_len, n_value};
   emu::launch([&] { reduce_partials_kernel(r); }, dim3((row + 15) / 16), dim3(1024), 0);
   return 0;
 }
