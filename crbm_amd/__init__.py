@@ -6,6 +6,8 @@ behind the C-ABI in include/crbm_amd.h.
 """
 from .crbm import CRBM  # noqa: F401
 from . import dist  # noqa: F401
-from .sequences import seqsToCodes, codesToOneHot, seqToOneHot  # noqa: F401
+from .sequences import (seqsToCodes, codesToOneHot, seqToOneHot, readSeqsFromFasta,  # noqa: F401
+                        splitTrainingTest, fastaToCodes, writeFasta, load_sample)
+from .utils import saveMotifs  # noqa: F401
 
 __version__ = "0.1.0"

@@ -73,6 +73,7 @@ SIGNATURES = {
     "crbm_train_step": (_I32, [_H, _F, _I32, _I32]),
     "crbm_dataset_upload": (_I32, [_H, _F, _I32, _I32]),
     "crbm_dataset_upload_codes": (_I32, [_H, _U8P, _I32, _I32]),
+    "crbm_dataset_select": (_I32, [_H, _I32]),
     "crbm_train_step_resident": (_I32, [_H, _I32, _I32]),
     "crbm_gibbs_steps": (_I32, [_H, _I32]),
     "crbm_gibbs_steps_async": (_I32, [_H, _I32]),
@@ -86,6 +87,14 @@ SIGNATURES = {
     "crbm_free_energy_per_motif": (_I32, [_H, _F, _I32, _I32, _F]),
     "crbm_eval_data": (_I32, [_H, _F, _I32, _I32, _F, _F]),
     "crbm_eval_params": (_I32, [_H, _F, _F, _F]),
+    "crbm_hit_probs_codes": (_I32, [_H, _U8P, _I32, _I32, _F]),
+    "crbm_hit_probs_resident": (_I32, [_H, _I32, _I32, _F]),
+    "crbm_free_energy_codes": (_I32, [_H, _U8P, _I32, _I32, _F, _F]),
+    "crbm_free_energy_resident": (_I32, [_H, _I32, _I32, _F, _F]),
+    "crbm_eval_data_resident": (_I32, [_H, _I32, _I32, _F, _F]),
+    "crbm_hit_summary": (_I32, [_H, _F, _I32, _I32, _F, _F, _F]),
+    "crbm_hit_summary_codes": (_I32, [_H, _U8P, _I32, _I32, _F, _F, _F]),
+    "crbm_hit_summary_resident": (_I32, [_H, _I32, _I32, _F, _F, _F]),
     "crbm_comm_unique_id": (_I32, [_U8P]),
     "crbm_comm_init": (_I32, [_H, _U8P, _I32, _I32]),
     "crbm_comm_destroy": (_I32, [_H]),

@@ -206,6 +206,21 @@ class CRBM(object):
         return data
 
     @staticmethod
+    def _is_codes(data):
+        """True for the packed input form: a 2-D uint8 array (n, L) of letter codes 0..3
+        (crbm_amd.sequences.seqsToCodes / fastaToCodes)."""
+        return isinstance(data, np.ndarray) and data.ndim == 2 and data.dtype == np.uint8
+
+    def _input(self, data):
+        """-> (suffix, leading ctypes args, n, L) for the `crbm_*` / `crbm_*_codes` entry points."""
+        if self._is_codes(data):
+            codes = np.ascontiguousarray(data)
+            return "_codes", (codes.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), codes.shape[0], codes.shape[1]), \
+                codes.shape[0], codes.shape[1], codes
+        data = self._data(data)
+        return "", (fptr(data), data.shape[0], data.shape[3]), data.shape[0], data.shape[3], data
+
+    @staticmethod
     def _data_codes(data):
         """(n,1,4,L) one-hot float array -> (n,L) uint8 letter codes; raises unless exactly one-hot."""
         onehot = (data[:, 0] == 1.0)
@@ -344,23 +359,38 @@ class CRBM(object):
         self._call("crbm_train_step", fptr(data), data.shape[0], data.shape[3])
 
     def motifHitProbs(self, data):
-        """convRBM.py:535-547 -> (n,K,1,L-M+1)."""
-        data = self._data(data)
-        n, L = data.shape[0], data.shape[3]
+        """convRBM.py:535-547 -> (n,K,1,L-M+1).  `data` is the reference's one-hot
+        array or, for data-set scale sweeps, (n,L) uint8 letter codes."""
+        suffix, args, n, L, _keep = self._input(data)
         out = np.empty((n, self.num_motifs, 1, L - self.motif_length + 1), dtype=np.float32)
-        self._call("crbm_hit_probs", fptr(data), n, L, fptr(out))
+        self._call("crbm_hit_probs" + suffix, *(args + (fptr(out),)))
+        return out
+
+    def motifHitSummary(self, data, position_mean=True):
+        """The reductions of motifHitProbs() the reference's analysis code takes
+        (utils.py:113-116, :154, :242-244, :305), computed on the device without the
+        dense (n,K,1,Lh) tensor: dict with 'max' (n,K) = P.max(axis=(2,3)),
+        'mean' (n,K) = P.mean(axis=(2,3)), 'position_mean' (K,Lh) = P.mean(axis=(0,2))."""
+        suffix, args, n, L, _keep = self._input(data)
+        K, Lh = self.num_motifs, L - self.motif_length + 1
+        hmax = np.empty((n, K), dtype=np.float32)
+        hmean = np.empty((n, K), dtype=np.float32)
+        pos = np.empty((K, Lh), dtype=np.float32) if position_mean else None
+        self._call("crbm_hit_summary" + suffix, *(args + (fptr(hmax), fptr(hmean),
+                                                           fptr(pos) if position_mean else None)))
+        out = {"max": hmax, "mean": hmean}
+        if position_mean:
+            out["position_mean"] = pos
         return out
 
     def freeEnergy(self, data, permotif=False):
-        """convRBM.py:549-568 -> (n,) or (n,K)."""
-        data = self._data(data)
-        n, L = data.shape[0], data.shape[3]
-        if permotif:
-            out = np.empty((n, self.num_motifs), dtype=np.float32)
-            self._call("crbm_free_energy_per_motif", fptr(data), n, L, fptr(out))
+        """convRBM.py:549-568 -> (n,) or (n,K); one-hot or (n,L) uint8 codes."""
+        suffix, args, n, L, _keep = self._input(data)
+        out = np.empty((n, self.num_motifs) if permotif else (n,), dtype=np.float32)
+        if suffix:
+            self._call("crbm_free_energy_codes", *(args + ((None, fptr(out)) if permotif else (fptr(out), None))))
         else:
-            out = np.empty((n,), dtype=np.float32)
-            self._call("crbm_free_energy", fptr(data), n, L, fptr(out))
+            self._call("crbm_free_energy_per_motif" if permotif else "crbm_free_energy", *(args + (fptr(out),)))
         return out
 
     def getPFMs(self):
@@ -379,46 +409,58 @@ class CRBM(object):
         with the parameters frozen."""
         self._call("crbm_gibbs_steps", int(k))
 
+    def _upload(self, data, slot):
+        """Make a data set resident in HBM (packed 2-bit) in the given slot; returns (n, L).
+        Ships one byte per base instead of the float one-hot array: 16x less PCIe traffic."""
+        if self._is_codes(data):
+            codes = np.ascontiguousarray(data)
+        else:
+            codes = self._data_codes(self._data(data))   # refuses anything that is not exactly one-hot
+        self._call("crbm_dataset_select", slot)
+        self._call("crbm_dataset_upload_codes", codes.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)),
+                   codes.shape[0], codes.shape[1])
+        return codes.shape
+
+    def _truncate(self, data):
+        """convRBM.py:586-599: truncate so that (L-M+1) % pooling == 0."""
+        L = data.shape[-1]
+        nseq = int((L - self.motif_length + 1) / self.pooling) * self.pooling + self.motif_length - 1
+        return data[..., :nseq]
+
     def fit(self, training_data, test_data=None):
         """convRBM.py:570-634: epochs x sequential, unshuffled mini-batches;
-        one status line per epoch.  The training set is uploaded once (packed
-        2-bit) and the batch loop only passes row bounds."""
-        # convRBM.py:586-599: truncate so that (L-M+1) % pooling == 0
-        nseq = int((training_data.shape[3] - self.motif_length + 1) / self.pooling) * \
-            self.pooling + self.motif_length - 1
-        training_data = training_data[:, :, :, :nseq]
-        if test_data is not None:
-            nseq = int((test_data.shape[3] - self.motif_length + 1) / self.pooling) * \
-                self.pooling + self.motif_length - 1
-            test_data = test_data[:, :, :, :nseq]
-        else:
-            test_data = training_data
+        one status line per epoch.  Both sets are uploaded once (packed 2-bit)
+        and the loops only pass row bounds.  Besides the reference's one-hot
+        arrays, (n,L) uint8 letter codes are accepted."""
+        training_data = self._truncate(training_data)
+        same = test_data is None
+        test_data = training_data if same else self._truncate(test_data)
 
         print(("BatchSize: " + str(self.batchsize)))
         print("Start training the model...")
         starttime = time.time()
-        h = self._h()
-        lib = self._lib
-        train = self._data(training_data)
-        test = self._data(test_data)
+        self._h()
+        ntrain = ntest = 0
         if self.epochs > 0:
-            # ship letters (1 byte per base) instead of the float one-hot array: 16x less PCIe traffic;
-            # _data_codes() refuses anything that is not exactly one-hot
-            codes = self._data_codes(train)
-            self._call("crbm_dataset_upload_codes", codes.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)),
-                       train.shape[0], train.shape[3])
+            ntrain, _ = self._upload(training_data, 0)
+            ntest = ntrain if same else self._upload(test_data, 1)[0]
         for epoch in range(self.epochs):
-            for [start, end] in self._iterateBatchIndices(train.shape[0], self.batchsize):
+            self._call("crbm_dataset_select", 0)
+            for [start, end] in self._iterateBatchIndices(ntrain, self.batchsize):
                 lo, hi = self._shard_rows(start, end)
                 self._call("crbm_train_step_resident", lo, hi)
             meanfe = 0.0
             meannmh = 0.0
             nb = 0
-            for [start, end] in self._iterateBatchIndices(test.shape[0], self.batchsize):
-                [mfe_, nmh_] = self._evaluateData(test[start:end, :, :, :])
-                meanfe = meanfe + mfe_
-                meannmh = meannmh + nmh_
+            self._call("crbm_dataset_select", 0 if same else 1)
+            mfe, nmh = ctypes.c_float(), ctypes.c_float()
+            for [start, end] in self._iterateBatchIndices(ntest, self.batchsize):
+                # convRBM.py:619-625 on rows of the resident test set
+                self._call("crbm_eval_data_resident", start, end, ctypes.byref(mfe), ctypes.byref(nmh))
+                meanfe = meanfe + mfe.value
+                meannmh = meannmh + nmh.value
                 nb = nb + 1
+            self._call("crbm_dataset_select", 0)
             [twn_, ic_, medic_] = self._evaluateParams()
             if self.rank == 0:
                 print(("Epoch {:d}: ".format(epoch) +

@@ -112,10 +112,12 @@ struct crbm_handle {
   uint32_t* d_flags = nullptr;
   unsigned long long* d_ones = nullptr;
   DevBuf<float> stage, stage2, out_a, out_b, out_c;
-  DevBuf<uint32_t> letters, dataset, masks_tmp;
+  DevBuf<uint32_t> letters, masks_tmp;
+  DevBuf<uint32_t> dataset[CRBM_DATASET_SLOTS];   // resident data sets (slot 0: training, slot 1: test by convention)
   DevBuf<float> partials, partials2;
   float* d_sums = nullptr;
-  int dataset_n = 0, dataset_L = 0;
+  int dataset_n[CRBM_DATASET_SLOTS] = {0, 0}, dataset_L[CRBM_DATASET_SLOTS] = {0, 0};
+  int slot = 0;
   // sampler
   uint64_t seed = 0;
   uint32_t gibbs_step = 0, eval_step = 0, chain_offset = 0;
@@ -201,6 +203,20 @@ int encode_host(crbm_handle* h, const float* v, int n, int L, uint32_t* d_letter
   a.n = n; a.L = L; a.LW = letter_words(L);
   const int grid = grid_for((long)n * a.LW, 256, h->num_cu * 8);
   hipLaunchKernelGGL(encode_onehot_kernel, dim3(grid), dim3(256), 0, h->stream, a);
+  HIPCHK(hipGetLastError());
+  return check_flags(h);
+}
+
+// host bytes (n,L) -> packed letters on the device
+int encode_codes_host(crbm_handle* h, const uint8_t* codes, int n, int L, uint32_t* d_letters) {
+  const size_t bytes = (size_t)n * L;
+  HIPCHK(h->stage.ensure((bytes + 3) / 4));
+  HIPCHK(hipMemcpyAsync(h->stage.p, codes, bytes, hipMemcpyHostToDevice, h->stream));
+  EncodeCodesArgs a;
+  a.codes = reinterpret_cast<const unsigned char*>(h->stage.p);
+  a.letters = d_letters; a.flags = h->d_flags;
+  a.n = n; a.L = L; a.LW = letter_words(L);
+  hipLaunchKernelGGL(encode_codes_kernel, dim3(grid_for((long)n * a.LW, 256, h->num_cu * 8)), dim3(256), 0, h->stream, a);
   HIPCHK(hipGetLastError());
   return check_flags(h);
 }
@@ -551,7 +567,8 @@ int crbm_destroy(crbm_handle* h) {
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   h->stage.release(); h->stage2.release(); h->out_a.release(); h->out_b.release(); h->out_c.release();
-  h->letters.release(); h->dataset.release(); h->masks_tmp.release(); h->partials.release(); h->partials2.release();
+  h->letters.release(); h->masks_tmp.release();
+  for (auto& d : h->dataset) d.release(); h->partials.release(); h->partials2.release();
   if (h->jk.module) (void)hipModuleUnload(h->jk.module);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -698,21 +715,30 @@ int crbm_train_step(crbm_handle* h, const float* D, int32_t n, int32_t L) {
   return CRBM_OK;
 }
 
+int crbm_dataset_select(crbm_handle* h, int32_t slot) {
+  ENTER();
+  ARGCHK(slot >= 0 && slot < CRBM_DATASET_SLOTS, "no such data-set slot");
+  h->slot = slot;
+  return CRBM_OK;
+}
+
 int crbm_dataset_upload(crbm_handle* h, const float* data, int32_t n, int32_t L) {
   ENTER();
   ARGCHK(data, "null argument");
   int rc = check_data_shape(h, n, L);
   if (rc) return rc;
   const int LW = letter_words(L);
-  HIPCHK(h->dataset.ensure((size_t)n * LW));
+  DevBuf<uint32_t>& ds = h->dataset[h->slot];
+  h->dataset_n[h->slot] = 0;
+  HIPCHK(ds.ensure((size_t)n * LW));
   // stream the fp32 array through the staging buffer in slabs of <= 64 MiB
   const int slab = std::max(1, (int)std::min<long>(n, (64L << 20) / ((long)4 * L * 4)));
   for (int start = 0; start < n; start += slab) {
     const int cnt = std::min(slab, n - start);
-    rc = encode_host(h, data + (size_t)start * 4 * L, cnt, L, h->dataset.p + (size_t)start * LW);
+    rc = encode_host(h, data + (size_t)start * 4 * L, cnt, L, ds.p + (size_t)start * LW);
     if (rc) return rc;
   }
-  h->dataset_n = n; h->dataset_L = L;
+  h->dataset_n[h->slot] = n; h->dataset_L[h->slot] = L;
   return CRBM_OK;
 }
 
@@ -722,29 +748,27 @@ int crbm_dataset_upload_codes(crbm_handle* h, const uint8_t* codes, int32_t n, i
   int rc = check_data_shape(h, n, L);
   if (rc) return rc;
   const int LW = letter_words(L);
-  HIPCHK(h->dataset.ensure((size_t)n * LW));
-  const size_t bytes = (size_t)n * L;
-  HIPCHK(h->stage.ensure((bytes + 3) / 4));
-  HIPCHK(hipMemcpyAsync(h->stage.p, codes, bytes, hipMemcpyHostToDevice, h->stream));
-  EncodeCodesArgs a;
-  a.codes = reinterpret_cast<const unsigned char*>(h->stage.p);
-  a.letters = h->dataset.p; a.flags = h->d_flags;
-  a.n = n; a.L = L; a.LW = LW;
-  hipLaunchKernelGGL(encode_codes_kernel, dim3(grid_for((long)n * LW, 256, h->num_cu * 8)), dim3(256), 0, h->stream, a);
-  HIPCHK(hipGetLastError());
-  rc = check_flags(h);
-  if (rc) return rc;
-  h->dataset_n = n; h->dataset_L = L;
+  DevBuf<uint32_t>& ds = h->dataset[h->slot];
+  h->dataset_n[h->slot] = 0;
+  HIPCHK(ds.ensure((size_t)n * LW));
+  const int slab = std::max(1, (int)std::min<long>(n, (256L << 20) / (long)L));
+  for (int start = 0; start < n; start += slab) {
+    const int cnt = std::min(slab, n - start);
+    rc = encode_codes_host(h, codes + (size_t)start * L, cnt, L, ds.p + (size_t)start * LW);
+    if (rc) return rc;
+  }
+  h->dataset_n[h->slot] = n; h->dataset_L[h->slot] = L;
   return CRBM_OK;
 }
 
 int crbm_train_step_resident(crbm_handle* h, int32_t start, int32_t end) {
   ENTER();
-  ARGCHK(h->dataset_n > 0, "no resident data set (call crbm_dataset_upload)");
-  ARGCHK(start >= 0 && end >= start && end <= h->dataset_n, "row range out of bounds");
+  const int slot = h->slot;
+  ARGCHK(h->dataset_n[slot] > 0, "no resident data set (call crbm_dataset_upload)");
+  ARGCHK(start >= 0 && end >= start && end <= h->dataset_n[slot], "row range out of bounds");
   ARGCHK(end > start || h->comm, "empty row range");
-  const int LW = letter_words(h->dataset_L);
-  int rc = train_core(h, h->dataset.p + (size_t)start * LW, end - start, h->dataset_L);
+  const int LW = letter_words(h->dataset_L[slot]);
+  int rc = train_core(h, h->dataset[slot].p + (size_t)start * LW, end - start, h->dataset_L[slot]);
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(h->stream));
   return CRBM_OK;
@@ -784,12 +808,13 @@ int crbm_time_gibbs(crbm_handle* h, int32_t k, int32_t launches, float* total_ms
 
 int crbm_time_train(crbm_handle* h, int32_t start, int32_t end, int32_t launches, float* total_ms) {
   ENTER();
-  ARGCHK(h->dataset_n > 0, "no resident data set (call crbm_dataset_upload)");
-  ARGCHK(start >= 0 && end > start && end <= h->dataset_n && launches >= 1 && total_ms, "bad argument");
-  const int LW = letter_words(h->dataset_L);
+  const int slot = h->slot;
+  ARGCHK(h->dataset_n[slot] > 0, "no resident data set (call crbm_dataset_upload)");
+  ARGCHK(start >= 0 && end > start && end <= h->dataset_n[slot] && launches >= 1 && total_ms, "bad argument");
+  const int LW = letter_words(h->dataset_L[slot]);
   HIPCHK(hipEventRecord(h->ev0, h->stream));
   for (int i = 0; i < launches; ++i) {
-    int rc = train_core(h, h->dataset.p + (size_t)start * LW, end - start, h->dataset_L);
+    int rc = train_core(h, h->dataset[slot].p + (size_t)start * LW, end - start, h->dataset_L[slot]);
     if (rc) return rc;
   }
   HIPCHK(hipEventRecord(h->ev1, h->stream));
@@ -862,9 +887,11 @@ int crbm_v_given_h(crbm_handle* h, const float* hid, const float* hid_prime, int
 }
 
 // ---- evaluation --------------------------------------------------------------
-// sequences per slab so that the staged fp32 input plus the dense outputs of
-// one slab stay around 256 MB (inference over data sets far larger than HBM
-// scratch: SURVEY 8(f)-1)
+// Every evaluation entry point exists in three forms: fp32 one-hot host input
+// (the reference's layout), one byte per base host input (`_codes`), and rows of
+// a data set already resident in HBM (`_resident`).  Host input is streamed in
+// slabs so that the staged input plus the outputs of one slab stay around
+// 256 MB (data sets far larger than the scratch: SURVEY 8(f)-1).
 static int slab_rows(int n, size_t bytes_per_row) {
   const size_t budget = (size_t)env_int("CRBM_SLAB_BYTES", 256 << 20);
   size_t rows = budget / std::max<size_t>(bytes_per_row, 1);
@@ -872,22 +899,54 @@ static int slab_rows(int n, size_t bytes_per_row) {
   return (int)std::min<size_t>(rows, (size_t)n);
 }
 
-int crbm_hit_probs(crbm_handle* h, const float* v, int32_t n, int32_t L, float* out) {
-  ENTER();
-  ARGCHK(v && out, "null argument");
-  int rc = check_data_shape(h, n, L);
+namespace {
+
+// where the letters of an evaluation call come from
+struct RowSource {
+  const float* onehot = nullptr;      // host (n,1,4,L) fp32
+  const uint8_t* codes = nullptr;     // host (n,L) bytes 0..3
+  const uint32_t* resident = nullptr; // device packed rows
+  int n = 0, L = 0;
+  size_t in_bytes_per_row() const { return onehot ? (size_t)16 * L : (codes ? (size_t)L : 0); }
+};
+
+// packed letters of rows [start, start+cnt) of a source; host sources go through h->letters
+int source_rows(crbm_handle* h, const RowSource& src, int start, int cnt, const uint32_t** out) {
+  const int LW = letter_words(src.L);
+  if (src.resident) {
+    *out = src.resident + (size_t)start * LW;
+    return CRBM_OK;
+  }
+  HIPCHK(h->letters.ensure((size_t)cnt * LW));
+  *out = h->letters.p;
+  if (src.onehot) return encode_host(h, src.onehot + (size_t)start * 4 * src.L, cnt, src.L, h->letters.p);
+  return encode_codes_host(h, src.codes + (size_t)start * src.L, cnt, src.L, h->letters.p);
+}
+
+int resident_source(crbm_handle* h, int start, int end, RowSource* src) {
+  const int slot = h->slot;
+  ARGCHK(h->dataset_n[slot] > 0, "no resident data set (call crbm_dataset_upload)");
+  ARGCHK(start >= 0 && end > start && end <= h->dataset_n[slot], "row range out of bounds");
+  src->L = h->dataset_L[slot];
+  src->n = end - start;
+  src->resident = h->dataset[slot].p + (size_t)start * letter_words(src->L);
+  return CRBM_OK;
+}
+
+int hit_probs_any(crbm_handle* h, const RowSource& src, float* out) {
+  int rc = check_data_shape(h, src.n, src.L);
   if (rc) return rc;
-  const int Lh = L - h->M + 1;
+  const int L = src.L, Lh = L - h->M + 1;
   const size_t per_seq_out = (size_t)h->K * Lh;
-  const int slab = slab_rows(n, ((size_t)4 * L + per_seq_out) * sizeof(float));
-  HIPCHK(h->letters.ensure((size_t)slab * letter_words(L)));
+  const int slab = slab_rows(src.n, src.in_bytes_per_row() + per_seq_out * sizeof(float));
   HIPCHK(h->out_b.ensure((size_t)slab * per_seq_out));
-  for (int start = 0; start < n; start += slab) {
-    const int cnt = std::min(slab, n - start);
-    rc = encode_host(h, v + (size_t)start * 4 * L, cnt, L, h->letters.p);
+  for (int start = 0; start < src.n; start += slab) {
+    const int cnt = std::min(slab, src.n - start);
+    const uint32_t* rows = nullptr;
+    rc = source_rows(h, src, start, cnt, &rows);
     if (rc) return rc;
     // convRBM.py:507-514: doublestranded -> sigma(x); single-stranded -> sigma(x + x')
-    rc = launch_hgv(h, h->letters.p, cnt, L, h->ds ? 0 : 2, nullptr, h->out_b.p, nullptr, nullptr, KIND_API_H, 0, 0);
+    rc = launch_hgv(h, rows, cnt, L, h->ds ? 0 : 2, nullptr, h->out_b.p, nullptr, nullptr, KIND_API_H, 0, 0);
     if (rc) return rc;
     rc = copy_out(h, out + (size_t)start * per_seq_out, h->out_b.p, (size_t)cnt * per_seq_out);
     if (rc) return rc;
@@ -896,74 +955,62 @@ int crbm_hit_probs(crbm_handle* h, const float* v, int32_t n, int32_t L, float* 
   return CRBM_OK;
 }
 
-// one slab: letters must already be in h->letters
-static int free_energy_slab(crbm_handle* h, int n, int L, float* fe, float* fem) {
+// free energies of n packed rows into h->out_a (per sequence) / h->out_b (per motif), no copy
+int launch_free_energy(crbm_handle* h, const uint32_t* rows, int n, int L) {
   int rc = ensure_tables(h);
   if (rc) return rc;
   HIPCHK(h->out_a.ensure((size_t)n));
   HIPCHK(h->out_b.ensure((size_t)n * h->K));
   FeArgs a;
   a.tables = h->d_tables;
-  a.letters = h->letters.p;
+  a.letters = rows;
   a.n = n; a.L = L; a.Lh = L - h->M + 1; a.LW = letter_words(L);
   a.fe = h->out_a.p; a.fem = h->out_b.p;
   const unsigned gx = (unsigned)std::max(1, std::min((n + 3) / 4, h->num_cu * 8));
   HIPCHK(jit_launch(h->jk.free_energy, a, gx, 1, 256, (unsigned)((1 + h->ds) * tab_bytes(h)), h->stream));
-  if (fe && (rc = copy_out(h, fe, h->out_a.p, (size_t)n))) return rc;
-  if (fem && (rc = copy_out(h, fem, h->out_b.p, (size_t)n * h->K))) return rc;
-  HIPCHK(hipStreamSynchronize(h->stream));
   return CRBM_OK;
 }
 
-static int free_energy_common(crbm_handle* h, const float* v, int n, int L, float* fe, float* fem) {
-  int rc = check_data_shape(h, n, L);
+int free_energy_any(crbm_handle* h, const RowSource& src, float* fe, float* fem) {
+  int rc = check_data_shape(h, src.n, src.L);
   if (rc) return rc;
-  const int slab = slab_rows(n, ((size_t)4 * L + h->K + 1) * sizeof(float));
-  HIPCHK(h->letters.ensure((size_t)slab * letter_words(L)));
-  for (int start = 0; start < n; start += slab) {
-    const int cnt = std::min(slab, n - start);
-    rc = encode_host(h, v + (size_t)start * 4 * L, cnt, L, h->letters.p);
+  const int slab = slab_rows(src.n, src.in_bytes_per_row() + ((size_t)h->K + 1) * sizeof(float));
+  for (int start = 0; start < src.n; start += slab) {
+    const int cnt = std::min(slab, src.n - start);
+    const uint32_t* rows = nullptr;
+    rc = source_rows(h, src, start, cnt, &rows);
     if (rc) return rc;
-    rc = free_energy_slab(h, cnt, L, fe ? fe + start : nullptr, fem ? fem + (size_t)start * h->K : nullptr);
+    rc = launch_free_energy(h, rows, cnt, src.L);
     if (rc) return rc;
+    if (fe && (rc = copy_out(h, fe + start, h->out_a.p, (size_t)cnt))) return rc;
+    if (fem && (rc = copy_out(h, fem + (size_t)start * h->K, h->out_b.p, (size_t)cnt * h->K))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
   }
   return CRBM_OK;
 }
 
-int crbm_free_energy(crbm_handle* h, const float* v, int32_t n, int32_t L, float* out) {
-  ENTER();
-  ARGCHK(v && out, "null argument");
-  return free_energy_common(h, v, n, L, out, nullptr);
-}
-
-int crbm_free_energy_per_motif(crbm_handle* h, const float* v, int32_t n, int32_t L, float* out) {
-  ENTER();
-  ARGCHK(v && out, "null argument");
-  return free_energy_common(h, v, n, L, nullptr, out);
-}
-
-int crbm_eval_data(crbm_handle* h, const float* v, int32_t n, int32_t L, float* mfe, float* nmh) {
-  ENTER();
-  ARGCHK(v && mfe && nmh, "null argument");
-  int rc = check_data_shape(h, n, L);
+int eval_data_any(crbm_handle* h, const RowSource& src, float* mfe, float* nmh) {
+  int rc = check_data_shape(h, src.n, src.L);
   if (rc) return rc;
-  const int slab = slab_rows(n, ((size_t)4 * L + h->K + 1) * sizeof(float));
-  HIPCHK(h->letters.ensure((size_t)slab * letter_words(L)));
+  const int n = src.n, L = src.L;
+  const int slab = slab_rows(n, src.in_bytes_per_row() + ((size_t)h->K + 1) * sizeof(float));
   std::vector<float> fe((size_t)slab);
   double tot = 0.0;
   HIPCHK(hipMemsetAsync(h->d_ones, 0, sizeof(unsigned long long), h->stream));
   for (int start = 0; start < n; start += slab) {
     const int cnt = std::min(slab, n - start);
-    rc = encode_host(h, v + (size_t)start * 4 * L, cnt, L, h->letters.p);
+    const uint32_t* rows = nullptr;
+    rc = source_rows(h, src, start, cnt, &rows);
     if (rc) return rc;
-    rc = free_energy_slab(h, cnt, L, fe.data(), nullptr);
+    rc = launch_free_energy(h, rows, cnt, L);
     if (rc) return rc;
-    for (int i = 0; i < cnt; ++i) tot += fe[i];
-    // mean of a fresh forward-strand sample (convRBM.py:469-472); rows keep their global index
-    rc = launch_hgv(h, h->letters.p, cnt, L, 0, nullptr, nullptr, nullptr, h->d_ones, KIND_EVAL_H, h->eval_step,
-                    (uint32_t)start);
+    rc = copy_out(h, fe.data(), h->out_a.p, (size_t)cnt);
+    if (rc) return rc;
+    // mean of a fresh forward-strand sample (convRBM.py:469-472); rows keep their index within the call
+    rc = launch_hgv(h, rows, cnt, L, 0, nullptr, nullptr, nullptr, h->d_ones, KIND_EVAL_H, h->eval_step, (uint32_t)start);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < cnt; ++i) tot += fe[i];
   }
   *mfe = (float)(tot / n);                       // convRBM.py:636-638
   h->eval_step += 1;
@@ -972,6 +1019,154 @@ int crbm_eval_data(crbm_handle* h, const float* v, int32_t n, int32_t L, float* 
   HIPCHK(hipStreamSynchronize(h->stream));
   *nmh = (float)((double)ones / ((double)n * h->K * (L - h->M + 1)));
   return CRBM_OK;
+}
+
+// max / mean over positions per (sequence, motif) and mean over sequences per (motif, position)
+int hit_summary_any(crbm_handle* h, const RowSource& src, float* hmax, float* hmean, float* posmean) {
+  int rc = check_data_shape(h, src.n, src.L);
+  if (rc) return rc;
+  rc = ensure_tables(h);
+  if (rc) return rc;
+  const int n = src.n, L = src.L, Lh = L - h->M + 1, K = h->K;
+  const int tabs = (h->ds ? 1 : 2) * tab_bytes(h);
+  // a block covers one chunk of 64*HIT_NI positions; its (PC,K) sums share the LDS with the tables
+  const int PC = 64 * h->ms.HIT_NI;
+  const int nchunks = (Lh + PC - 1) / PC;
+  const unsigned lds = (unsigned)(tabs + (size_t)PC * K * 4);
+  ARGCHK(lds <= 160u * 1024u, "model too large for the hit-summary kernel");
+  const int slab = slab_rows(n, src.in_bytes_per_row() + (size_t)2 * K * sizeof(float));
+  HIPCHK(h->out_a.ensure((size_t)slab * K));
+  HIPCHK(h->out_b.ensure((size_t)slab * K));
+  if (posmean) {
+    HIPCHK(h->out_c.ensure((size_t)K * Lh));
+    HIPCHK(hipMemsetAsync(h->out_c.p, 0, (size_t)K * Lh * 4, h->stream));
+  }
+  std::vector<float> sums;
+  for (int start = 0; start < n; start += slab) {
+    const int cnt = std::min(slab, n - start);
+    const uint32_t* rows = nullptr;
+    rc = source_rows(h, src, start, cnt, &rows);
+    if (rc) return rc;
+    if (nchunks > 1) {
+      HIPCHK(hipMemsetAsync(h->out_a.p, 0, (size_t)cnt * K * 4, h->stream));
+      HIPCHK(hipMemsetAsync(h->out_b.p, 0, (size_t)cnt * K * 4, h->stream));
+    }
+    HitArgs a;
+    a.tables = h->d_tables; a.letters = rows;
+    a.n = cnt; a.L = L; a.Lh = Lh; a.LW = letter_words(L);
+    a.hmax = hmax ? h->out_a.p : nullptr;
+    a.hsum = hmean ? h->out_b.p : nullptr;
+    a.pos = posmean ? h->out_c.p : nullptr;
+    const unsigned gx = (unsigned)std::max(1, std::min((cnt + 3) / 4, std::max(1, h->num_cu * 8 / nchunks)));
+    HIPCHK(jit_launch(h->jk.hit_summary, a, gx, (unsigned)nchunks, 256, lds, h->stream));
+    if (hmax && (rc = copy_out(h, hmax + (size_t)start * K, h->out_a.p, (size_t)cnt * K))) return rc;
+    if (hmean && (rc = copy_out(h, hmean + (size_t)start * K, h->out_b.p, (size_t)cnt * K))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  if (hmean) {
+    const float inv = 1.0f / (float)Lh;
+    for (size_t i = 0; i < (size_t)n * K; ++i) hmean[i] *= inv;
+  }
+  if (posmean) {
+    rc = copy_out(h, posmean, h->out_c.p, (size_t)K * Lh);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const float inv = 1.0f / (float)n;
+    for (size_t i = 0; i < (size_t)K * Lh; ++i) posmean[i] *= inv;
+  }
+  return CRBM_OK;
+}
+
+static RowSource host_onehot(const float* v, int n, int L) { RowSource s; s.onehot = v; s.n = n; s.L = L; return s; }
+static RowSource host_codes(const uint8_t* c, int n, int L) { RowSource s; s.codes = c; s.n = n; s.L = L; return s; }
+
+}  // namespace
+
+int crbm_hit_probs(crbm_handle* h, const float* v, int32_t n, int32_t L, float* out) {
+  ENTER();
+  ARGCHK(v && out, "null argument");
+  return hit_probs_any(h, host_onehot(v, n, L), out);
+}
+
+int crbm_hit_probs_codes(crbm_handle* h, const uint8_t* codes, int32_t n, int32_t L, float* out) {
+  ENTER();
+  ARGCHK(codes && out, "null argument");
+  return hit_probs_any(h, host_codes(codes, n, L), out);
+}
+
+int crbm_hit_probs_resident(crbm_handle* h, int32_t start, int32_t end, float* out) {
+  ENTER();
+  ARGCHK(out, "null argument");
+  RowSource src;
+  int rc = resident_source(h, start, end, &src);
+  if (rc) return rc;
+  return hit_probs_any(h, src, out);
+}
+
+int crbm_free_energy(crbm_handle* h, const float* v, int32_t n, int32_t L, float* out) {
+  ENTER();
+  ARGCHK(v && out, "null argument");
+  return free_energy_any(h, host_onehot(v, n, L), out, nullptr);
+}
+
+int crbm_free_energy_per_motif(crbm_handle* h, const float* v, int32_t n, int32_t L, float* out) {
+  ENTER();
+  ARGCHK(v && out, "null argument");
+  return free_energy_any(h, host_onehot(v, n, L), nullptr, out);
+}
+
+int crbm_free_energy_codes(crbm_handle* h, const uint8_t* codes, int32_t n, int32_t L, float* fe, float* fe_per_motif) {
+  ENTER();
+  ARGCHK(codes && (fe || fe_per_motif), "null argument");
+  return free_energy_any(h, host_codes(codes, n, L), fe, fe_per_motif);
+}
+
+int crbm_free_energy_resident(crbm_handle* h, int32_t start, int32_t end, float* fe, float* fe_per_motif) {
+  ENTER();
+  ARGCHK(fe || fe_per_motif, "null argument");
+  RowSource src;
+  int rc = resident_source(h, start, end, &src);
+  if (rc) return rc;
+  return free_energy_any(h, src, fe, fe_per_motif);
+}
+
+int crbm_eval_data(crbm_handle* h, const float* v, int32_t n, int32_t L, float* mfe, float* nmh) {
+  ENTER();
+  ARGCHK(v && mfe && nmh, "null argument");
+  return eval_data_any(h, host_onehot(v, n, L), mfe, nmh);
+}
+
+int crbm_eval_data_resident(crbm_handle* h, int32_t start, int32_t end, float* mfe, float* nmh) {
+  ENTER();
+  ARGCHK(mfe && nmh, "null argument");
+  RowSource src;
+  int rc = resident_source(h, start, end, &src);
+  if (rc) return rc;
+  return eval_data_any(h, src, mfe, nmh);
+}
+
+int crbm_hit_summary(crbm_handle* h, const float* v, int32_t n, int32_t L, float* hit_max, float* hit_mean,
+                     float* position_mean) {
+  ENTER();
+  ARGCHK(v && (hit_max || hit_mean || position_mean), "null argument");
+  return hit_summary_any(h, host_onehot(v, n, L), hit_max, hit_mean, position_mean);
+}
+
+int crbm_hit_summary_codes(crbm_handle* h, const uint8_t* codes, int32_t n, int32_t L, float* hit_max, float* hit_mean,
+                           float* position_mean) {
+  ENTER();
+  ARGCHK(codes && (hit_max || hit_mean || position_mean), "null argument");
+  return hit_summary_any(h, host_codes(codes, n, L), hit_max, hit_mean, position_mean);
+}
+
+int crbm_hit_summary_resident(crbm_handle* h, int32_t start, int32_t end, float* hit_max, float* hit_mean,
+                              float* position_mean) {
+  ENTER();
+  ARGCHK(hit_max || hit_mean || position_mean, "null argument");
+  RowSource src;
+  int rc = resident_source(h, start, end, &src);
+  if (rc) return rc;
+  return hit_summary_any(h, src, hit_max, hit_mean, position_mean);
 }
 
 int crbm_eval_params(crbm_handle* h, float* twn, float* ic, float* medic) {

@@ -840,7 +840,15 @@ struct FeArgs {
   float* fem;
 };
 
-__device__ __forceinline__ float softplusf(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
+// softplus(x) = max(x,0) + log1p(exp(-|x|)) from z = -x*log2(e), on the hardware
+// exp2/log2: log1p by its series below 2^-5 (where 1+t would round t away), by
+// log2(1+t) above; relative error of either branch < 3e-7.
+__device__ __forceinline__ float softplus_of_z(float z) {
+  const float t = __builtin_amdgcn_exp2f(-fabsf(z));
+  const float series = t * (1.0f - t * (0.5f - t * (0.33333334f - 0.25f * t)));
+  const float vialog = 0.6931471805599453f * __builtin_amdgcn_logf(1.0f + t);
+  return fmaxf(x_of_z(z), 0.f) + (t < 0.03125f ? series : vialog);
+}
 
 template <class C>
 __device__ void free_energy_body(const FeArgs& a) {
@@ -864,11 +872,11 @@ __device__ void free_energy_body(const FeArgs& a) {
       float x[KP];
       conv_gather<C>(Tf, win, x);
 #pragma unroll
-      for (int q = 0; q < K; ++q) acc[q] += softplusf(x_of_z(x[q]));
+      for (int q = 0; q < K; ++q) acc[q] += softplus_of_z(x[q]);
       if (C::DS) {
         conv_gather<C>(Tr, win, x);
 #pragma unroll
-        for (int q = 0; q < K; ++q) acc[q] += softplusf(x_of_z(x[q]));
+        for (int q = 0; q < K; ++q) acc[q] += softplus_of_z(x[q]);
       }
     }
     float cs = 0.f;
@@ -885,6 +893,103 @@ __device__ void free_energy_body(const FeArgs& a) {
       if (lane == 0 && a.fem) a.fem[(size_t)nn * K + q] = -v - cs;
     }
     if (lane == 0 && a.fe) a.fe[nn] = (-tot - cs) / (float)a.L;
+  }
+}
+
+// ===========================================================================
+// Motif-hit summaries for data-set scale sweeps.  The reference's
+// analysis code only ever reduces motifHitProbs() (convRBM.py:507-514): the max
+// and the mean over positions per (sequence, motif) (utils.py:154, :242-244,
+// :305) and the mean over sequences per (motif, position) (utils.py:113-116).
+// This kernel produces those three reductions directly, so the dense
+// (n,K,1,Lh) tensor never exists.  One wave per sequence; a lane owns HIT_NI
+// positions (stride 64) of the chunk blockIdx.y of 64*HIT_NI positions and keeps
+// their sums over sequences in registers; chunks are combined with atomics.
+// ===========================================================================
+struct HitArgs {
+  const float* tables;
+  const uint32_t* letters;
+  int32_t n, L, Lh, LW;
+  float* hmax;      // (n,K) max over positions   (zero-initialised when gridDim.y > 1)
+  float* hsum;      // (n,K) sum over positions   (zero-initialised when gridDim.y > 1)
+  float* pos;       // (K,Lh) sum over sequences, accumulated atomically (zero-initialised), or null
+};
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_down(v, off, 64));
+  return v;
+}
+
+template <class C>
+__device__ void hit_summary_body(const HitArgs& a) {
+  constexpr int KP = C::KP, K = C::K, M = C::M, NI = C::HIT_NI, PC = 64 * NI;
+  constexpr bool BOTH = !C::DS;   // single-stranded models report sigma(x + x'), convRBM.py:511-514
+  HIP_DYNAMIC_SHARED(float, smem);
+  float* Tf = smem;
+  float* Tr = Tf + C::TAB;
+  float* acc = Tf + (BOTH ? 2 : 1) * C::TAB;   // [PC][K], block total of the waves' register sums
+  copy_tables<C::TAB>(Tf, a.tables + C::OFF_TF);
+  if (BOTH) copy_tables<C::TAB>(Tr, a.tables + C::OFF_TR);
+  const int s0 = blockIdx.y * PC;
+  if (a.pos)
+    for (int i = threadIdx.x; i < PC * K; i += blockDim.x) acc[i] = 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  float pacc[NI][K];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int q = 0; q < K; ++q) pacc[i][q] = 0.f;
+  for (int nn = blockIdx.x * nwaves + wave; nn < a.n; nn += gridDim.x * nwaves) {
+    const uint32_t* row = a.letters + (size_t)nn * a.LW;
+    float mx[K], sm[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q) { mx[q] = 0.f; sm[q] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int s = s0 + lane + 64 * i;
+      if (s < a.Lh) {
+        const uint64_t win = letter_window<M>(row, s);
+        float z[KP];
+        conv_gather<C>(Tf, win, z);
+        if (BOTH) conv_gather<C, true>(Tr, win, z);
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+          const float p = sigmoid_z(z[q]);
+          mx[q] = fmaxf(mx[q], p);
+          sm[q] += p;
+          pacc[i][q] += p;
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+      const float m = wave_max(mx[q]);
+      const float t = wave_sum(sm[q]);
+      if (lane == 0) {
+        const size_t idx = (size_t)nn * K + q;
+        if (gridDim.y == 1) {
+          if (a.hmax) a.hmax[idx] = m;
+          if (a.hsum) a.hsum[idx] = t;
+        } else {   // probabilities are >= 0: their bit patterns order like unsigned integers
+          if (a.hmax) atomicMax(reinterpret_cast<unsigned int*>(a.hmax) + idx, __float_as_uint(m));
+          if (a.hsum) atomicAdd(a.hsum + idx, t);
+        }
+      }
+    }
+  }
+  if (a.pos) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int q = 0; q < K; ++q) atomicAdd(&acc[(lane + 64 * i) * K + q], pacc[i][q]);
+    __syncthreads();
+    const int npos = min(PC, a.Lh - s0);
+    for (int i = threadIdx.x; i < npos * K; i += blockDim.x) {
+      const int sl = i / K, q = i - sl * K;
+      atomicAdd(a.pos + (size_t)q * a.Lh + s0 + sl, acc[i]);
+    }
   }
 }
 

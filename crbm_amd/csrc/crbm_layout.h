@@ -70,6 +70,8 @@ struct Cfg {
   static constexpr int STATS_UNR = (KP <= 16) ? CRBM_STATS_UNR : 2;   // parked rows in flight per lane
   static constexpr int OFF_TR = DS ? TAB : TABLES;
   static constexpr int TABLES_ALL = DS ? TABLES : TABLES + TAB;
+  // hit-summary kernel: a lane keeps the position sums of HIT_NI positions in registers
+  static constexpr int HIT_NI = (48 / KP) < 1 ? 1 : ((48 / KP) > 4 ? 4 : (48 / KP));
 };
 
 // Host-side mirror of Cfg (runtime values, same arithmetic).
@@ -77,6 +79,7 @@ struct ModelShape {
   int K, M, DS, G;
   int NQ, KP, NW, NG, ROWS, TAB, NCH, DENSE, TV, WT, NGRP;
   int OFF_TF, OFF_TR, OFF_TV, OFF_TVR, OFF_WT, OFF_C, TABLES, TABLES_ALL;
+  int HIT_NI;
 };
 inline ModelShape model_shape(int K, int M, int DS, int G) {
   ModelShape s;
@@ -91,6 +94,7 @@ inline ModelShape model_shape(int K, int M, int DS, int G) {
   s.OFF_TF = 0; s.OFF_TV = s.TAB * (1 + DS); s.OFF_TVR = s.OFF_TV + s.TV;
   s.OFF_WT = s.OFF_TV + s.TV * (1 + DS); s.OFF_C = s.OFF_WT + s.WT; s.TABLES = s.OFF_C + 4;
   s.OFF_TR = DS ? s.TAB : s.TABLES; s.TABLES_ALL = DS ? s.TABLES : s.TABLES + s.TAB;
+  s.HIT_NI = (48 / s.KP) < 1 ? 1 : ((48 / s.KP) > 4 ? 4 : (48 / s.KP));
   return s;
 }
 

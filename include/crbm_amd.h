@@ -114,6 +114,11 @@ int crbm_dataset_upload(crbm_handle* h, const float* data, int32_t n, int32_t L)
  * sequences.py:9-17), shape (n,L): 16x less host->device traffic than the
  * float one-hot array that sequences.py:101-117 builds. */
 int crbm_dataset_upload_codes(crbm_handle* h, const uint8_t* codes, int32_t n, int32_t L);
+/* A handle holds CRBM_DATASET_SLOTS resident data sets (fit() keeps the
+ * training set in slot 0 and the test set of convRBM.py:617-625 in slot 1);
+ * uploads and every *_resident call address the selected slot (default 0). */
+#define CRBM_DATASET_SLOTS 2
+int crbm_dataset_select(crbm_handle* h, int32_t slot);
 int crbm_train_step_resident(crbm_handle* h, int32_t start, int32_t end);
 /* The persistent chain alone (convRBM.py:397-408): k Gibbs steps on all
  * fantasy chains, parameters frozen.  Benchmark entry. */
@@ -149,6 +154,29 @@ int crbm_free_energy_per_motif(crbm_handle* h, const float* v, int32_t n, int32_
 int crbm_eval_data(crbm_handle* h, const float* v, int32_t n, int32_t L, float* mfe, float* nmh);
 /* theano_evaluateParams (:494-499) -> rms(W), IC, median IC */
 int crbm_eval_params(crbm_handle* h, float* twn, float* ic, float* medic);
+
+/* ---- data-set scale sweeps --------------------------------
+ * The same evaluations fed with one byte per base (`_codes`, (n,L), 0..3) or
+ * with rows [start,end) of the selected resident data set (`_resident`), so
+ * that the fp32 one-hot array of sequences.py:101-117 never has to exist.
+ * Output pointers of the free-energy calls may be NULL (at least one is set). */
+int crbm_hit_probs_codes(crbm_handle* h, const uint8_t* codes, int32_t n, int32_t L, float* out);
+int crbm_hit_probs_resident(crbm_handle* h, int32_t start, int32_t end, float* out);
+int crbm_free_energy_codes(crbm_handle* h, const uint8_t* codes, int32_t n, int32_t L, float* fe, float* fe_per_motif);
+int crbm_free_energy_resident(crbm_handle* h, int32_t start, int32_t end, float* fe, float* fe_per_motif);
+int crbm_eval_data_resident(crbm_handle* h, int32_t start, int32_t end, float* mfe, float* nmh);
+/* The three reductions of theano_getHitProbs' output that the reference's
+ * analysis code uses, without materialising (n,K,1,Lh):
+ *   hit_max  (n,K)  = P.max(axis=(2,3))    utils.py:154, :242-244
+ *   hit_mean (n,K)  = P.mean(axis=(2,3))   utils.py:305
+ *   position_mean (K,Lh) = P.mean(axis=(0,2))   utils.py:113-116
+ * Any of the three pointers may be NULL. */
+int crbm_hit_summary(crbm_handle* h, const float* v, int32_t n, int32_t L, float* hit_max, float* hit_mean,
+                     float* position_mean);
+int crbm_hit_summary_codes(crbm_handle* h, const uint8_t* codes, int32_t n, int32_t L, float* hit_max,
+                           float* hit_mean, float* position_mean);
+int crbm_hit_summary_resident(crbm_handle* h, int32_t start, int32_t end, float* hit_max, float* hit_mean,
+                              float* position_mean);
 
 /* ---- data-parallel (new: the reference is single-device) -----------------
  * One process per GPU.  Rank 0 calls crbm_comm_unique_id and distributes the

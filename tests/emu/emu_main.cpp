@@ -239,6 +239,17 @@ int emu_free_energy(int id, const float* tables, const uint32_t* letters, int n,
   return 0;
 }
 
+int emu_hit_summary(int id, const float* tables, const uint32_t* letters, int n, int L, float* hmax, float* hsum,
+                     float* pos, int grid, int threads) {
+  HitArgs a;
+  a.tables = tables; a.letters = letters; a.n = n; a.L = L; a.LW = letter_words(L);
+  a.hmax = hmax; a.hsum = hsum; a.pos = pos;
+  CFG_DISPATCH(id, (a.Lh = L - C::M + 1,
+                    emu::launch([&] { hit_summary_body<C>(a); }, dim3(grid, (a.Lh + 64 * C::HIT_NI - 1) / (64 * C::HIT_NI)),
+                                dim3(threads), (size_t)(C::DS ? 1 : 2) * C::TAB * 4 + (size_t)64 * C::HIT_NI * C::K * 4)));
+  return 0;
+}
+
 int emu_sums_layout(int K, int M, int* out) {
   const SumsLayout s = sums_layout(K, M);
   out[0] = s.data_off; out[1] = s.n_d; out[2] = s.model_off; out[3] = s.n_m; out[4] = s.count;

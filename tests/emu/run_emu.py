@@ -333,8 +333,28 @@ def test_free_energy():
         print("free energy ok", (K, M, ds))
 
 
+def test_hit_summary():
+    for cid in CASES:
+        info, o = oracle_for(cid)
+        K, M, ds = info["K"], info["M"], info["ds"]
+        tables = build_tables(cid, o)
+        for n, L in ((9, M + 149), (5, M + 299)):   # one or two chunks (plain stores / atomic combine) for KP <= 12
+            Lh = L - M + 1
+            d = synthetic_onehot(n, L, seed=K + 5)
+            letters, _ = encode(d)
+            P = o.motifHitProbs(d)
+            hmax = np.zeros((n, K), dtype=np.float32)
+            hsum = np.zeros((n, K), dtype=np.float32)
+            pos = np.zeros((K, Lh), dtype=np.float32)
+            lib.emu_hit_summary(cid, fp(tables), up(letters), n, L, fp(hmax), fp(hsum), fp(pos), 2, 128)
+            np.testing.assert_allclose(hmax, P.max(axis=(2, 3)), rtol=1e-5, atol=1e-7)
+            np.testing.assert_allclose(hsum / Lh, P.mean(axis=(2, 3)), rtol=1e-5, atol=1e-7)
+            np.testing.assert_allclose(pos / n, P.mean(axis=(0, 2)), rtol=1e-5, atol=1e-7)
+        print("hit summary ok", (K, M, ds))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["encode_pack", "hgv", "vgh", "gibbs", "train_step", "free_energy"]
+    which = sys.argv[1:] or ["encode_pack", "hgv", "vgh", "gibbs", "train_step", "free_energy", "hit_summary"]
     for w in which:
         globals()["test_" + w]()
     print("EMU ALL OK")

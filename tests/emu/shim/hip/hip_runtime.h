@@ -112,11 +112,30 @@ static inline uint32_t atomicOr(uint32_t* p, uint32_t v) { return __atomic_fetch
 static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) {
   return __atomic_fetch_add(p, v, __ATOMIC_RELAXED);
 }
+static inline float atomicAdd(float* p, float v) {   // CAS loop: the blocks of a grid run as concurrent OS threads
+  uint32_t* ip = reinterpret_cast<uint32_t*>(p);
+  uint32_t old = __atomic_load_n(ip, __ATOMIC_RELAXED), want;
+  float f;
+  do {
+    __builtin_memcpy(&f, &old, 4);
+    f += v;
+    __builtin_memcpy(&want, &f, 4);
+  } while (!__atomic_compare_exchange_n(ip, &old, want, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+  __builtin_memcpy(&f, &old, 4);
+  return f;
+}
+static inline unsigned int atomicMax(unsigned int* p, unsigned int v) {
+  unsigned int old = __atomic_load_n(p, __ATOMIC_RELAXED);
+  while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+  return old;
+}
+static inline unsigned int __float_as_uint(float f) { unsigned int u; __builtin_memcpy(&u, &f, 4); return u; }
 static inline int __ffs(uint32_t v) { return __builtin_ffs((int)v); }
 static inline uint32_t __umulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
 #define __expf(x) expf(x)
 static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
+static inline float __builtin_amdgcn_logf(float x) { return log2f(x); }
 static inline float __fdividef(float a, float b) { return a / b; }
 using std::max;
 using std::min;

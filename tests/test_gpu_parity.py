@@ -487,3 +487,95 @@ def test_edge_shapes(K, M, ds, L, n):
     np.testing.assert_allclose(model.motifs.get_value(), o.W, rtol=RTOL, atol=5e-6)
     np.testing.assert_allclose(model.bias.get_value(), o.b, rtol=RTOL, atol=5e-6)
     np.testing.assert_allclose(model.c.get_value(), o.c, rtol=RTOL, atol=5e-6)
+
+
+# ---- packed input and data-set scale sweeps ------------------------
+@pytest.mark.parametrize("ds", [False, True])
+def test_codes_input_equals_onehot(ds):
+    """(n,L) uint8 letter codes give bit-identical results to the fp32 one-hot array."""
+    from crbm_amd.sequences import codesToOneHot
+    rng = np.random.default_rng(31)
+    codes = rng.integers(0, 4, size=(37, 150), dtype=np.uint8)
+    data = codesToOneHot(codes)
+    m, o = make_pair(10, 15, ds=ds, bshift=4.0)
+    np.testing.assert_array_equal(m.motifHitProbs(codes), m.motifHitProbs(data))
+    np.testing.assert_array_equal(m.freeEnergy(codes), m.freeEnergy(data))
+    np.testing.assert_array_equal(m.freeEnergy(codes, True), m.freeEnergy(data, True))
+    np.testing.assert_allclose(m.freeEnergy(codes), o.freeEnergy(data), rtol=RTOL, atol=1e-6)
+    bad = codes.copy()
+    bad[5, 9] = 4
+    with pytest.raises(Exception, match="one-hot"):
+        m.freeEnergy(bad)
+
+
+@pytest.mark.parametrize("K,M,ds,L", [(10, 15, False, 200), (10, 15, True, 200), (20, 15, True, 1200), (3, 4, False, 50)])
+def test_hit_summary_matches_oracle(K, M, ds, L):
+    """utils.py:113-116, :154, :305 reductions of motifHitProbs, fused on the device
+    (L=1200 with K=20 needs several position chunks: the atomic combine path)."""
+    n = 45
+    data = synthetic_onehot(n, L, seed=41)
+    m, o = make_pair(K, M, ds=ds, bshift=4.0)
+    P = o.motifHitProbs(data)
+    got = m.motifHitSummary(data)
+    np.testing.assert_allclose(got["max"], P.max(axis=(2, 3)), rtol=RTOL, atol=1e-7)
+    np.testing.assert_allclose(got["mean"], P.mean(axis=(2, 3)), rtol=RTOL, atol=1e-7)
+    np.testing.assert_allclose(got["position_mean"], P.mean(axis=(0, 2)), rtol=RTOL, atol=1e-7)
+    dense = m.motifHitProbs(data)
+    np.testing.assert_allclose(got["max"], dense.max(axis=(2, 3)), rtol=1e-6)
+    only = m.motifHitSummary(data, position_mean=False)
+    np.testing.assert_array_equal(only["max"], got["max"])
+    assert "position_mean" not in only
+
+
+def test_resident_sweeps_and_slots(monkeypatch):
+    """Rows of a resident data set give the same numbers as host input; two slots coexist."""
+    import ctypes
+    from crbm_amd._lib import fptr
+    rng = np.random.default_rng(33)
+    ca = rng.integers(0, 4, size=(64, 90), dtype=np.uint8)
+    cb = rng.integers(0, 4, size=(40, 70), dtype=np.uint8)
+    monkeypatch.setenv("CRBM_SLAB_BYTES", str(32 * 1024))
+    m, _ = make_pair(10, 15, ds=True, bshift=4.0)
+    m._upload(ca, 0)
+    m._upload(cb, 1)
+    K = 10
+    for slot, c, lo, hi in ((0, ca, 5, 61), (1, cb, 0, 40)):
+        m._call("crbm_dataset_select", slot)
+        n, Lh = hi - lo, c.shape[1] - 15 + 1
+        fe = np.empty(n, np.float32); fem = np.empty((n, K), np.float32)
+        m._call("crbm_free_energy_resident", lo, hi, fptr(fe), fptr(fem))
+        np.testing.assert_array_equal(fe, m.freeEnergy(c[lo:hi]))
+        np.testing.assert_array_equal(fem, m.freeEnergy(c[lo:hi], True))
+        hp = np.empty((n, K, 1, Lh), np.float32)
+        m._call("crbm_hit_probs_resident", lo, hi, fptr(hp))
+        np.testing.assert_array_equal(hp, m.motifHitProbs(c[lo:hi]))
+        mx = np.empty((n, K), np.float32); mean = np.empty((n, K), np.float32); pos = np.empty((K, Lh), np.float32)
+        m._call("crbm_hit_summary_resident", lo, hi, fptr(mx), fptr(mean), fptr(pos))
+        s = m.motifHitSummary(c[lo:hi])
+        np.testing.assert_array_equal(mx, s["max"])
+        np.testing.assert_allclose(pos, s["position_mean"], rtol=1e-5)
+    with pytest.raises(Exception, match="slot"):
+        m._call("crbm_dataset_select", 2)
+    m._call("crbm_dataset_select", 0)
+    with pytest.raises(Exception, match="out of bounds"):
+        m._call("crbm_free_energy_resident", 0, 65, fptr(np.empty(65, np.float32)), None)
+
+
+def test_fit_with_codes_and_test_set(capsys):
+    """fit() on letter codes == fit() on the one-hot array, with a separate test set."""
+    from crbm_amd.sequences import codesToOneHot
+    rng = np.random.default_rng(35)
+    train = rng.integers(0, 4, size=(50, 60), dtype=np.uint8)
+    test = rng.integers(0, 4, size=(30, 60), dtype=np.uint8)
+    a, _ = make_pair(6, 9, ds=True, batchsize=20, cd_k=2, bshift=4.0, epochs=2)
+    b, _ = make_pair(6, 9, ds=True, batchsize=20, cd_k=2, bshift=4.0, epochs=2)
+    a.fit(train, test)
+    out_a = capsys.readouterr().out
+    b.fit(codesToOneHot(train), codesToOneHot(test))
+    out_b = capsys.readouterr().out
+    np.testing.assert_array_equal(a.motifs.get_value(), b.motifs.get_value())
+    status = lambda s: [l for l in s.splitlines() if l.startswith("Epoch")]
+    assert status(out_a) == status(out_b) and len(status(out_a)) == 2
+    # the status line is the batch mean of _evaluateData over the test set (convRBM.py:617-625)
+    fe = np.mean([a._evaluateData(codesToOneHot(test[lo:hi]))[0] for lo, hi in a._iterateBatchIndices(30, 20)])
+    assert "FE={:1.3f}".format(fe) in status(out_a)[-1]

@@ -111,3 +111,57 @@ def test_sequence_helpers():
         seqsToCodes(["ACGN"])
     with pytest.raises(Exception):
         seqsToCodes(["ACG", "AC"])
+
+
+# ---- sequences.py / utils.py counterparts ---------------------------
+def test_fasta_reader_and_split(tmp_path, capsys):
+    from crbm_amd import sequences as sq
+    fa = tmp_path / "toy.fa"
+    fa.write_text(">s1 first\nACGT\nacgt\n\n>s2\nACGTNCGT\n>s3 third one\nTTTTCCCC\n>s4\nGGGGAAAA\n")
+    recs = sq.readSeqsFromFasta(str(fa))
+    assert "skip sequence containing N" in capsys.readouterr().out          # sequences.py:47-50
+    assert [r.id for r in recs] == ["s1", "s3", "s4"] and recs[0].seq == "ACGTacgt"
+    assert recs[1].description == "s3 third one"
+    codes = sq.fastaToCodes(str(fa))
+    assert codes.dtype == np.uint8 and codes.shape == (3, 8)
+    np.testing.assert_array_equal(codes[0], [0, 1, 2, 3, 0, 1, 2, 3])
+    onehot = sq.seqToOneHot(recs)
+    assert onehot.shape == (3, 1, 4, 8) and onehot.dtype == np.float32
+    np.testing.assert_array_equal(onehot, sq.codesToOneHot(codes))
+    np.testing.assert_array_equal(onehot.sum(axis=2), 1.0)
+    sq.splitTrainingTest(str(fa), 0.34, randomize=False)                  # sequences.py:54-98
+    tr = sq.readSeqsFromFasta(str(tmp_path / "toy_train.fa"))
+    te = sq.readSeqsFromFasta(str(tmp_path / "toy_test.fa"))
+    assert [r.id for r in te] == ["s1"] and [r.id for r in tr] == ["s3", "s4"]
+    sq.splitTrainingTest(str(fa), 0.5, num_top_regions=2, randomize=True)
+    assert len(sq.readSeqsFromFasta(str(tmp_path / "toy_train.fa"))) == 1
+    with pytest.raises(Exception, match="same length"):
+        sq.seqsToCodes(["ACGT", "ACG"])
+    with pytest.raises(Exception, match="load_sample"):
+        sq.load_sample(str(tmp_path / "missing.fa"))
+    assert sq.load_sample(str(fa)).shape == (3, 1, 4, 8)
+
+
+def test_save_motifs_formats(tmp_path):
+    from crbm_amd.utils import saveMotifs, formatMotif
+
+    class Fake(object):
+        def getPFMs(self):
+            return [np.array([[0.7, 0.1], [0.1, 0.2], [0.1, 0.3], [0.1, 0.4]]), np.full((4, 2), 0.25)]
+
+    saveMotifs(Fake(), str(tmp_path / "out"), name="m")                    # utils.py:16-47
+    txt = (tmp_path / "out" / "m0.pfm").read_text().splitlines()
+    assert txt[0] == ">m1 m1"
+    assert txt[1] == "A [  0.70   0.10]" and txt[4] == "T [  0.10   0.40]"
+    assert (tmp_path / "out" / "m1.pfm").exists()
+    assert formatMotif(np.full((4, 2), 0.25), "x", "pfm").splitlines()[0] == "  0.25   0.25"
+    assert formatMotif(np.full((4, 2), 0.25), "x", "tab").splitlines()[2] == "G\t0.25\t0.25"
+    with pytest.raises(ValueError):
+        formatMotif(np.full((4, 2), 0.25), "x", "meme")
+
+
+def test_codes_detection():
+    from crbm_amd import CRBM
+    assert CRBM._is_codes(np.zeros((3, 9), np.uint8))
+    assert not CRBM._is_codes(np.zeros((3, 1, 4, 9), np.float32))
+    assert not CRBM._is_codes(np.zeros((3, 9), np.float32))
