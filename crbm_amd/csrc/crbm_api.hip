@@ -100,7 +100,7 @@ struct crbm_handle {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;          // model phase of a training step runs beside the data phase
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
-  bool overlap = true;
+  bool overlap = false;
   ModelShape ms;
   JitKernels jk;            // kernels specialised for this model (hiprtc)
   float* d_tables = nullptr;   // precomputed LDS images (gather / top-down tables, c)
@@ -289,7 +289,7 @@ int launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool d
   const int per_cu = std::max(1, std::min(8, (160 * 1024) / std::max(1, st.lds_bytes)));
   const int cap = h->stats_rows > 0 ? h->stats_rows : h->num_cu * per_cu;
   const int gx = std::max(1, std::min(ntiles, cap));
-  const int rows = gx * st.parts;
+  const int rows = gx;   // one partial row per block
   HIPCHK(pbuf.ensure((size_t)rows * st.row));
   a.partials = pbuf.p;
   a.debug = env_int("CRBM_STATS_DEBUG", 0);
@@ -298,7 +298,7 @@ int launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool d
   ReduceArgs r;
   r.partials = pbuf.p;
   r.nrows = rows; r.row = st.row;
-  r.parts = st.parts; r.K = h->K; r.KAM = h->KAM; r.ds = h->ds; r.want_sparsity = want_sp;
+  r.K = h->K; r.KAM = h->KAM; r.ds = h->ds; r.want_sparsity = want_sp;
   if (data_half) {
     r.sums = h->d_sums + h->sl.data_off;
     r.skip_begin = st.row; r.skip_len = 0;
@@ -307,7 +307,7 @@ int launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool d
     r.skip_begin = h->sl.model_skip_begin; r.skip_len = h->sl.model_skip_len;
   }
   r.n_value = (float)n;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((st.row + 15) / 16), dim3(1024), 0, s, r);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((st.row + 31) / 32), dim3(1024), 0, s, r);
   HIPCHK(hipGetLastError());
   return CRBM_OK;
 }
@@ -327,8 +327,10 @@ int launch_update(crbm_handle* h, int L_data) {
 }
 
 // data statistics + k Gibbs steps + model statistics -> d_sums (local).  The two
-// halves are independent given (W,b,c): the model half (chain + its statistics)
-// runs on a second stream beside the data half and is joined before the update.
+// halves are independent given (W,b,c): with CRBM_OVERLAP=1 the model half (chain
+// + its statistics) runs on a second stream beside the data half and is joined
+// before the update (off by default: each kernel fills the chip on its own and the
+// cross-stream events cost ~10 us per step).
 int train_local_dev(crbm_handle* h, const uint32_t* d_letters, int n, int L) {
   int rc = ensure_tables(h);
   if (rc) return rc;
@@ -532,7 +534,7 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
   TRY(hipEventCreate(&hh->ev1));
   TRY(hipEventCreateWithFlags(&hh->ev_fork, hipEventDisableTiming));
   TRY(hipEventCreateWithFlags(&hh->ev_join, hipEventDisableTiming));
-  hh->overlap = env_int("CRBM_OVERLAP", 1) != 0;
+  hh->overlap = env_int("CRBM_OVERLAP", 0) != 0;   // measured: no gain once the statistics kernel fills the chip
   const size_t kam = (size_t)hh->KAM, k = (size_t)hh->K;
   TRY(hipMalloc((void**)&hh->dW, kam * 4)); TRY(hipMalloc((void**)&hh->dvW, kam * 4));
   TRY(hipMalloc((void**)&hh->db, k * 4));   TRY(hipMalloc((void**)&hh->dvb, k * 4));

@@ -104,10 +104,34 @@ __device__ __forceinline__ float class_sum(float v) {
   return v;
 }
 
+// Wave-wide reductions on the VALU (DPP): four row rotations give every lane its
+// 16-lane row total, row_bcast15 / row_bcast31 fold the four rows into lane 63,
+// one v_readlane hands the result to all lanes.  (The LDS-crossbar shuffles are
+// an order of magnitude slower when dozens of values are reduced back to back.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_move(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;
+  v += dpp_move<0x121, 0xf>(v);   // row_ror:1
+  v += dpp_move<0x122, 0xf>(v);   // row_ror:2
+  v += dpp_move<0x124, 0xf>(v);   // row_ror:4
+  v += dpp_move<0x128, 0xf>(v);   // row_ror:8
+  v += dpp_move<0x142, 0xa>(v);   // row_bcast15 into rows 1 and 3
+  v += dpp_move<0x143, 0xc>(v);   // row_bcast31 into rows 2 and 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// maximum of non-negative values (rows a DPP move does not reach contribute 0)
+__device__ __forceinline__ float wave_max_nonneg(float v) {
+  v = fmaxf(v, dpp_move<0x121, 0xf>(v));
+  v = fmaxf(v, dpp_move<0x122, 0xf>(v));
+  v = fmaxf(v, dpp_move<0x124, 0xf>(v));
+  v = fmaxf(v, dpp_move<0x128, 0xf>(v));
+  v = fmaxf(v, dpp_move<0x142, 0xa>(v));
+  v = fmaxf(v, dpp_move<0x143, 0xc>(v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // ---------------------------------------------------------------------------
@@ -565,7 +589,10 @@ __device__ void gibbs_body(const GibbsArgs& a) {
 //     K registers: the lane that owns (a, j) accumulates VH[:, a, j] directly,
 //     the 16 rows read by a group are consecutive (no LDS bank conflicts) and
 //     no cross-lane reduction is ever needed.
-// Every (block, wave) writes its own partial row: fixed summation order.
+// At the end the waves of a block are combined through LDS in a fixed order and
+// the block writes one partial row.  Small models (Cfg::STATS_MERGE) fold the
+// sparsity statistic into the forward pass: it also accumulates sum P^2 and
+// sw = sum P - sum P^2.
 // ---------------------------------------------------------------------------
 struct StatsArgs {
   const float* tables;
@@ -581,7 +608,7 @@ struct StatsArgs {
   int32_t want_sparsity;
   FastDiv divLS, divLvis, divL;   // / LS, / (LS+M-1), / L
   int32_t row, off_vh0, off_vh1, off_h0, off_h1, off_sw, off_sb, off_v;
-  float* partials;      // [gridDim.x * parts][row]; columns nobody writes are never read (reduce_partials_kernel)
+  float* partials;      // [gridDim.x][row]; columns nobody writes are never read (reduce_partials_kernel)
   int32_t debug;        // profiling only: bit 0 skips phase B, bit 1 skips the phase-A arithmetic
 };
 
@@ -604,9 +631,12 @@ __device__ void stats_body(const StatsArgs& a) {
   float* xch = reinterpret_cast<float*>(lists + (size_t)nwaves * 4 * CH);   // [nwaves][3*KP+4]
   uint32_t* lw = reinterpret_cast<uint32_t*>(xch + (size_t)nwaves * (3 * KP + 4));   // [S][LWt] letters of the tile
 
-  copy_tables<C::TAB>(Tf, a.tables + C::OFF_TF);
-  if (C::DS) copy_tables<C::TAB>(Tr, a.tables + C::OFF_TR);
+  if (!(a.debug & 16)) {
+    copy_tables<C::TAB>(Tf, a.tables + C::OFF_TF);
+    if (C::DS) copy_tables<C::TAB>(Tr, a.tables + C::OFF_TR);
+  }
   // pad rows stay zero for the whole kernel
+  if (!(a.debug & 32))
   for (int i = threadIdx.x; i < nrows * KP; i += nthr) {
     Pb0[i] = 0.f;
     if (C::DS) Pb1[i] = 0.f;
@@ -617,14 +647,21 @@ __device__ void stats_body(const StatsArgs& a) {
   const int pass = blockIdx.y * a.PB + (wave % a.PB);
   const int part = wave / a.PB;
   const bool active = pass < a.npasses;
-  // passes: 0 = vh (forward strand), 1 = vh' (ds only), last = sw (forward, P(1-P))
-  const int t_kind = (active && a.want_sparsity && pass == C::DS + 1) ? 1 : 0;
+  // passes: 0 = vh (forward strand; with sum P^2 when merged), 1 = vh' (ds only),
+  // last = sw (forward, P(1-P)) when not merged
+  constexpr bool MERGE = C::STATS_MERGE;
+  const int t_kind = (!MERGE && active && a.want_sparsity && pass == C::DS + 1) ? 1 : 0;
   const int t_strand = (active && !t_kind && pass == 1) ? 1 : 0;
+  const bool with_sq = MERGE && active && a.want_sparsity && pass == 0;
   float acc[JCH][KP];
+  float sq[MERGE ? JCH : 1][MERGE ? KP : 1];
 #pragma unroll
   for (int c = 0; c < JCH; ++c)
 #pragma unroll
-    for (int q = 0; q < KP; ++q) acc[c][q] = 0.f;
+    for (int q = 0; q < KP; ++q) {
+      acc[c][q] = 0.f;
+      if (MERGE) sq[c][q] = 0.f;
+    }
 
   const bool owner = blockIdx.y == 0;   // h / sb / letter counts are accumulated once
   float hs0[KP], hs1[KP], sb[KP];
@@ -635,6 +672,29 @@ __device__ void stats_body(const StatsArgs& a) {
   const int grp = lane >> 4, lj = lane & 15;           // letter class of this lane group, its filter column
   const int ngroups = (a.n + a.S - 1) / a.S;
   const int ntiles = ngroups * a.nseg;
+  // software prefetch of a tile's letter words (global memory latency is otherwise
+  // exposed once per tile: a block has nothing else to do until they arrive)
+  constexpr int PRE = 4;
+  uint32_t pre[PRE];
+  auto fetch_letters = [&](int tile) {
+#pragma unroll
+    for (int u = 0; u < PRE; ++u) pre[u] = 0u;
+    if (tile < ntiles) {
+      const int cg = tile / a.nseg, seg = tile - cg * a.nseg;
+      const int n0 = cg * a.S;
+      const int ns = min(a.S, a.n - n0);
+      const int w0 = (seg * a.LS) >> 4;
+#pragma unroll
+      for (int u = 0; u < PRE; ++u) {
+        const int i = threadIdx.x + u * nthr;
+        if (i < ns * a.LWt) {
+          const int nl = i / a.LWt, w = i - nl * a.LWt;
+          if (w0 + w < a.LW) pre[u] = a.letters[(size_t)(n0 + nl) * a.LW + w0 + w];
+        }
+      }
+    }
+  };
+  fetch_letters(blockIdx.x);
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int cg = tile / a.nseg, seg = tile - cg * a.nseg;
     const int n0 = cg * a.S;
@@ -645,12 +705,19 @@ __device__ void stats_body(const StatsArgs& a) {
     const int w0 = s0 >> 4;                        // first letter word of the segment's window
     const int pofs = s0 - 16 * w0;                 // position of s0 inside the staged window
     __syncthreads();                               // previous tile fully consumed / tables + zero rows ready
-    // letters of the tile -> LDS (every later letter access is an LDS read)
-    for (int i = threadIdx.x; i < ns * a.LWt; i += nthr) {
+    // letters of the tile -> LDS (every later letter access is an LDS read); the first
+    // PRE words per thread were fetched while the previous tile was being processed
+#pragma unroll
+    for (int u = 0; u < PRE; ++u) {
+      const int i = threadIdx.x + u * nthr;
+      if (i < ns * a.LWt) lw[i] = pre[u];
+    }
+    for (int i = threadIdx.x + PRE * nthr; i < ns * a.LWt; i += nthr) {
       const int nl = i / a.LWt, w = i - nl * a.LWt;
       lw[i] = (w0 + w < a.LW) ? a.letters[(size_t)(n0 + nl) * a.LW + w0 + w] : 0u;
     }
     __syncthreads();
+    fetch_letters(tile + gridDim.x);               // in flight during phases A and B
     // ---- phase A: park P rows (zero beyond the segment / beyond the last chain) ----
     for (uint32_t i = threadIdx.x; i < (uint32_t)(a.S * a.LS); i += nthr) {
       const uint32_t nl = fastdiv(i, a.divLS);
@@ -746,7 +813,8 @@ __device__ void stats_body(const StatsArgs& a) {
         // order, so no workgroup barrier is needed between filling and reading them
         __builtin_amdgcn_wave_barrier();
         auto consume = [&](auto KIND) {
-          constexpr bool SPARSITY = decltype(KIND)::value != 0;
+          constexpr bool SPARSITY = decltype(KIND)::value == 1;   // P(1-P) only
+          constexpr bool SQUARES = decltype(KIND)::value == 2;    // P and P^2
           for (int e = 0; e < padded; e += UNR) {
             int r[UNR];
 #pragma unroll
@@ -771,34 +839,65 @@ __device__ void stats_body(const StatsArgs& a) {
                       v.x = v.x * (1.f - v.x); v.y = v.y * (1.f - v.y); v.z = v.z * (1.f - v.z); v.w = v.w * (1.f - v.w);
                     }
                     acc[c][4 * q] += v.x; acc[c][4 * q + 1] += v.y; acc[c][4 * q + 2] += v.z; acc[c][4 * q + 3] += v.w;
+                    if (SQUARES) {
+                      constexpr int cc = MERGE ? 1 : 0;   // sq is a dummy [1][1] when not merged
+                      sq[c * cc][(4 * q) * cc] = fmaf(v.x, v.x, sq[c * cc][(4 * q) * cc]);
+                      sq[c * cc][(4 * q + 1) * cc] = fmaf(v.y, v.y, sq[c * cc][(4 * q + 1) * cc]);
+                      sq[c * cc][(4 * q + 2) * cc] = fmaf(v.z, v.z, sq[c * cc][(4 * q + 2) * cc]);
+                      sq[c * cc][(4 * q + 3) * cc] = fmaf(v.w, v.w, sq[c * cc][(4 * q + 3) * cc]);
+                    }
                   }
               }
             }
           }
         };
-        if (t_kind) consume(IC<1>{}); else consume(IC<0>{});
+        if (t_kind) consume(IC<1>{});
+        else if (MERGE && with_sq) consume(IC<2>{});
+        else consume(IC<0>{});
         __builtin_amdgcn_wave_barrier();   // lists are rewritten by the next chunk
       }
     }
   }
 
-  // lane (grp, lj) holds the sums for letter a = grp and filter columns j = 16c + lj
-  float* out = a.partials + ((size_t)blockIdx.x * a.parts + part) * a.row;
-  if (active && !(a.debug & 4)) {
-    const int off = t_kind ? a.off_sw : (t_strand ? a.off_vh1 : a.off_vh0);
+  // lane (grp, lj) holds the sums for letter a = grp and filter columns j = 16c + lj.
+  // Combine the waves of the block through LDS (tables and parked rows are dead
+  // now), part by part in a fixed order: buf[0] = vh, buf[1] = vh', buf[2] = sw or sum P^2.
+  constexpr int KAM = K * 4 * M;
+  float* out = a.partials + (size_t)blockIdx.x * a.row;
+  __syncthreads();
+  if (!(a.debug & 4)) {
+    float* buf = smem;
+    for (int p = 0; p < a.parts; ++p) {
+      if (active && part == p) {
+        float* dst = buf + (t_kind ? 2 : t_strand) * KAM;
 #pragma unroll
-    for (int c = 0; c < JCH; ++c) {
-      const int j = 16 * c + lj;
-      if (j < M) {
+        for (int c = 0; c < JCH; ++c) {
+          const int j = 16 * c + lj;
+          if (j < M) {
 #pragma unroll
-        for (int q = 0; q < K; ++q) out[off + (q * 4 + grp) * M + j] = acc[c][q];
+            for (int q = 0; q < K; ++q) {
+              const int idx = (q * 4 + grp) * M + j;
+              dst[idx] = p == 0 ? acc[c][q] : dst[idx] + acc[c][q];
+              if (MERGE) {
+                if (with_sq) buf[2 * KAM + idx] = p == 0 ? sq[c][q] : buf[2 * KAM + idx] + sq[c][q];
+              }
+            }
+          }
+        }
       }
+      __syncthreads();
     }
+    for (int i = threadIdx.x; i < KAM; i += nthr) {
+      out[a.off_vh0 + i] = buf[i];
+      if (C::DS) out[a.off_vh1 + i] = buf[KAM + i];
+      if (a.want_sparsity) out[a.off_sw + i] = MERGE ? buf[i] - buf[2 * KAM + i] : buf[2 * KAM + i];
+    }
+    __syncthreads();   // xch (below) lives in the same LDS
   }
   if (owner && !(a.debug & 8)) {
     // per-thread sums -> wave (shuffles) -> block (one LDS exchange), fixed order;
-    // stored in part 0's row by one thread per value
-    float* out0 = a.partials + (size_t)blockIdx.x * a.parts * a.row;
+    // stored by one thread per value
+    float* out0 = out;
     constexpr int NV = 3 * KP + 4;
 #pragma unroll
     for (int q = 0; q < KP; ++q) {
@@ -915,12 +1014,6 @@ struct HitArgs {
   float* pos;       // (K,Lh) sum over sequences, accumulated atomically (zero-initialised), or null
 };
 
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_down(v, off, 64));
-  return v;
-}
-
 template <class C>
 __device__ void hit_summary_body(const HitArgs& a) {
   constexpr int KP = C::KP, K = C::K, M = C::M, NI = C::HIT_NI, PC = 64 * NI;
@@ -965,7 +1058,7 @@ __device__ void hit_summary_body(const HitArgs& a) {
     }
 #pragma unroll
     for (int q = 0; q < K; ++q) {
-      const float m = wave_max(mx[q]);
+      const float m = wave_max_nonneg(mx[q]);
       const float t = wave_sum(sm[q]);
       if (lane == 0) {
         const size_t idx = (size_t)nn * K + q;
@@ -1203,40 +1296,45 @@ __global__ void __launch_bounds__(256) vgh_dense_kernel(VghArgs a) {
 }
 
 // sums[dst(r)] = sum over partial rows of column r in a fixed order.  Block =
-// 16 columns x 64 row groups: each thread adds the rows of its group (64-byte
-// segments per row), the 64 groups are combined through LDS.  The partial
-// buffer is never cleared: the kernel knows which columns a statistics launch
-// wrote (pass columns: every row; h/sb/v: the first row of each block only)
-// and yields 0 for the classes that launch did not compute.
+// 32 columns x 32 row groups: each thread adds the rows of its group (128-byte
+// segments per row), the 32 groups are combined through LDS.  The partial
+// buffer is never cleared: the kernel knows which column classes a statistics
+// launch wrote and yields 0 for the classes that launch did not compute.
 struct ReduceArgs {
   const float* partials;
   float* sums;
   int32_t nrows, row;
-  int32_t parts;                  // rows per block of the statistics launch
   int32_t K, KAM, ds, want_sparsity;
   int32_t skip_begin, skip_len;   // columns [skip_begin, skip_begin+skip_len) are dropped
   float n_value;                  // written after the last kept column
 };
 
 __global__ void __launch_bounds__(1024) reduce_partials_kernel(ReduceArgs a) {
-  __shared__ float part[64][16];
-  const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
-  const int r = blockIdx.x * 16 + col;
+  __shared__ float part[32][33];
+  const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int r = blockIdx.x * 32 + col;
   float t = 0.f;
   if (r < a.row) {
     // column classes of a partial row: [vh KAM][vh' KAM][h K][h' K][sw KAM][sb K][v 4]
     const int K = a.K, KAM = a.KAM;
-    bool valid, owner;
-    if (r < KAM) { valid = true; owner = false; }
-    else if (r < 2 * KAM) { valid = a.ds != 0; owner = false; }
-    else if (r < 2 * KAM + K) { valid = true; owner = true; }
-    else if (r < 2 * KAM + 2 * K) { valid = a.ds != 0; owner = true; }
-    else if (r < 3 * KAM + 2 * K) { valid = a.want_sparsity != 0; owner = false; }
-    else if (r < 3 * KAM + 3 * K) { valid = a.want_sparsity != 0; owner = true; }
-    else { valid = true; owner = true; }
+    bool valid;
+    if (r < KAM) valid = true;
+    else if (r < 2 * KAM) valid = a.ds != 0;
+    else if (r < 2 * KAM + K) valid = true;
+    else if (r < 2 * KAM + 2 * K) valid = a.ds != 0;
+    else if (r < 3 * KAM + 3 * K) valid = a.want_sparsity != 0;
+    else valid = true;
     if (valid) {
-      const int step = owner ? a.parts : 1;     // h/sb/v live in the first row of each block
-      for (int i = grp * step; i < a.nrows; i += 64 * step) t += a.partials[(size_t)i * a.row + r];
+      float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;   // four rows in flight; fixed order
+      int i = grp;
+      for (; i + 96 < a.nrows; i += 128) {
+        t0 += a.partials[(size_t)i * a.row + r];
+        t1 += a.partials[(size_t)(i + 32) * a.row + r];
+        t2 += a.partials[(size_t)(i + 64) * a.row + r];
+        t3 += a.partials[(size_t)(i + 96) * a.row + r];
+      }
+      for (; i < a.nrows; i += 32) t0 += a.partials[(size_t)i * a.row + r];
+      t = (t0 + t1) + (t2 + t3);
     }
   }
   part[grp][col] = t;
@@ -1245,7 +1343,7 @@ __global__ void __launch_bounds__(1024) reduce_partials_kernel(ReduceArgs a) {
     const bool skipped = r >= a.skip_begin && r < a.skip_begin + a.skip_len;
     if (!skipped) {
       float s = 0.f;
-      for (int g = 0; g < 64; ++g) s += part[g][col];
+      for (int g = 0; g < 32; ++g) s += part[g][col];
       a.sums[r < a.skip_begin ? r : r - a.skip_len] = s;
     }
   }

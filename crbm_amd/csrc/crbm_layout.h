@@ -68,6 +68,10 @@ struct Cfg {
 #define CRBM_STATS_UNR 4
 #endif
   static constexpr int STATS_UNR = (KP <= 16) ? CRBM_STATS_UNR : 2;   // parked rows in flight per lane
+  // small models: the forward vh pass also accumulates sum P^2 (sw = vh - that), so the
+  // sparsity statistic costs no second walk over the parked rows; large models keep a
+  // separate pass (the second accumulator set would not fit the register file)
+  static constexpr bool STATS_MERGE = KP * cdiv(M, 16) <= 32;
   static constexpr int OFF_TR = DS ? TAB : TABLES;
   static constexpr int TABLES_ALL = DS ? TABLES : TABLES + TAB;
   // hit-summary kernel: a lane keeps the position sums of HIT_NI positions in registers
@@ -79,7 +83,7 @@ struct ModelShape {
   int K, M, DS, G;
   int NQ, KP, NW, NG, ROWS, TAB, NCH, DENSE, TV, WT, NGRP;
   int OFF_TF, OFF_TR, OFF_TV, OFF_TVR, OFF_WT, OFF_C, TABLES, TABLES_ALL;
-  int HIT_NI;
+  int HIT_NI, STATS_MERGE;
 };
 inline ModelShape model_shape(int K, int M, int DS, int G) {
   ModelShape s;
@@ -95,6 +99,7 @@ inline ModelShape model_shape(int K, int M, int DS, int G) {
   s.OFF_WT = s.OFF_TV + s.TV * (1 + DS); s.OFF_C = s.OFF_WT + s.WT; s.TABLES = s.OFF_C + 4;
   s.OFF_TR = DS ? s.TAB : s.TABLES; s.TABLES_ALL = DS ? s.TABLES : s.TABLES + s.TAB;
   s.HIT_NI = (48 / s.KP) < 1 ? 1 : ((48 / s.KP) > 4 ? 4 : (48 / s.KP));
+  s.STATS_MERGE = s.KP * cdiv(M, 16) <= 32;
   return s;
 }
 
@@ -143,7 +148,7 @@ struct StatsLayout {
 inline StatsLayout stats_layout(const ModelShape& ms, int want_sparsity, int Lh, int n, int lds_budget) {
   StatsLayout s;
   const int K = ms.K, M = ms.M, KAM = K * 4 * M;
-  s.npasses = 1 + ms.DS + want_sparsity;
+  s.npasses = 1 + ms.DS + (ms.STATS_MERGE ? 0 : want_sparsity);
   const int waves = 4;
   s.threads = 64 * waves;
   s.PB = s.npasses <= 1 ? 1 : (s.npasses == 2 ? 2 : 4);
@@ -182,6 +187,7 @@ inline StatsLayout stats_layout(const ModelShape& ms, int want_sparsity, int Lh,
   s.off_v = 3 * KAM + 3 * K;
   s.row = 3 * KAM + 3 * K + 4;
   s.lds_bytes = (int)(fixed + (long)s.S * s.Rrow * per_row);
+  if (s.lds_bytes < 3 * KAM * 4) s.lds_bytes = 3 * KAM * 4;   // the block's waves are combined through LDS at the end
   return s;
 }
 

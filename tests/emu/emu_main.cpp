@@ -181,7 +181,7 @@ int emu_stats(int id, const float* tables, const uint32_t* letters, int n, int L
     a.off_sw = st.off_sw; a.off_sb = st.off_sb; a.off_v = st.off_v;
     const int ntiles = ((n + st.S - 1) / st.S) * st.nseg;
     if (gx > ntiles) gx = ntiles;
-    const int rows = gx * st.parts;
+    const int rows = gx;
     if ((long)rows * st.row > partials_cap) return -2;
     for (size_t i = 0; i < (size_t)rows * st.row; ++i) partials[i] = 1e30f;   // never cleared on the GPU either
     emu::launch([&] { stats_body<C>(a); }, dim3(gx, st.grid_y), dim3(st.threads), (size_t)st.lds_bytes);
@@ -192,17 +192,16 @@ int emu_stats(int id, const float* tables, const uint32_t* letters, int n, int L
     const int KAM = C::K * 4 * C::M, K = C::K;
     for (int r = 0; r < st.row; ++r) {
       if (r >= sb && r < sb + sl) continue;
-      bool valid, owner;
-      if (r < KAM) { valid = true; owner = false; }
-      else if (r < 2 * KAM) { valid = C::DS != 0; owner = false; }
-      else if (r < 2 * KAM + K) { valid = true; owner = true; }
-      else if (r < 2 * KAM + 2 * K) { valid = C::DS != 0; owner = true; }
-      else if (r < 3 * KAM + 2 * K) { valid = want_sparsity != 0; owner = false; }
-      else if (r < 3 * KAM + 3 * K) { valid = want_sparsity != 0; owner = true; }
-      else { valid = true; owner = true; }
+      bool valid;
+      if (r < KAM) valid = true;
+      else if (r < 2 * KAM) valid = C::DS != 0;
+      else if (r < 2 * KAM + K) valid = true;
+      else if (r < 2 * KAM + 2 * K) valid = C::DS != 0;
+      else if (r < 3 * KAM + 3 * K) valid = want_sparsity != 0;
+      else valid = true;
       float t = 0.f;
       if (valid)
-        for (int i = 0; i < rows; i += owner ? st.parts : 1) t += partials[(size_t)i * st.row + r];
+        for (int i = 0; i < rows; ++i) t += partials[(size_t)i * st.row + r];
       sums[r < sb ? r : r - sl] = t;
     }
     sums[st.row - sl] = (float)n;
@@ -211,11 +210,11 @@ int emu_stats(int id, const float* tables, const uint32_t* letters, int n, int L
   return row;
 }
 
-int emu_reduce(const float* partials, float* sums, int nrows, int row, int parts, int K, int KAM, int ds, int want,
+int emu_reduce(const float* partials, float* sums, int nrows, int row, int K, int KAM, int ds, int want,
                int skip_begin, int skip_len, float n_value) {
   // a synthetic layout: K = 1, KAM = 2 -> row = 3*2 + 3 + 4 = 13 columns when row == 13
-  ReduceArgs r{partials, sums, nrows, row, parts, K, KAM, ds, want, skip_begin, skip_len, n_value};
-  emu::launch([&] { reduce_partials_kernel(r); }, dim3((row + 15) / 16), dim3(1024), 0);
+  ReduceArgs r{partials, sums, nrows, row, K, KAM, ds, want, skip_begin, skip_len, n_value};
+  emu::launch([&] { reduce_partials_kernel(r); }, dim3((row + 31) / 32), dim3(1024), 0);
   return 0;
 }
 

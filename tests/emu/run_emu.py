@@ -137,17 +137,16 @@ def test_encode_pack():
         h2 = h.copy(); h2[0, 0, 0, 0] = 0.25
         assert pack_hidden(h2, NW)[1] == 2
     # reduce_partials_kernel on a synthetic K=1, M=1 layout (KAM = 4): row = 3*4 + 3 + 4 = 19 columns
-    # [vh 4][vh' 4][h 1][h' 1][sw 4][sb 1][v 4]; parts = 2 -> owner columns only in even rows
-    nrows, row, parts = 70, 19, 2
+    # [vh 4][vh' 4][h 1][h' 1][sw 4][sb 1][v 4]; 300 rows exercise the 4-rows-in-flight loop and its tail
+    nrows, row = 300, 19
     part = rng.standard_normal((nrows, row)).astype(np.float32)
     for ds_, want_ in ((1, 1), (0, 0)):
         skip_b, skip_l = (10, 5) if not want_ else (row, 0)      # model half drops sw, sb
         sums = np.full(row - skip_l + 1, -1.0, dtype=np.float32)
-        lib.emu_reduce(fp(part), fp(sums), nrows, row, parts, 1, 4, ds_, want_, skip_b, skip_l, ctypes.c_float(42.0))
+        lib.emu_reduce(fp(part), fp(sums), nrows, row, 1, 4, ds_, want_, skip_b, skip_l, ctypes.c_float(42.0))
         full = part.astype(np.float64).sum(axis=0)
-        own = part[::parts].astype(np.float64).sum(axis=0)
-        exp = np.concatenate([full[0:4], full[4:8] * ds_, own[8:9], own[9:10] * ds_, full[10:14] * want_,
-                              own[14:15] * want_, own[15:19]])
+        exp = np.concatenate([full[0:4], full[4:8] * ds_, full[8:9], full[9:10] * ds_, full[10:14] * want_,
+                              full[14:15] * want_, full[15:19]])
         keep = [i for i in range(row) if not (skip_b <= i < skip_b + skip_l)]
         np.testing.assert_allclose(sums[:len(keep)], exp[keep], rtol=1e-5, atol=1e-5)
         assert sums[len(keep)] == 42.0

@@ -72,18 +72,38 @@ static inline float __shfl_xor(float v, int mask, int width = 64) {
   return r;
 }
 
-// DPP row rotation (ctrl 0x120 + n = row_ror:n): lane l of a 16-lane row reads lane (l - n) mod 16
+// DPP moves used by crbm_kernels.h: row_ror:n (ctrl 0x120 + n: lane l of a 16-lane row
+// reads lane (l - n) mod 16), row_bcast15 (0x142: lane 15 of the previous row) and
+// row_bcast31 (0x143: lane 31); rows outside row_mask keep `old`.
 static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
   const unsigned lane = emu::t_threadIdx.x & 63u, wave = emu::t_threadIdx.x >> 6;
   float* s = emu::t_ctx->wave_scratch + wave * 64;
   memcpy(&s[lane], &src, 4);
   pthread_barrier_wait(&emu::t_ctx->wave_bar[wave]);
-  const unsigned n = (unsigned)ctrl - 0x120u;
-  const unsigned from = (lane & ~15u) | ((lane - n) & 15u);
-  int r;
-  memcpy(&r, &s[from], 4);
+  int r = old;
+  const unsigned row = lane >> 4;
+  if ((row_mask >> row) & 1) {
+    if (ctrl == 0x142) { if (row >= 1) memcpy(&r, &s[16 * row - 1], 4); }
+    else if (ctrl == 0x143) { if (row >= 2) memcpy(&r, &s[31], 4); }
+    else {
+      const unsigned n = (unsigned)ctrl - 0x120u;
+      const unsigned from = (lane & ~15u) | ((lane - n) & 15u);
+      memcpy(&r, &s[from], 4);
+    }
+  }
   pthread_barrier_wait(&emu::t_ctx->wave_bar[wave]);
-  (void)old; (void)row_mask; (void)bank_mask; (void)bound_ctrl;
+  (void)bank_mask; (void)bound_ctrl;
+  return r;
+}
+
+static inline int __builtin_amdgcn_readlane(int v, int src_lane) {
+  const unsigned lane = emu::t_threadIdx.x & 63u, wave = emu::t_threadIdx.x >> 6;
+  float* s = emu::t_ctx->wave_scratch + wave * 64;
+  memcpy(&s[lane], &v, 4);
+  pthread_barrier_wait(&emu::t_ctx->wave_bar[wave]);
+  int r;
+  memcpy(&r, &s[src_lane], 4);
+  pthread_barrier_wait(&emu::t_ctx->wave_bar[wave]);
   return r;
 }
 
