@@ -208,29 +208,28 @@ __device__ __forceinline__ uint64_t letter_window(const uint32_t* w, int s) {
 // z[k] (+)= sum over letter groups of T[g][tuple][k]  (z = -log2(e) * activation).
 template <class C, bool ACCUMULATE = false>
 __device__ __forceinline__ void conv_gather(const float* T, uint64_t win, float (&x)[C::KP]) {
-  if (!ACCUMULATE) {
-#pragma unroll
-    for (int q = 0; q < C::KP; ++q) x[q] = 0.f;
-  }
-  auto group = [&](int g) {
+  auto group = [&](int g, auto FIRST) {
+    constexpr bool first = decltype(FIRST)::value != 0;   // the first group of a fresh sum assigns (saves KP adds of 0)
     const uint32_t r = (uint32_t)(win >> (2 * C::G * g)) & (uint32_t)(C::ROWS - 1);
     const float4* row = reinterpret_cast<const float4*>(T + (size_t)g * C::ROWS * C::KP) + (size_t)r * C::NQ;
 #pragma unroll
     for (int q = 0; q < C::NQ; ++q) {
       const float4 t = row[q];
-      x[4 * q + 0] += t.x;
-      x[4 * q + 1] += t.y;
-      x[4 * q + 2] += t.z;
-      x[4 * q + 3] += t.w;
+      if (first) {
+        x[4 * q + 0] = t.x; x[4 * q + 1] = t.y; x[4 * q + 2] = t.z; x[4 * q + 3] = t.w;
+      } else {
+        x[4 * q + 0] += t.x; x[4 * q + 1] += t.y; x[4 * q + 2] += t.z; x[4 * q + 3] += t.w;
+      }
     }
   };
+  if (ACCUMULATE) group(0, IC<0>{}); else group(0, IC<1>{});
   if constexpr (C::NG * C::NQ <= 48) {
 #pragma unroll
-    for (int g = 0; g < C::NG; ++g) group(g);
+    for (int g = 1; g < C::NG; ++g) group(g, IC<0>{});
   } else {
     // large models: a rolled loop keeps the in-flight LDS reads (and registers) bounded
 #pragma unroll 1
-    for (int g = 0; g < C::NG; ++g) group(g);
+    for (int g = 1; g < C::NG; ++g) group(g, IC<0>{});
   }
 }
 
