@@ -34,6 +34,7 @@ CONFIGS = {
     "cfg5": dict(K=20, M=15, L=500, ds=True, chains=8192, k=1,
                  desc="20 motifs len 15, doublestranded, batch 8192/GPU x 4x500, PCD-1"),
 }
+TRAIN_WATCHDOG_S = 180
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
@@ -172,34 +173,7 @@ def main():
     hf, _ = model.get_fantasy()
     activity = float(hf.mean())
 
-    # ---- secondary: full PCD-k training steps (with the RCCL all-reduce when N > 1) ----
-    train = None
-    if not args.no_train:
-        try:
-            if world > 1 and backend != "gloo":
-                uid = cdist.exchange_unique_id(rank, world)
-                buf = (ctypes.c_uint8 * _lib.UNIQUE_ID_BYTES).from_buffer_copy(uid)
-                model._call("crbm_comm_init", buf, world, rank)
-            n = cfg["chains"]
-            D = synthetic_onehot(n, cfg["L"], seed=1234 + rank)
-            model._call("crbm_dataset_upload", fptr(D), n, cfg["L"])
-            tms = ctypes.c_float()
-            model._call("crbm_time_train", 0, n, 5, ctypes.byref(tms))
-            tsteps = max(10, min(200, args.steps // 10))
-            barrier()
-            t1 = time.perf_counter()
-            model._call("crbm_time_train", 0, n, tsteps, ctypes.byref(tms))
-            barrier()
-            tel = time.perf_counter() - t1
-            if dist is not None:
-                tt = torch.tensor([tel], dtype=torch.float64, device=red_dev)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                tel = float(tt[0])
-            train = {"train_steps_per_s": tsteps / tel, "global_batch": n * world, "cd_k": k,
-                     "all_reduce": "rccl" if (world > 1 and backend != "gloo") else "none", "ms_per_train_step": 1e3 * tel / tsteps}
-        except Exception as e:                      # report, never hide: the headline is the Gibbs metric
-            train = {"error": str(e)[:300]}
-
+    out = None
     if rank == 0:
         info = _lib.CrbmLaunchInfo()
         lib.crbm_get_launch_info(h, ctypes.byref(info))
@@ -237,11 +211,68 @@ def main():
                                  "the kernel keeps chain state bit-packed, so real HBM traffic is state_bytes_per_launch"},
             "launch": {"grid": info.gibbs_grid, "block": info.gibbs_block, "chains_per_tile": info.gibbs_seqs_per_tile,
                        "lds_bytes": info.gibbs_lds_bytes, "table_group": info.group},
-            "train": train,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg)
-        print(json.dumps(out))
+
+    # The headline line is complete before the secondary section starts.  With N > 1 a
+    # watchdog prints it anyway if the RCCL part of the training section should hang on
+    # some rank (a hang must not cost the Gibbs measurement).
+    done = {"printed": False}
+
+    def emit(train_result):
+        if done["printed"]:
+            return
+        done["printed"] = True
+        if rank == 0:
+            out["train"] = train_result
+            if world == 1 and not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(cfg)
+            print(json.dumps(out), flush=True)
+
+    watchdog = None
+    if world > 1 and not args.no_train:
+        import threading
+
+        def bail():
+            emit({"error": "training section did not finish within %d s" % TRAIN_WATCHDOG_S})
+            os._exit(0)
+        watchdog = threading.Timer(TRAIN_WATCHDOG_S, bail)
+        watchdog.daemon = True
+        watchdog.start()
+
+    # ---- secondary: full PCD-k training steps (with the RCCL all-reduce when N > 1) ----
+    train = None
+    if not args.no_train:
+        try:
+            if world > 1 and backend != "gloo":
+                # the 128-byte RCCL id travels over the process group that is already up
+                box = [cdist.make_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                uid = box[0]
+                buf = (ctypes.c_uint8 * _lib.UNIQUE_ID_BYTES).from_buffer_copy(uid)
+                model._call("crbm_comm_init", buf, world, rank)
+            n = cfg["chains"]
+            D = synthetic_onehot(n, cfg["L"], seed=1234 + rank)
+            model._call("crbm_dataset_upload", fptr(D), n, cfg["L"])
+            tms = ctypes.c_float()
+            model._call("crbm_time_train", 0, n, 5, ctypes.byref(tms))
+            tsteps = max(10, min(200, args.steps // 10))
+            barrier()
+            t1 = time.perf_counter()
+            model._call("crbm_time_train", 0, n, tsteps, ctypes.byref(tms))
+            barrier()
+            tel = time.perf_counter() - t1
+            if dist is not None:
+                tt = torch.tensor([tel], dtype=torch.float64, device=red_dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                tel = float(tt[0])
+            train = {"train_steps_per_s": tsteps / tel, "global_batch": n * world, "cd_k": k,
+                     "all_reduce": "rccl" if (world > 1 and backend != "gloo") else "none", "ms_per_train_step": 1e3 * tel / tsteps}
+        except Exception as e:                      # report, never hide: the headline is the Gibbs metric
+            train = {"error": str(e)[:300]}
+
+    if watchdog is not None:
+        watchdog.cancel()
+    emit(train)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -26,21 +26,23 @@ def shard_range(total, rank, world):
     return (total * rank) // world, (total * (rank + 1)) // world
 
 
+def make_unique_id():
+    """A fresh 128-byte RCCL id (crbm_comm_unique_id); call on one rank and ship it to the others."""
+    lib = _lib.load()
+    buf = (ctypes.c_uint8 * _lib.UNIQUE_ID_BYTES)()
+    rc = lib.crbm_comm_unique_id(buf)
+    if rc != 0:
+        raise Exception("crbm_comm_unique_id failed (%d): %s" % (rc, lib.crbm_last_error(None).decode()))
+    return bytes(buf)
+
+
 def exchange_unique_id(rank, world, addr=None, port=None, timeout=120.0, make_id=None):
     """Rank 0 creates the id (crbm_comm_unique_id) and serves it to the other
     ranks over TCP.  `make_id` is injectable for tests without a GPU."""
     addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
     port = int(port or int(os.environ.get("MASTER_PORT", "29500")) + _ID_PORT_OFFSET)
     if rank == 0:
-        if make_id is None:
-            lib = _lib.load()
-            buf = (ctypes.c_uint8 * _lib.UNIQUE_ID_BYTES)()
-            rc = lib.crbm_comm_unique_id(buf)
-            if rc != 0:
-                raise Exception("crbm_comm_unique_id failed (%d): %s" % (rc, lib.crbm_last_error(None).decode()))
-            uid = bytes(buf)
-        else:
-            uid = make_id()
+        uid = make_unique_id() if make_id is None else make_id()
         assert len(uid) == _lib.UNIQUE_ID_BYTES
         if world > 1:
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
