@@ -122,8 +122,18 @@ struct crbm_handle {
   uint64_t seed = 0;
   uint32_t gibbs_step = 0, eval_step = 0, chain_offset = 0;
   // launch geometry
-  GibbsLayout gl;
+  GibbsLayout gl;                      // of the variant in use
   int gibbs_threads = 256, gibbs_grid = 0;
+  // top-down variants of the Gibbs kernel: [0] dense tables (small models only), [1] set-bit walk
+  GibbsLayout glv[2];
+  int threadsv[2] = {256, 256}, gridv[2] = {0, 0};
+  bool has_dense = false;
+  int variant = 1;
+  int topdown_mode = 0;                // CRBM_TOPDOWN: 0 auto (by measured hidden activity), 1 dense, 2 sparse
+  uint32_t* d_nset = nullptr;          // per wave of the last Gibbs launch: set bits of the final state
+  int nset_slots = 0;
+  uint32_t launches_since_read = 0, activity_reads = 0;
+  double activity = -1.0;              // fraction of hidden units on after the last launch that was read back
   int stats_rows = 0, stats_lds_budget = 48 * 1024;
   SumsLayout sl;
   // data parallel
@@ -241,6 +251,13 @@ int launch_hgv(crbm_handle* h, const uint32_t* d_letters, int n, int L, int mode
   return CRBM_OK;
 }
 
+void use_variant(crbm_handle* h, int v) {
+  h->variant = v;
+  h->gl = h->glv[v];
+  h->gibbs_threads = h->threadsv[v];
+  h->gibbs_grid = h->gridv[v];
+}
+
 int launch_gibbs(crbm_handle* h, int steps, hipStream_t s = nullptr) {
   if (!s) s = h->stream;
   int rc = ensure_tables(h);
@@ -256,9 +273,35 @@ int launch_gibbs(crbm_handle* h, int steps, hipStream_t s = nullptr) {
   a.divLfw = make_fastdiv((uint32_t)(a.Lf * h->NW));
   a.steps = steps;
   a.rng = rng_view(h, h->gibbs_step, h->chain_offset);
-  HIPCHK(jit_launch(h->jk.gibbs, a, (unsigned)h->gibbs_grid, 1, (unsigned)h->gibbs_threads,
-                    (unsigned)h->gl.lds_bytes, s));
+  a.ones = h->d_nset;
+  h->nset_slots = h->gibbs_grid * (h->gibbs_threads / 64);
+  HIPCHK(jit_launch(h->variant ? h->jk.gibbs_sparse : h->jk.gibbs, a, (unsigned)h->gibbs_grid, 1,
+                    (unsigned)h->gibbs_threads, (unsigned)h->gl.lds_bytes, s));
   h->gibbs_step += (uint32_t)steps;
+  h->launches_since_read += 1;
+  return CRBM_OK;
+}
+
+// Called after a stream synchronisation: reads the activity monitor of the Gibbs
+// kernel back (every call when `always`, else every 16th) and, in auto mode, picks
+// the top-down variant for the next launches: the set-bit walk wins while few
+// hidden units are on (its cost grows with their number), the dense tables above
+// that.  The variants round differently in the last bit, so a switch can flip
+// samples that sit on a p == u tie.
+int refresh_activity(crbm_handle* h, bool always) {
+  if (h->launches_since_read == 0) return CRBM_OK;
+  if (!always && (h->activity_reads++ & 15u) != 0) return CRBM_OK;
+  std::vector<uint32_t> slots((size_t)h->nset_slots);
+  HIPCHK(hipMemcpy(slots.data(), h->d_nset, slots.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  unsigned long long last = 0;
+  for (uint32_t v : slots) last += v;
+  h->launches_since_read = 0;
+  h->activity = (double)last / ((double)h->B * h->Lf * h->K * (1 + h->ds));
+  if (h->topdown_mode == 0 && h->has_dense) {
+    const double hi = 0.03, lo = 0.02;   // hysteresis around the measured break-even (2.3 % at config #2)
+    if (h->variant == 1 && h->activity > hi) use_variant(h, 0);
+    else if (h->variant == 0 && h->activity < lo) use_variant(h, 1);
+  }
   return CRBM_OK;
 }
 
@@ -421,7 +464,7 @@ struct GibbsGeom {
   int S, threads, grid, lds;
 };
 
-GibbsGeom choose_gibbs_geometry(const ModelShape& ms, int Lf, int B, int num_cu) {
+GibbsGeom choose_gibbs_geometry(const ModelShape& ms, int Lf, int B, int num_cu, bool sparse) {
   const int forceS = env_int("CRBM_GIBBS_S", 0), forceT = env_int("CRBM_GIBBS_THREADS", 0);
   GibbsGeom best{1, 256, 1, 0};
   double best_score = -1.0;
@@ -429,7 +472,7 @@ GibbsGeom choose_gibbs_geometry(const ModelShape& ms, int Lf, int B, int num_cu)
     if (forceT > 0 && threads != forceT) continue;
     for (int S = 1; S <= std::min(B, 64); ++S) {
       if (forceS > 0 && S != forceS) continue;
-      const GibbsLayout gl = gibbs_layout(ms, Lf, S);
+      const GibbsLayout gl = gibbs_layout(ms, Lf, S, sparse);
       if (gl.lds_bytes > 150 * 1024 && !(forceS > 0)) continue;
       if (gl.lds_bytes > 160 * 1024 || (long)S * gl.Lrow * ms.NW >= (1 << 20)) continue;
       // lanes are used at wave granularity (an idle wave of a pass costs nothing);
@@ -513,13 +556,23 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
   TRY(hipGetDeviceProperties(&prop, hh->device));
   hh->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   // launch geometry, then the model-specific kernels (hiprtc; cached on disk)
-  const GibbsGeom geom = choose_gibbs_geometry(hh->ms, hh->Lf, hh->B, hh->num_cu);
-  hh->gl = gibbs_layout(hh->ms, hh->Lf, geom.S);
-  hh->gibbs_threads = geom.threads;
-  hh->gibbs_grid = geom.grid;
-  if (geom.lds <= 0) {
-    g_create_error = "model too large for the LDS-resident Gibbs kernel";
-    return bail(CRBM_ERR_INVALID);
+  hh->has_dense = hh->ms.DENSE != 0;
+  for (int v = hh->has_dense ? 0 : 1; v < 2; ++v) {
+    const GibbsGeom geom = choose_gibbs_geometry(hh->ms, hh->Lf, hh->B, hh->num_cu, v == 1);
+    if (geom.lds <= 0) {
+      g_create_error = "model too large for the LDS-resident Gibbs kernel";
+      return bail(CRBM_ERR_INVALID);
+    }
+    hh->glv[v] = gibbs_layout(hh->ms, hh->Lf, geom.S, v == 1);
+    hh->threadsv[v] = geom.threads;
+    hh->gridv[v] = geom.grid;
+  }
+  {
+    const char* td = getenv("CRBM_TOPDOWN");
+    hh->topdown_mode = (td && !strcmp(td, "dense")) ? 1 : (td && !strcmp(td, "sparse")) ? 2 : 0;
+    if (hh->topdown_mode == 1 && !hh->has_dense) hh->topdown_mode = 2;
+    // chains start at h = 0 (convRBM.py:168): begin with the set-bit walk
+    use_variant(hh, hh->topdown_mode == 1 ? 0 : 1);
   }
   {
     std::string err;
@@ -550,6 +603,10 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
   TRY(hipMalloc((void**)&hh->d_vf, vwords * 4)); TRY(hipMemset(hh->d_vf, 0, vwords * 4));
   TRY(hipMalloc((void**)&hh->d_flags, 16)); TRY(hipMemset(hh->d_flags, 0, 16));
   TRY(hipMalloc((void**)&hh->d_ones, 16)); TRY(hipMemset(hh->d_ones, 0, 16));
+  {
+    const size_t slots = (size_t)std::max(hh->gridv[0] * (hh->threadsv[0] / 64), hh->gridv[1] * (hh->threadsv[1] / 64)) + 64;
+    TRY(hipMalloc((void**)&hh->d_nset, slots * 4)); TRY(hipMemset(hh->d_nset, 0, slots * 4));
+  }
   TRY(hipMalloc((void**)&hh->d_sums, (size_t)hh->sl.count * 4)); TRY(hipMemset(hh->d_sums, 0, (size_t)hh->sl.count * 4));
 #undef TRY
   hh->tables_dirty = true;
@@ -565,7 +622,7 @@ int crbm_destroy(crbm_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->stream2) (void)hipStreamSynchronize(h->stream2);
   if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
-  void* ptrs[] = {h->dW, h->db, h->dc, h->dvW, h->dvb, h->dvc, h->d_hm, h->d_hmp, h->d_vf, h->d_flags, h->d_ones, h->d_sums, h->d_tables};
+  void* ptrs[] = {h->dW, h->db, h->dc, h->dvW, h->dvb, h->dvc, h->d_hm, h->d_hmp, h->d_vf, h->d_flags, h->d_ones, h->d_nset, h->d_sums, h->d_tables};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   h->stage.release(); h->stage2.release(); h->out_a.release(); h->out_b.release(); h->out_c.release();
@@ -714,7 +771,7 @@ int crbm_train_step(crbm_handle* h, const float* D, int32_t n, int32_t L) {
   rc = train_core(h, h->letters.p, n, L);
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(h->stream));
-  return CRBM_OK;
+  return refresh_activity(h, false);
 }
 
 int crbm_dataset_select(crbm_handle* h, int32_t slot) {
@@ -773,7 +830,7 @@ int crbm_train_step_resident(crbm_handle* h, int32_t start, int32_t end) {
   int rc = train_core(h, h->dataset[slot].p + (size_t)start * LW, end - start, h->dataset_L[slot]);
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(h->stream));
-  return CRBM_OK;
+  return refresh_activity(h, false);
 }
 
 int crbm_gibbs_steps_async(crbm_handle* h, int32_t k) {
@@ -785,7 +842,7 @@ int crbm_gibbs_steps_async(crbm_handle* h, int32_t k) {
 int crbm_sync(crbm_handle* h) {
   ENTER();
   HIPCHK(hipStreamSynchronize(h->stream));
-  return CRBM_OK;
+  return refresh_activity(h, true);
 }
 
 int crbm_gibbs_steps(crbm_handle* h, int32_t k) {
@@ -805,7 +862,7 @@ int crbm_time_gibbs(crbm_handle* h, int32_t k, int32_t launches, float* total_ms
   HIPCHK(hipEventRecord(h->ev1, h->stream));
   HIPCHK(hipEventSynchronize(h->ev1));
   HIPCHK(hipEventElapsedTime(total_ms, h->ev0, h->ev1));
-  return CRBM_OK;
+  return refresh_activity(h, true);
 }
 
 int crbm_time_train(crbm_handle* h, int32_t start, int32_t end, int32_t launches, float* total_ms) {
@@ -822,7 +879,7 @@ int crbm_time_train(crbm_handle* h, int32_t start, int32_t end, int32_t launches
   HIPCHK(hipEventRecord(h->ev1, h->stream));
   HIPCHK(hipEventSynchronize(h->ev1));
   HIPCHK(hipEventElapsedTime(total_ms, h->ev0, h->ev1));
-  return CRBM_OK;
+  return refresh_activity(h, true);
 }
 
 // ---- stand-alone passes ------------------------------------------------------
@@ -1282,6 +1339,8 @@ int crbm_get_launch_info(const crbm_handle* h, crbm_launch_info* out) {
   out->stats_grid_x = h->stats_rows > 0 ? h->stats_rows : h->num_cu * std::max(1, std::min(8, (160 * 1024) / std::max(1, st.lds_bytes)));
   out->stats_grid_y = st.grid_y;
   out->stats_block = st.threads; out->stats_lds_bytes = st.lds_bytes;
+  out->gibbs_sparse = h->variant;
+  out->activity_ppm = h->activity < 0.0 ? -1 : (int32_t)(h->activity * 1e6 + 0.5);
   return CRBM_OK;
 }
 

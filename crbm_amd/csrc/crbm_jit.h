@@ -26,7 +26,8 @@ namespace crbm {
 
 struct JitKernels {
   hipModule_t module = nullptr;
-  hipFunction_t build_tables = nullptr, hgv = nullptr, gibbs = nullptr, stats = nullptr, free_energy = nullptr,
+  hipFunction_t build_tables = nullptr, hgv = nullptr, gibbs = nullptr /* dense top-down; null if the model has none */,
+                gibbs_sparse = nullptr, stats = nullptr, free_energy = nullptr,
                 hit_summary = nullptr;
   bool from_cache = false;
   std::string cache_file;
@@ -63,13 +64,14 @@ inline uint64_t jit_fnv1a(const std::string& s, uint64_t h = 1469598103934665603
 }
 
 inline std::string jit_stub(int K, int M, int DS, int G) {
-  char buf[3072];
+  char buf[4096];
   snprintf(buf, sizeof(buf),
            "#include \"crbm_kernels.h\"\n"
            "using ModelCfg = crbm::Cfg<%d, %d, %d, %d>;\n"
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_build_tables(crbm::TablesArgs a) { crbm::build_tables_body<ModelCfg>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_hgv(crbm::HgvArgs a) { crbm::hgv_body<ModelCfg>(a); }\n"
-           "extern \"C\" __global__ void __launch_bounds__(256) crbm_gibbs(crbm::GibbsArgs a) { crbm::gibbs_body<ModelCfg>(a); }\n"
+           "extern \"C\" __global__ void __launch_bounds__(256) crbm_gibbs_sparse(crbm::GibbsArgs a) { crbm::gibbs_body<ModelCfg, true>(a); }\n"
+           "extern \"C\" __global__ void __launch_bounds__(256) crbm_gibbs(crbm::GibbsArgs a) { if constexpr (ModelCfg::DENSE) crbm::gibbs_body<ModelCfg, ModelCfg::DENSE ? false : true>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_stats(crbm::StatsArgs a) { crbm::stats_body<ModelCfg>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_free_energy(crbm::FeArgs a) { crbm::free_energy_body<ModelCfg>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_hit_summary(crbm::HitArgs a) { crbm::hit_summary_body<ModelCfg>(a); }\n",
@@ -161,6 +163,7 @@ inline int jit_load(int K, int M, int DS, int G, JitKernels* out, std::string* e
   }
   struct { const char* name; hipFunction_t* f; } syms[] = {
       {"crbm_build_tables", &out->build_tables}, {"crbm_hgv", &out->hgv}, {"crbm_gibbs", &out->gibbs},
+      {"crbm_gibbs_sparse", &out->gibbs_sparse},
       {"crbm_stats", &out->stats}, {"crbm_free_energy", &out->free_energy},
       {"crbm_hit_summary", &out->hit_summary}};
   for (auto& s : syms) {

@@ -251,7 +251,8 @@ __device__ __forceinline__ void copy_tables(float* dst, const float* src) {
 //    Pad columns k >= K get +1e30 in group 0: exp(-x) = inf, sigmoid -> 0.
 //  Tv[jr][ch][pat] (float4 over letters) = sum_{bit in pat} W[5ch+bit][:][M-1-jr]
 //  Tvr          = same for rc(W)                           (convRBM.py:279-287)
-//  Wt[jr][k]    (float4 over letters) = W[k][:][M-1-jr]    (sparse top-down)
+//  Ws[jr+3][k]  (float4 over letters) = W[k][:][M-1-jr] for 0 <= jr < M, else 0   (sparse top-down)
+//  Wsr          = same for rc(W)
 // ---------------------------------------------------------------------------
 struct TablesArgs {
   const float* W;   // (K,4,M)
@@ -283,7 +284,7 @@ __device__ void build_tables_body(const TablesArgs& a) {
       } else if (g == 0) {
         val = 1e30f;
       }
-    } else if (idx < C::OFF_WT) {                            // dense top-down tables
+    } else if (idx < C::OFF_C) {                             // dense top-down tables
       const bool rc = C::DS && idx >= C::OFF_TVR;
       const int t0 = idx - (rc ? C::OFF_TVR : C::OFF_TV);
       const int al = t0 & 3, pat = (t0 >> 2) & 31, ch = (t0 >> 7) % C::NCH, jr = (t0 >> 7) / C::NCH;
@@ -292,12 +293,15 @@ __device__ void build_tables_body(const TablesArgs& a) {
         if (k < K && ((pat >> bit) & 1))
           val += rc ? a.W[(k * 4 + (3 - al)) * M + jr] : a.W[(k * 4 + al) * M + (M - 1 - jr)];
       }
-    } else if (idx < C::OFF_C) {                             // sparse scatter table
-      const int t0 = idx - C::OFF_WT;
-      const int al = t0 & 3, k = (t0 >> 2) % (C::NW * 32), jr = (t0 >> 2) / (C::NW * 32);
-      val = k < K ? a.W[(k * 4 + al) * M + (M - 1 - jr)] : 0.f;
-    } else {
+    } else if (idx < C::TABLES) {
       val = a.c[idx - C::OFF_C];
+    } else if (idx < C::OFF_C2) {                            // sparse top-down tables, zero rows at both ends
+      const bool rc = C::DS && idx >= C::OFF_WSR;
+      const int t0 = idx - (rc ? C::OFF_WSR : C::OFF_WS);
+      const int al = t0 & 3, k = (t0 >> 2) % K, jr = (t0 >> 2) / K - 3;
+      if (jr >= 0 && jr < M) val = rc ? a.W[(k * 4 + (3 - al)) * M + jr] : a.W[(k * 4 + al) * M + (M - 1 - jr)];
+    } else {
+      val = a.c[idx - C::OFF_C2];
     }
     a.out[idx] = val;
   }
@@ -390,6 +394,7 @@ struct GibbsArgs {
   FastDiv divVB, divHB, divRow, divLfw;   // / nvb, / nhb, / (Lrow*NW), / (Lf*NW)
   int32_t steps;
   RngView rng;
+  uint32_t* ones;      // [gridDim.x * waves per block] set bits of the final hidden state per wave (activity monitor), may be null
 };
 
 // letter of one visible position from its 4 top-down activations
@@ -400,21 +405,51 @@ __device__ __forceinline__ uint32_t sample_letter(float y0, float y1, float y2, 
   return (uint32_t)(t >= e0) + (uint32_t)(t >= e0 + e1) + (uint32_t)(t >= (e0 + e1) + e2);
 }
 
+// Adds the top-down contributions of every set bit of one window word to the 4
+// visible positions of a thread.  Bit b of the word is hidden unit k of window slot
+// q = q_base + ql (b = ql*K + k); visible position i sees it through filter column
+// jr = q - i, i.e. table row (q - i + 3): address (q_base*K + b)*16 + (3 - i)*K*16,
+// out-of-range columns hit the zero rows of the table.
 template <class C>
+__device__ __forceinline__ void topdown_bits(unsigned long long w, const char* tab_q, float (&y)[4][4]) {
+  constexpr int K = C::K;
+  while (w) {
+    const int b = __ffsll(w) - 1;
+    w &= w - 1ull;
+    const char* p = tab_q + b * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 t = *reinterpret_cast<const float4*>(p + (3 - i) * K * 16);
+      y[i][0] += t.x; y[i][1] += t.y; y[i][2] += t.z; y[i][3] += t.w;
+    }
+  }
+}
+
+// SPARSE selects the top-down variant (Cfg comment in crbm_layout.h); the LDS image
+// differs accordingly.  The dense variant exists only for Cfg::DENSE models.
+template <class C, bool SPARSE>
 __device__ void gibbs_body(const GibbsArgs& a) {
   constexpr int KP = C::KP, M = C::M, NW = C::NW, NCH = C::NCH;
+  static_assert(SPARSE || C::DENSE, "no dense top-down tables for this model");
+  constexpr int LTAB = SPARSE ? C::SP_TABLES : C::TABLES;
   HIP_DYNAMIC_SHARED(float, smem);
-  const float* Tf = smem + C::OFF_TF;
-  const float* Tr = smem + C::OFF_TR;
-  const float* cv = smem + C::OFF_C;
-  uint32_t* hm = reinterpret_cast<uint32_t*>(smem + C::TABLES);
+  const float* Tf = smem;
+  const float* Tr = smem + C::TAB;
+  const float* cv = smem + (SPARSE ? C::SP_C : C::OFF_C);
+  uint32_t* hm = reinterpret_cast<uint32_t*>(smem + LTAB);
   uint32_t* hmp = hm + (size_t)a.S * a.Lrow * NW;
   uint32_t* let = hmp + (C::DS ? (size_t)a.S * a.Lrow * NW : 0);
 
-  copy_tables<C::TABLES>(smem, a.tables);
+  if (SPARSE) {
+    copy_tables<C::TAB * (1 + C::DS)>(smem, a.tables);
+    copy_tables<C::WS * (1 + C::DS) + 4>(smem + C::SP_WS, a.tables + C::OFF_WS);
+  } else {
+    copy_tables<C::TABLES>(smem, a.tables);
+  }
 
   const int rowW = a.Lrow * NW;
   const int ntiles = (a.nchains + a.S - 1) / a.S;
+  int nset = 0;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int n0 = tile * a.S;
     const int ns = min(a.S, a.nchains - n0);
@@ -441,7 +476,7 @@ __device__ void gibbs_body(const GibbsArgs& a) {
         float y[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { y[i][0] = cv[0]; y[i][1] = cv[1]; y[i][2] = cv[2]; y[i][3] = cv[3]; }
-        if constexpr (C::DENSE) {
+        if constexpr (!SPARSE) {
           // masks p0 .. p0+M+2 (padded row), then one float4 table row per
           // (filter column, 5-bit chunk) of each mask
           constexpr int NMV = (M + 3 + 3) / 4;
@@ -471,35 +506,37 @@ __device__ void gibbs_body(const GibbsArgs& a) {
                 }
           }
         } else {
-          const float4* Wt = reinterpret_cast<const float4*>(smem + C::OFF_WT);   // [jr][slot] -> W[k][0..3][M-1-jr]
+          // window slots q = 0 .. M+2 are the masks at padded-row positions p0 .. p0+M+2;
+          // their bits are packed into 64-bit words (as many whole masks as fit) and every
+          // set bit adds one table row to each of the 4 positions
+          constexpr int NSLOT = M + 3;
+          constexpr int PPW = NW == 1 ? 64 / C::K : 1;         // masks per word
+          constexpr int NWORD = (NSLOT + PPW - 1) / PPW;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {   // y[i] is indexed statically; the bit loops below are runtime loops
-            const uint32_t* mrow = hm + (size_t)nl * rowW + (size_t)(p0 + i) * NW;
-            for (int jr = 0; jr < M; ++jr) {
+          for (int strand = 0; strand <= C::DS; ++strand) {
+            const uint32_t* mrow = (strand ? hmp : hm) + ((size_t)nl * a.Lrow + p0) * NW;
+            const char* tab = reinterpret_cast<const char*>(smem + (strand ? C::SP_WSR : C::SP_WS));
+            if constexpr (NW == 1) {
+              constexpr int NMV = (NSLOT + 3) / 4;
+              uint32_t m[4 * NMV];
 #pragma unroll
-              for (int w = 0; w < NW; ++w) {
-                uint32_t m = mrow[jr * NW + w];
-                while (m) {
-                  const int bit = __ffs(m) - 1;
-                  m &= m - 1;
-                  const float4 t = Wt[(jr * NW + w) * 32 + bit];
-                  y[i][0] += t.x; y[i][1] += t.y; y[i][2] += t.z; y[i][3] += t.w;
-                }
+              for (int v4 = 0; v4 < NMV; ++v4) {
+                const uint4 mm = reinterpret_cast<const uint4*>(mrow)[v4];
+                m[4 * v4] = mm.x; m[4 * v4 + 1] = mm.y; m[4 * v4 + 2] = mm.z; m[4 * v4 + 3] = mm.w;
               }
-            }
-            if (C::DS) {   // rc strand: rc(W)[k,a,j] = W[k,3-a,M-1-j]
-              const uint32_t* prow = hmp + (size_t)nl * rowW + (size_t)(p0 + i) * NW;
-              for (int jr = 0; jr < M; ++jr) {
 #pragma unroll
-                for (int w = 0; w < NW; ++w) {
-                  uint32_t m = prow[jr * NW + w];
-                  while (m) {
-                    const int bit = __ffs(m) - 1;
-                    m &= m - 1;
-                    const float4 t = Wt[((M - 1 - jr) * NW + w) * 32 + bit];
-                    y[i][0] += t.w; y[i][1] += t.z; y[i][2] += t.y; y[i][3] += t.x;
-                  }
-                }
+              for (int wi = 0; wi < NWORD; ++wi) {
+                unsigned long long w = 0ull;
+#pragma unroll
+                for (int t = 0; t < PPW; ++t)
+                  if (wi * PPW + t < NSLOT) w |= (unsigned long long)m[wi * PPW + t] << (t * C::K);
+                topdown_bits<C>(w, tab + (size_t)wi * PPW * C::K * 16, y);
+              }
+            } else {
+#pragma unroll 1
+              for (int q = 0; q < NSLOT; ++q) {
+                const uint2 mm = *reinterpret_cast<const uint2*>(mrow + 2 * q);
+                topdown_bits<C>((unsigned long long)mm.x | ((unsigned long long)mm.y << 32), tab + (size_t)q * C::K * 16, y);
               }
             }
           }
@@ -536,7 +573,10 @@ __device__ void gibbs_body(const GibbsArgs& a) {
                                       a.rng.step + (uint32_t)st, mask, p);
               uint32_t* dst = (strand ? hmp : hm) + (size_t)nl * rowW + (size_t)(s + M - 1) * NW;
 #pragma unroll
-              for (int w = 0; w < NW; ++w) dst[w] = mask[w];
+              for (int w = 0; w < NW; ++w) {
+                dst[w] = mask[w];
+                if (st == a.steps - 1) nset += __popc(mask[w]);
+              }
             }
           }
         };
@@ -565,6 +605,10 @@ __device__ void gibbs_body(const GibbsArgs& a) {
     if (a.vout)
       for (int idx = threadIdx.x; idx < ns * a.LWs; idx += blockDim.x)
         a.vout[(size_t)n0 * a.LWs + idx] = let[idx];
+  }
+  if (a.ones) {   // one plain store per wave, summed by the host (counts stay far below 2^24: exact in float)
+    const float tot = wave_sum((float)nset);
+    if ((threadIdx.x & 63) == 0) a.ones[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = (uint32_t)tot;
   }
 }
 

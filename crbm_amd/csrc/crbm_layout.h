@@ -48,21 +48,37 @@ struct Cfg {
   static constexpr int NG = cdiv(M, G), ROWS = cpow4(G);  // gather table: groups x letter tuples
   static constexpr int TAB = NG * ROWS * KP;              // floats per gather table
   static constexpr int NCH = cdiv(K, 5);                  // 5-bit chunks of a position's mask
-  // v|h as dense table look-ups (small K*M) or as a loop over set bits
+  // v|h top-down pass, two kernel variants:
+  //  dense  (small K*M only): table look-ups per (filter column, 5-bit chunk of a mask)
+  //  sparse (every model): a walk over the set bits of the hidden masks
   static constexpr bool DENSE = (NW == 1) && (NCH * M * (1 + DS) <= 64);
   static constexpr int TV = DENSE ? M * NCH * 32 * 4 : 0; // floats per dense top-down table
-  static constexpr int WT = DENSE ? 0 : M * NW * 32 * 4;  // floats of the sparse scatter table
+  // sparse table Ws[jr+3][k] = float4 over letters of W[k][:][M-1-jr], rows jr = -3..-1 and
+  // M..M+2 all zero (a thread's 4 positions see jr = q-i, q = window slot, without range checks);
+  // Wsr is the same for the reverse-complement strand
+  static constexpr int WSROWS = M + 6;
+  static constexpr int WS = WSROWS * K * 4;               // floats per sparse table
   static constexpr int NGRP = cdiv(K, 10);                // sampler groups of 10 hidden units
-  // precomputed tables buffer (floats): [Tf][Tr*][Tv][Tvr*][Wt][c] is what the
-  // Gibbs kernel keeps in LDS (* = doublestranded only, TABLES floats); a
-  // single-stranded model still needs Tr for flip=True calls and for
-  // motifHitProbs (convRBM.py:511-514), kept after c in global memory only.
+  // Precomputed tables buffer (floats), global memory:
+  //   [Tf][Tr*][Tv][Tvr*][c]   TABLES floats = LDS image of the dense Gibbs variant
+  //   [Ws][Wsr*][c]            with [Tf][Tr*] the LDS image of the sparse variant (SP_TABLES floats)
+  //   [Tr]                     single-stranded models only: Tr is still needed for flip=True
+  //                            calls and for motifHitProbs (convRBM.py:511-514), global only
+  // (* = doublestranded only)
   static constexpr int OFF_TF = 0;
   static constexpr int OFF_TV = TAB * (1 + DS);
   static constexpr int OFF_TVR = OFF_TV + TV;
-  static constexpr int OFF_WT = OFF_TV + TV * (1 + DS);
-  static constexpr int OFF_C = OFF_WT + WT;
+  static constexpr int OFF_C = OFF_TV + TV * (1 + DS);
   static constexpr int TABLES = OFF_C + 4;                // multiple of 4 floats
+  static constexpr int OFF_WS = TABLES;
+  static constexpr int OFF_WSR = OFF_WS + WS;
+  static constexpr int OFF_C2 = OFF_WS + WS * (1 + DS);
+  static constexpr int END2 = OFF_C2 + 4;
+  // sparse variant, offsets inside LDS
+  static constexpr int SP_WS = TAB * (1 + DS);
+  static constexpr int SP_WSR = SP_WS + WS;
+  static constexpr int SP_C = SP_WS + WS * (1 + DS);
+  static constexpr int SP_TABLES = SP_C + 4;
   static constexpr int STATS_CH = 256;                    // positions a statistics wave buckets at a time
 #ifndef CRBM_STATS_UNR
 #define CRBM_STATS_UNR 4
@@ -72,8 +88,8 @@ struct Cfg {
   // sparsity statistic costs no second walk over the parked rows; large models keep a
   // separate pass (the second accumulator set would not fit the register file)
   static constexpr bool STATS_MERGE = KP * cdiv(M, 16) <= 32;
-  static constexpr int OFF_TR = DS ? TAB : TABLES;
-  static constexpr int TABLES_ALL = DS ? TABLES : TABLES + TAB;
+  static constexpr int OFF_TR = DS ? TAB : END2;
+  static constexpr int TABLES_ALL = DS ? END2 : END2 + TAB;
   // hit-summary kernel: a lane keeps the position sums of HIT_NI positions in registers
   static constexpr int HIT_NI = (48 / KP) < 1 ? 1 : ((48 / KP) > 4 ? 4 : (48 / KP));
 };
@@ -81,8 +97,8 @@ struct Cfg {
 // Host-side mirror of Cfg (runtime values, same arithmetic).
 struct ModelShape {
   int K, M, DS, G;
-  int NQ, KP, NW, NG, ROWS, TAB, NCH, DENSE, TV, WT, NGRP;
-  int OFF_TF, OFF_TR, OFF_TV, OFF_TVR, OFF_WT, OFF_C, TABLES, TABLES_ALL;
+  int NQ, KP, NW, NG, ROWS, TAB, NCH, DENSE, TV, WS, NGRP;
+  int OFF_TF, OFF_TR, OFF_TV, OFF_TVR, OFF_C, TABLES, OFF_WS, END2, SP_TABLES, TABLES_ALL;
   int HIT_NI, STATS_MERGE;
 };
 inline ModelShape model_shape(int K, int M, int DS, int G) {
@@ -93,11 +109,13 @@ inline ModelShape model_shape(int K, int M, int DS, int G) {
   s.NCH = cdiv(K, 5);
   s.DENSE = (s.NW == 1) && (s.NCH * M * (1 + DS) <= 64);
   s.TV = s.DENSE ? M * s.NCH * 32 * 4 : 0;
-  s.WT = s.DENSE ? 0 : M * s.NW * 32 * 4;
+  s.WS = (M + 6) * K * 4;
   s.NGRP = cdiv(K, 10);
   s.OFF_TF = 0; s.OFF_TV = s.TAB * (1 + DS); s.OFF_TVR = s.OFF_TV + s.TV;
-  s.OFF_WT = s.OFF_TV + s.TV * (1 + DS); s.OFF_C = s.OFF_WT + s.WT; s.TABLES = s.OFF_C + 4;
-  s.OFF_TR = DS ? s.TAB : s.TABLES; s.TABLES_ALL = DS ? s.TABLES : s.TABLES + s.TAB;
+  s.OFF_C = s.OFF_TV + s.TV * (1 + DS); s.TABLES = s.OFF_C + 4;
+  s.OFF_WS = s.TABLES; s.END2 = s.OFF_WS + s.WS * (1 + DS) + 4;
+  s.SP_TABLES = s.TAB * (1 + DS) + s.WS * (1 + DS) + 4;
+  s.OFF_TR = DS ? s.TAB : s.END2; s.TABLES_ALL = DS ? s.END2 : s.END2 + s.TAB;
   s.HIT_NI = (48 / s.KP) < 1 ? 1 : ((48 / s.KP) > 4 ? 4 : (48 / s.KP));
   s.STATS_MERGE = s.KP * cdiv(M, 16) <= 32;
   return s;
@@ -122,7 +140,7 @@ struct GibbsLayout {
   int S, Lv, nvb, nhb, Lrow, LWs;
   int lds_bytes;
 };
-inline GibbsLayout gibbs_layout(const ModelShape& ms, int Lf, int S) {
+inline GibbsLayout gibbs_layout(const ModelShape& ms, int Lf, int S, bool sparse) {
   GibbsLayout g;
   g.S = S;
   g.Lv = Lf + ms.M - 1;
@@ -130,7 +148,7 @@ inline GibbsLayout gibbs_layout(const ModelShape& ms, int Lf, int S) {
   g.nhb = cdiv(Lf, 4);
   g.Lrow = 4 * cdiv(4 * g.nvb + ms.M - 1 + 3, 4);
   g.LWs = letter_words(4 * g.nvb);
-  const long words = (long)ms.TABLES + (long)(1 + ms.DS) * S * g.Lrow * ms.NW + (long)S * g.LWs;
+  const long words = (long)(sparse ? ms.SP_TABLES : ms.TABLES) + (long)(1 + ms.DS) * S * g.Lrow * ms.NW + (long)S * g.LWs;
   g.lds_bytes = (int)(words * 4);
   return g;
 }

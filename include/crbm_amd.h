@@ -204,6 +204,9 @@ typedef struct crbm_launch_info {
   int32_t group;         /* letters per gather-table group (G)                    */
   int32_t gibbs_grid, gibbs_block, gibbs_seqs_per_tile, gibbs_lds_bytes;
   int32_t stats_grid_x, stats_grid_y, stats_block, stats_lds_bytes;
+  int32_t gibbs_sparse;  /* top-down variant of the next Gibbs launch: 1 = walk over set bits, 0 = dense tables.
+                            Chosen from the measured hidden activity unless CRBM_TOPDOWN=dense|sparse.      */
+  int32_t activity_ppm;  /* hidden units on per million after the last launch read back, -1 = not read yet  */
 } crbm_launch_info;
 int crbm_get_launch_info(const crbm_handle* h, crbm_launch_info* out);
 /* Actual bytes of chain state one Gibbs launch reads+writes in HBM. */

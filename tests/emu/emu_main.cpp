@@ -134,21 +134,27 @@ int emu_vgh(const float* W, const float* c, int K, int M, const float* hid, cons
 }
 
 // returns LWs (letter words per chain row of vout) or -1
+// sparse != 0: set-bit walk; 0: dense top-down tables (returns -3 if the model has none)
 int emu_gibbs(int id, const float* tables, uint32_t* hm, uint32_t* hmp, uint32_t* vout, int nchains, int Lf, int S,
-              int steps, uint64_t seed, uint32_t step, uint32_t off, int grid, int threads) {
+              int steps, uint64_t seed, uint32_t step, uint32_t off, int grid, int threads, int sparse,
+              uint32_t* ones) {
   GibbsArgs a;
-  a.tables = tables; a.hm = hm; a.hmp = hmp; a.vout = vout;
+  a.tables = tables; a.hm = hm; a.hmp = hmp; a.vout = vout; a.ones = ones;
   a.nchains = nchains; a.Lf = Lf; a.S = S; a.steps = steps; a.rng = make_rng(seed, step, off);
   int lws = -1;
   CFG_DISPATCH(id, {
     const ModelShape ms = shape_of<C>();
-    const GibbsLayout gl = gibbs_layout(ms, Lf, S);
+    if (!sparse && !C::DENSE) return -3;
+    const GibbsLayout gl = gibbs_layout(ms, Lf, S, sparse != 0);
     a.Lv = gl.Lv; a.nvb = gl.nvb; a.nhb = gl.nhb; a.Lrow = gl.Lrow; a.LWs = gl.LWs;
     a.divVB = make_fastdiv((uint32_t)gl.nvb); a.divHB = make_fastdiv((uint32_t)gl.nhb);
     a.divRow = make_fastdiv((uint32_t)(gl.Lrow * ms.NW)); a.divLfw = make_fastdiv((uint32_t)(Lf * ms.NW));
     if (!C::DS) a.hmp = nullptr;
     lws = gl.LWs;
-    if (vout) emu::launch([&] { gibbs_body<C>(a); }, dim3(grid), dim3(threads), (size_t)gl.lds_bytes);
+    if (vout) {
+      if (sparse) emu::launch([&] { gibbs_body<C, true>(a); }, dim3(grid), dim3(threads), (size_t)gl.lds_bytes);
+      else emu::launch([&] { gibbs_body<C, C::DENSE ? false : true>(a); }, dim3(grid), dim3(threads), (size_t)gl.lds_bytes);
+    }
   });
   return lws;
 }

@@ -220,7 +220,7 @@ def test_vgh():
         print("vgh ok", (K, M, ds))
 
 
-def run_gibbs(cid, o, tables, S, steps, grid, threads):
+def run_gibbs(cid, o, tables, S, steps, grid, threads, sparse=1, ones=None):
     info = case_info(cid)
     K, M, ds, NW = info["K"], info["M"], info["ds"], info["NW"]
     hm, _ = pack_hidden(f32(o.fantasy_h), NW)
@@ -228,11 +228,12 @@ def run_gibbs(cid, o, tables, S, steps, grid, threads):
     B, Lf = o.fantasy_h.shape[0], o.fantasy_h.shape[3]
     Lv = Lf + M - 1
     lws = lib.emu_gibbs(cid, fp(tables), up(hm), up(hmp), None, B, Lf, S, steps,
-                        ctypes.c_uint64(o.seed), o.gibbs_step, o.seq_offset, grid, threads)
+                        ctypes.c_uint64(o.seed), o.gibbs_step, o.seq_offset, grid, threads, sparse, None)
     assert lws > 0
     vout = np.zeros((B, lws), dtype=np.uint32)
     rc = lib.emu_gibbs(cid, fp(tables), up(hm), up(hmp), up(vout), B, Lf, S, steps,
-                       ctypes.c_uint64(o.seed), o.gibbs_step, o.seq_offset, grid, threads)
+                       ctypes.c_uint64(o.seed), o.gibbs_step, o.seq_offset, grid, threads, sparse,
+                       up(ones) if ones is not None else None)
     assert rc == lws
     v = np.zeros((B, 1, 4, Lv), dtype=np.float32)
     lib.emu_decode(up(vout), fp(v), B, Lv, lws, 2)
@@ -241,21 +242,25 @@ def run_gibbs(cid, o, tables, S, steps, grid, threads):
 
 def test_gibbs():
     for cid in GIBBS_CASES:
-        for (B, Lf, S, steps, grid, threads) in ((5, 21, 2, 3, 2, 128), (3, 40, 4, 1, 1, 64)):
-            info, o = oracle_for(cid, seed=11, batch=B, Lf=Lf, wscale=1.5)
-            ds = info["ds"]
-            o.seq_offset = 6
-            rng = np.random.default_rng(5)
-            o.fantasy_h = rng.binomial(1, 0.1, size=o.fantasy_h.shape).astype(np.float64)
-            if ds:
-                o.fantasy_h_prime = rng.binomial(1, 0.1, size=o.fantasy_h.shape).astype(np.float64)
-            tables = build_tables(cid, o)
-            h, hp, v, _, _ = run_gibbs(cid, o, tables, S, steps, grid, threads)
-            o.gibbs_steps(steps)
-            mism = int((h != o.fantasy_h).sum()) + (int((hp != o.fantasy_h_prime).sum()) if ds else 0)
-            mism_v = int((v != o.last_v_model).sum())
-            assert mism == 0 and mism_v == 0, ("gibbs mismatch", cid, mism, mism_v)
-            assert o.fantasy_h.sum() > 0
+        info = case_info(cid)
+        for sparse in ((1, 0) if info["DENSE"] else (1,)):     # both top-down variants where both exist
+            for (B, Lf, S, steps, grid, threads) in ((5, 21, 2, 3, 2, 128), (3, 40, 4, 1, 1, 64)):
+                info, o = oracle_for(cid, seed=11, batch=B, Lf=Lf, wscale=1.5)
+                ds = info["ds"]
+                o.seq_offset = 6
+                rng = np.random.default_rng(5)
+                o.fantasy_h = rng.binomial(1, 0.1, size=o.fantasy_h.shape).astype(np.float64)
+                if ds:
+                    o.fantasy_h_prime = rng.binomial(1, 0.1, size=o.fantasy_h.shape).astype(np.float64)
+                tables = build_tables(cid, o)
+                ones = np.zeros(grid * (threads // 64), dtype=np.uint32)
+                h, hp, v, _, _ = run_gibbs(cid, o, tables, S, steps, grid, threads, sparse, ones)
+                o.gibbs_steps(steps)
+                mism = int((h != o.fantasy_h).sum()) + (int((hp != o.fantasy_h_prime).sum()) if ds else 0)
+                mism_v = int((v != o.last_v_model).sum())
+                assert mism == 0 and mism_v == 0, ("gibbs mismatch", cid, sparse, mism, mism_v)
+                assert o.fantasy_h.sum() > 0
+                assert int(ones.sum()) == int(h.sum()) + (int(hp.sum()) if ds else 0), "activity monitor"
         print("gibbs ok", cid, info)
 
 

@@ -26,6 +26,7 @@ struct float4 {
   float x, y, z, w;
 };
 static inline float4 make_float4(float a, float b, float c, float d) { return float4{a, b, c, d}; }
+struct alignas(8) uint2 { uint32_t x, y; };
 struct uint4 {
   unsigned x, y, z, w;
 };
@@ -151,6 +152,8 @@ static inline unsigned int atomicMax(unsigned int* p, unsigned int v) {
 }
 static inline unsigned int __float_as_uint(float f) { unsigned int u; __builtin_memcpy(&u, &f, 4); return u; }
 static inline int __ffs(uint32_t v) { return __builtin_ffs((int)v); }
+static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
+static inline int __popc(uint32_t v) { return __builtin_popcount(v); }
 static inline uint32_t __umulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
 #define __expf(x) expf(x)
 static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }

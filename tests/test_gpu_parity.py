@@ -180,6 +180,52 @@ def test_gibbs_chain_matches_oracle(K, M, ds, Lf):
     assert (v != o.last_v_model).mean() < 1e-4
 
 
+@pytest.mark.parametrize("variant", ["dense", "sparse"])
+@pytest.mark.parametrize("ds", [False, True])
+def test_gibbs_topdown_variants_match_oracle(variant, ds, monkeypatch):
+    """Both top-down variants of the Gibbs kernel (dense tables / walk over set bits)
+    reproduce the oracle chain; the activity monitor counts the final state."""
+    import ctypes
+    from crbm_amd._lib import CrbmLaunchInfo
+    monkeypatch.setenv("CRBM_TOPDOWN", variant)
+    B, K, M, Lf = 40, 10, 15, 186 if not ds else 60
+    model, o = make_pair(K, M, ds=ds, batchsize=B, Lf=Lf, wscale=1.5, bshift=5.0)
+    rng = np.random.default_rng(14)
+    h0 = rng.binomial(1, 0.1, size=(B, K, 1, Lf)).astype(np.float32)
+    hp0 = rng.binomial(1, 0.1, size=(B, K, 1, Lf)).astype(np.float32) if ds else None
+    model.set_fantasy(h0, hp0)
+    o.fantasy_h, o.fantasy_h_prime = h0.astype(np.float64), (hp0.astype(np.float64) if ds else None)
+    model.gibbsSteps(3)
+    o.gibbs_steps(3)
+    h, hp = model.get_fantasy()
+    assert (h != o.fantasy_h).mean() < 1e-4
+    assert (model.get_fantasy_visible() != o.last_v_model).mean() < 1e-4
+    info = CrbmLaunchInfo()
+    model._lib.crbm_get_launch_info(model._h(), ctypes.byref(info))
+    assert info.gibbs_sparse == (1 if variant == "sparse" else 0)
+    total = h.sum() + (hp.sum() if ds else 0.0)
+    assert abs(info.activity_ppm - 1e6 * total / (B * K * Lf * (2 if ds else 1))) <= 1.0
+
+
+def test_gibbs_variant_follows_activity():
+    """Auto mode: sparse chains use the set-bit walk, busy chains switch to the dense tables."""
+    import ctypes
+    from crbm_amd._lib import CrbmLaunchInfo
+    B, K, M, Lf = 64, 10, 15, 100
+
+    def variant_after(bshift):
+        model, _ = make_pair(K, M, ds=False, batchsize=B, Lf=Lf, bshift=bshift)
+        model.gibbsSteps(2)
+        info = CrbmLaunchInfo()
+        model._lib.crbm_get_launch_info(model._h(), ctypes.byref(info))
+        return info.gibbs_sparse, info.activity_ppm
+
+    sparse, ppm = variant_after(-1.0)      # b ~ -10: almost nothing on
+    assert sparse == 1 and 0 <= ppm < 30000
+    sparse, ppm = variant_after(9.0)       # b ~ 0: about half of the units on
+    assert sparse == 0 and ppm > 100000
+
+
 def test_gibbs_rejects_bad_state():
     model, _ = make_pair(4, 5, ds=False, batchsize=2, Lf=10)
     bad = np.full((2, 4, 1, 10), 0.5, dtype=np.float32)
