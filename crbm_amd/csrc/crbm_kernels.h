@@ -251,7 +251,7 @@ __device__ __forceinline__ void copy_tables(float* dst, const float* src) {
 //    Pad columns k >= K get +1e30 in group 0: exp(-x) = inf, sigmoid -> 0.
 //  Tv[jr][ch][pat] (float4 over letters) = sum_{bit in pat} W[5ch+bit][:][M-1-jr]
 //  Tvr          = same for rc(W)                           (convRBM.py:279-287)
-//  Ws[jr+3][k]  (float4 over letters) = W[k][:][M-1-jr] for 0 <= jr < M, else 0   (sparse top-down)
+//  Ws[jr+4][k]  (float4 over letters) = W[k][:][M-1-jr] for 0 <= jr < M, else 0   (sparse top-down)
 //  Wsr          = same for rc(W)
 // ---------------------------------------------------------------------------
 struct TablesArgs {
@@ -298,7 +298,7 @@ __device__ void build_tables_body(const TablesArgs& a) {
     } else if (idx < C::OFF_C2) {                            // sparse top-down tables, zero rows at both ends
       const bool rc = C::DS && idx >= C::OFF_WSR;
       const int t0 = idx - (rc ? C::OFF_WSR : C::OFF_WS);
-      const int al = t0 & 3, k = (t0 >> 2) % K, jr = (t0 >> 2) / K - 3;
+      const int al = t0 & 3, k = (t0 >> 2) % K, jr = (t0 >> 2) / K - 4;
       if (jr >= 0 && jr < M) val = rc ? a.W[(k * 4 + (3 - al)) * M + jr] : a.W[(k * 4 + al) * M + (M - 1 - jr)];
     } else {
       val = a.c[idx - C::OFF_C2];
@@ -395,6 +395,7 @@ struct GibbsArgs {
   int32_t steps;
   RngView rng;
   uint32_t* ones;      // [gridDim.x * waves per block] set bits of the final hidden state per wave (activity monitor), may be null
+  int32_t debug;       // profiling only: 1 skips the table copy, 2 the state load, 4 the state store
 };
 
 // letter of one visible position from its 4 top-down activations
@@ -408,19 +409,31 @@ __device__ __forceinline__ uint32_t sample_letter(float y0, float y1, float y2, 
 // Adds the top-down contributions of every set bit of one window word to the 4
 // visible positions of a thread.  Bit b of the word is hidden unit k of window slot
 // q = q_base + ql (b = ql*K + k); visible position i sees it through filter column
-// jr = q - i, i.e. table row (q - i + 3): address (q_base*K + b)*16 + (3 - i)*K*16,
-// out-of-range columns hit the zero rows of the table.
+// jr = q - i, i.e. table row (q - i + 4): address (q_base*K + b)*16 + (4 - i)*K*16,
+// out-of-range columns hit the zero rows of the table.  The rows of the next bit are
+// requested before those of the current one are added (the LDS latency of a set
+// bit overlaps the adds of the previous one); a lane that runs out of bits points
+// at the leading zero rows.
 template <class C>
-__device__ __forceinline__ void topdown_bits(unsigned long long w, const char* tab_q, float (&y)[4][4]) {
+__device__ __forceinline__ void topdown_bits(unsigned long long w, const char* tab, int q_base, float (&y)[4][4]) {
   constexpr int K = C::K;
+  const char* tab_q = tab + (size_t)q_base * K * 16;
+  const char* idle = tab - K * 16;                     // + (4-i)*K*16 = rows 3-i: all zero
+  auto rows_of = [&](unsigned long long bits) { return bits ? tab_q + (__ffsll(bits) - 1) * 16 : idle; };
+  auto fetch = [&](const char* p, float4 (&t)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i] = *reinterpret_cast<const float4*>(p + (4 - i) * K * 16);
+  };
+  float4 cur[4];
+  fetch(rows_of(w), cur);
   while (w) {
-    const int b = __ffsll(w) - 1;
     w &= w - 1ull;
-    const char* p = tab_q + b * 16;
+    float4 nxt[4];
+    fetch(rows_of(w), nxt);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const float4 t = *reinterpret_cast<const float4*>(p + (3 - i) * K * 16);
-      y[i][0] += t.x; y[i][1] += t.y; y[i][2] += t.z; y[i][3] += t.w;
+      y[i][0] += cur[i].x; y[i][1] += cur[i].y; y[i][2] += cur[i].z; y[i][3] += cur[i].w;
+      cur[i] = nxt[i];
     }
   }
 }
@@ -440,30 +453,96 @@ __device__ void gibbs_body(const GibbsArgs& a) {
   uint32_t* hmp = hm + (size_t)a.S * a.Lrow * NW;
   uint32_t* let = hmp + (C::DS ? (size_t)a.S * a.Lrow * NW : 0);
 
+  if (!(a.debug & 1)) {
   if (SPARSE) {
     copy_tables<C::TAB * (1 + C::DS)>(smem, a.tables);
     copy_tables<C::WS * (1 + C::DS) + 4>(smem + C::SP_WS, a.tables + C::OFF_WS);
   } else {
     copy_tables<C::TABLES>(smem, a.tables);
   }
+  }
 
   const int rowW = a.Lrow * NW;
+  const uint32_t per = (uint32_t)(a.Lf * NW);           // state words per chain
   const int ntiles = (a.nchains + a.S - 1) / a.S;
   int nset = 0;
+  // the pads of the mask rows (M-1 positions in front, the rest behind) stay zero for the whole kernel
+  {
+    const int padw = rowW - (int)per, front = (M - 1) * NW;
+    for (int idx = threadIdx.x; idx < a.S * padw; idx += blockDim.x) {
+      const int nl = idx / padw, e = idx - nl * padw;
+      const int d = nl * rowW + (e < front ? e : e + (int)per);
+      hm[d] = 0u;
+      if (C::DS) hmp[d] = 0u;
+    }
+  }
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int n0 = tile * a.S;
     const int ns = min(a.S, a.nchains - n0);
     __syncthreads();
-    // chain state -> zero-padded LDS rows (hidden position s sits at s + M-1)
-    for (uint32_t idx = threadIdx.x; idx < (uint32_t)(ns * rowW); idx += blockDim.x) {
-      const uint32_t nl = fastdiv(idx, a.divRow);
-      const uint32_t r = idx - nl * (uint32_t)rowW;
-      const int q = (int)(r / NW), w = (int)(r % NW);
-      const int s = q - (M - 1);
-      const bool in = s >= 0 && s < a.Lf;
-      const size_t g = ((size_t)(n0 + nl) * a.Lf + (in ? s : 0)) * NW + w;
-      hm[idx] = in ? a.hm[g] : 0u;
-      if (C::DS) hmp[idx] = in ? a.hmp[g] : 0u;
+    // chain state -> zero-padded LDS rows (hidden position s sits at s + M-1).  The
+    // chains of a tile are one contiguous range of ns*per words in global memory:
+    // all loads of a thread are issued before the first LDS store (one memory round
+    // trip per tile), 16 bytes per lane where the alignment allows.
+    if (!(a.debug & 2)) {
+      const uint32_t nwords = (uint32_t)ns * per;
+      auto lds_index = [&](uint32_t i) {           // word i of the tile -> padded row position
+        const uint32_t nl = fastdiv(i, a.divLfw);
+        return nl * (uint32_t)rowW + (uint32_t)((M - 1) * NW) + (i - nl * per);
+      };
+      const size_t g0 = (size_t)n0 * per;
+      if (((g0 | nwords) & 3u) == 0u) {
+        constexpr int UN = 2;
+        const uint4* src = reinterpret_cast<const uint4*>(a.hm + g0);
+        const uint4* srcp = C::DS ? reinterpret_cast<const uint4*>(a.hmp + g0) : nullptr;
+        for (uint32_t base = threadIdx.x; base < nwords / 4; base += UN * blockDim.x) {
+          uint4 t[UN], tp[UN];
+#pragma unroll
+          for (int u = 0; u < UN; ++u) {
+            const uint32_t i4 = base + u * blockDim.x;
+            if (i4 < nwords / 4) {
+              t[u] = src[i4];
+              if (C::DS) tp[u] = srcp[i4];
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < UN; ++u) {
+            const uint32_t i4 = base + u * blockDim.x;
+            if (i4 < nwords / 4) {
+              const uint32_t e[4] = {t[u].x, t[u].y, t[u].z, t[u].w};
+              const uint32_t ep[4] = {tp[u].x, tp[u].y, tp[u].z, tp[u].w};
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                const uint32_t d = lds_index(4 * i4 + c);
+                hm[d] = e[c];
+                if (C::DS) hmp[d] = ep[c];
+              }
+            }
+          }
+        }
+      } else {
+        constexpr int UN = 8;
+        for (uint32_t base = threadIdx.x; base < nwords; base += UN * blockDim.x) {
+          uint32_t t[UN], tp[UN];
+#pragma unroll
+          for (int u = 0; u < UN; ++u) {
+            const uint32_t i = base + u * blockDim.x;
+            if (i < nwords) {
+              t[u] = a.hm[g0 + i];
+              if (C::DS) tp[u] = a.hmp[g0 + i];
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < UN; ++u) {
+            const uint32_t i = base + u * blockDim.x;
+            if (i < nwords) {
+              const uint32_t d = lds_index(i);
+              hm[d] = t[u];
+              if (C::DS) hmp[d] = tp[u];
+            }
+          }
+        }
+      }
     }
     for (int idx = threadIdx.x; idx < ns * a.LWs; idx += blockDim.x) let[idx] = 0u;
     for (int st = 0; st < a.steps; ++st) {
@@ -530,13 +609,13 @@ __device__ void gibbs_body(const GibbsArgs& a) {
 #pragma unroll
                 for (int t = 0; t < PPW; ++t)
                   if (wi * PPW + t < NSLOT) w |= (unsigned long long)m[wi * PPW + t] << (t * C::K);
-                topdown_bits<C>(w, tab + (size_t)wi * PPW * C::K * 16, y);
+                topdown_bits<C>(w, tab, wi * PPW, y);
               }
             } else {
 #pragma unroll 1
               for (int q = 0; q < NSLOT; ++q) {
                 const uint2 mm = *reinterpret_cast<const uint2*>(mrow + 2 * q);
-                topdown_bits<C>((unsigned long long)mm.x | ((unsigned long long)mm.y << 32), tab + (size_t)q * C::K * 16, y);
+                topdown_bits<C>((unsigned long long)mm.x | ((unsigned long long)mm.y << 32), tab, q, y);
               }
             }
           }
@@ -592,17 +671,29 @@ __device__ void gibbs_body(const GibbsArgs& a) {
       }
     }
     __syncthreads();
-    // LDS -> chain state
-    const uint32_t per = (uint32_t)(a.Lf * NW);
-    for (uint32_t idx = threadIdx.x; idx < (uint32_t)ns * per; idx += blockDim.x) {
-      const uint32_t nl = fastdiv(idx, a.divLfw);
-      const uint32_t r = idx - nl * per;
-      const size_t src = (size_t)nl * rowW + (size_t)(M - 1) * NW + r;
-      const size_t g = (size_t)(n0 + nl) * per + r;
-      a.hm[g] = hm[src];
-      if (C::DS) a.hmp[g] = hmp[src];
+    // LDS -> chain state (contiguous in global memory, 16-byte stores where aligned)
+    if (!(a.debug & 4)) {
+      const uint32_t nwords = (uint32_t)ns * per;
+      const size_t g0 = (size_t)n0 * per;
+      auto lds_index = [&](uint32_t i) {
+        const uint32_t nl = fastdiv(i, a.divLfw);
+        return nl * (uint32_t)rowW + (uint32_t)((M - 1) * NW) + (i - nl * per);
+      };
+      if (((g0 | nwords) & 3u) == 0u) {
+        for (uint32_t i4 = threadIdx.x; i4 < nwords / 4; i4 += blockDim.x) {
+          const uint32_t d0 = lds_index(4 * i4), d1 = lds_index(4 * i4 + 1), d2 = lds_index(4 * i4 + 2), d3 = lds_index(4 * i4 + 3);
+          reinterpret_cast<uint4*>(a.hm + g0)[i4] = make_uint4(hm[d0], hm[d1], hm[d2], hm[d3]);
+          if (C::DS) reinterpret_cast<uint4*>(a.hmp + g0)[i4] = make_uint4(hmp[d0], hmp[d1], hmp[d2], hmp[d3]);
+        }
+      } else {
+        for (uint32_t i = threadIdx.x; i < nwords; i += blockDim.x) {
+          const uint32_t d = lds_index(i);
+          a.hm[g0 + i] = hm[d];
+          if (C::DS) a.hmp[g0 + i] = hmp[d];
+        }
+      }
     }
-    if (a.vout)
+    if (a.vout && !(a.debug & 4))
       for (int idx = threadIdx.x; idx < ns * a.LWs; idx += blockDim.x)
         a.vout[(size_t)n0 * a.LWs + idx] = let[idx];
   }

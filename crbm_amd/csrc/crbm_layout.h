@@ -53,10 +53,11 @@ struct Cfg {
   //  sparse (every model): a walk over the set bits of the hidden masks
   static constexpr bool DENSE = (NW == 1) && (NCH * M * (1 + DS) <= 64);
   static constexpr int TV = DENSE ? M * NCH * 32 * 4 : 0; // floats per dense top-down table
-  // sparse table Ws[jr+3][k] = float4 over letters of W[k][:][M-1-jr], rows jr = -3..-1 and
-  // M..M+2 all zero (a thread's 4 positions see jr = q-i, q = window slot, without range checks);
+  // sparse table Ws[jr+4][k] = float4 over letters of W[k][:][M-1-jr], rows jr = -4..-1 and
+  // M..M+2 all zero (a thread's 4 positions see jr = q-i, q = window slot, without range checks;
+  // the four leading zero rows also serve as the target of the walk's idle look-ups);
   // Wsr is the same for the reverse-complement strand
-  static constexpr int WSROWS = M + 6;
+  static constexpr int WSROWS = M + 7;
   static constexpr int WS = WSROWS * K * 4;               // floats per sparse table
   static constexpr int NGRP = cdiv(K, 10);                // sampler groups of 10 hidden units
   // Precomputed tables buffer (floats), global memory:
@@ -109,7 +110,7 @@ inline ModelShape model_shape(int K, int M, int DS, int G) {
   s.NCH = cdiv(K, 5);
   s.DENSE = (s.NW == 1) && (s.NCH * M * (1 + DS) <= 64);
   s.TV = s.DENSE ? M * s.NCH * 32 * 4 : 0;
-  s.WS = (M + 6) * K * 4;
+  s.WS = (M + 7) * K * 4;
   s.NGRP = cdiv(K, 10);
   s.OFF_TF = 0; s.OFF_TV = s.TAB * (1 + DS); s.OFF_TVR = s.OFF_TV + s.TV;
   s.OFF_C = s.OFF_TV + s.TV * (1 + DS); s.TABLES = s.OFF_C + 4;

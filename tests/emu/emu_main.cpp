@@ -139,7 +139,7 @@ int emu_gibbs(int id, const float* tables, uint32_t* hm, uint32_t* hmp, uint32_t
               int steps, uint64_t seed, uint32_t step, uint32_t off, int grid, int threads, int sparse,
               uint32_t* ones) {
   GibbsArgs a;
-  a.tables = tables; a.hm = hm; a.hmp = hmp; a.vout = vout; a.ones = ones;
+  a.tables = tables; a.hm = hm; a.hmp = hmp; a.vout = vout; a.ones = ones; a.debug = 0;
   a.nchains = nchains; a.Lf = Lf; a.S = S; a.steps = steps; a.rng = make_rng(seed, step, off);
   int lws = -1;
   CFG_DISPATCH(id, {

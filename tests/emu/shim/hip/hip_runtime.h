@@ -30,6 +30,7 @@ struct alignas(8) uint2 { uint32_t x, y; };
 struct uint4 {
   unsigned x, y, z, w;
 };
+static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { uint4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
 typedef void* hipStream_t;
 
 namespace emu {

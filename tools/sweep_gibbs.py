@@ -39,6 +39,8 @@ def time_cfg(cfg, env, steps=300):
 if __name__ == "__main__":
     cfg = bench.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "cfg2"]
     print("us/launch grid block S lds G activity")
-    for S, thr, G in itertools.product([4, 5, 8, 10, 16, 20], [64, 128, 256], [3]):
-        res, err = time_cfg(cfg, {"CRBM_GIBBS_S": S, "CRBM_GIBBS_THREADS": thr, "CRBM_GROUP": G})
-        print("S=%d thr=%d G=%d ->" % (S, thr, G), res if res else err, flush=True)
+    variants = (sys.argv[2].split(",") if len(sys.argv) > 2 else ["sparse", "dense"])
+    Ss = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [2, 3, 4, 5, 6, 8, 10, 16]
+    for td, S, thr in itertools.product(variants, Ss, [64, 128, 256]):
+        res, err = time_cfg(cfg, {"CRBM_TOPDOWN": td, "CRBM_GIBBS_S": S, "CRBM_GIBBS_THREADS": thr})
+        print("%s S=%d thr=%d ->" % (td, S, thr), res if res else err, flush=True)
