@@ -128,6 +128,7 @@ struct crbm_handle {
   GibbsLayout glv[2];
   int threadsv[2] = {256, 256}, gridv[2] = {0, 0};
   bool has_dense = false;
+  int gibbs_wpe = 0;                   // register-allocation hint compiled into the sparse Gibbs kernel
   int variant = 1;
   int topdown_mode = 0;                // CRBM_TOPDOWN: 0 auto (by measured hidden activity), 1 dense, 2 sparse
   uint32_t* d_nset = nullptr;          // per wave of the last Gibbs launch: set bits of the final state
@@ -498,6 +499,14 @@ GibbsGeom choose_gibbs_geometry(const ModelShape& ms, int Lf, int B, int num_cu,
   return best;
 }
 
+// waves per SIMD the sparse Gibbs variant reaches with its geometry; 0 when >= 4 (no hint needed)
+int gibbs_wpe_hint(const GibbsGeom& g) {
+  if (g.lds <= 0) return 0;
+  const int blocks_cu = std::max(1, std::min((160 * 1024) / g.lds, 2048 / g.threads));
+  const int wpe = std::max(1, blocks_cu * (g.threads / 64) / 4);
+  return wpe < 4 ? wpe : 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -514,7 +523,9 @@ int crbm_precompile(const crbm_config* cfg) {
   std::vector<char> code;
   bool cached = false;
   std::string file, err;
-  if (jit_compile(ms.K, ms.M, ms.DS, ms.G, &code, &cached, &file, &err) != 0) {
+  const int Lf_pc = cfg->fantasy_hidden_len > 0 ? cfg->fantasy_hidden_len : 200;
+  const int wpe = gibbs_wpe_hint(choose_gibbs_geometry(ms, Lf_pc, cfg->batchsize, env_int("CRBM_NUM_CU", 256), true));
+  if (jit_compile(ms.K, ms.M, ms.DS, ms.G, wpe, &code, &cached, &file, &err) != 0) {
     g_create_error = err;
     return CRBM_ERR_HIP;
   }
@@ -565,6 +576,7 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
       return bail(CRBM_ERR_INVALID);
     }
     hh->glv[v] = gibbs_layout(hh->ms, hh->Lf, geom.S, v == 1);
+    if (v == 1) hh->gibbs_wpe = gibbs_wpe_hint(geom);
     hh->threadsv[v] = geom.threads;
     hh->gridv[v] = geom.grid;
   }
@@ -577,7 +589,7 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
   }
   {
     std::string err;
-    if (jit_load(hh->K, hh->M, hh->ds, hh->G, &hh->jk, &err) != 0) {
+    if (jit_load(hh->K, hh->M, hh->ds, hh->G, hh->gibbs_wpe, &hh->jk, &err) != 0) {
       g_create_error = "kernel specialisation failed: " + err;
       return bail(CRBM_ERR_HIP);
     }

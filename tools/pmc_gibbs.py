@@ -14,5 +14,6 @@ for f in sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True)):
             acc[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
     print(f)
     for name in sorted(acc):
-        vals = list(acc[name].values())
+        ids = sorted(acc[name], key=int)[1:]          # the first launch is the 10-step burn-in of prof_gibbs.py
+        vals = [acc[name][i] for i in ids]
         print("   %-26s mean per launch = %.5g  (%d launches)" % (name, sum(vals) / len(vals), len(vals)))
