@@ -135,7 +135,7 @@ struct crbm_handle {
   int nset_slots = 0;
   uint32_t launches_since_read = 0, activity_reads = 0;
   double activity = -1.0;              // fraction of hidden units on after the last launch that was read back
-  int stats_rows = 0, stats_lds_budget = 48 * 1024;
+  int stats_rows = 0, stats_lds_budget = 0;
   SumsLayout sl;
   // data parallel
   ncclComm_t comm = nullptr;
@@ -624,7 +624,7 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
 #undef TRY
   hh->tables_dirty = true;
   hh->stats_rows = env_int("CRBM_STATS_ROWS", 0);   // 0: one resident wave of blocks
-  hh->stats_lds_budget = env_int("CRBM_STATS_LDS", 48 * 1024);
+  hh->stats_lds_budget = env_int("CRBM_STATS_LDS", 0);   // 0: chosen per model (stats_layout)
   *out = hh;
   return CRBM_OK;
 }

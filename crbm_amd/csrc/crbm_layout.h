@@ -177,6 +177,15 @@ inline StatsLayout stats_layout(const ModelShape& ms, int want_sparsity, int Lh,
   long fixed = (long)(1 + ms.DS) * (ms.TAB + M * ms.KP) * 4 + (long)waves * 4 * CH * 2 + (long)waves * (3 * ms.KP + 4) * 4;
   fixed += 16L * 4 * ((Lh + M - 1 + 15 + 15) / 16 + 3);      // staged letters for up to 16 chains (upper bound)
   const long per_row = (long)(1 + ms.DS) * ms.KP * 4;
+  if (lds_budget <= 0) {
+    // auto: as many blocks per CU (3, 2, 1) as still leave a tile >= 256 hidden positions
+    // (or a whole chain): short segments idle most of the block in phase A and pay the
+    // 2(M-1) halo rows over and over
+    const long want_rows = (Lh < 256 ? Lh : 256) + 2 * (M - 1);
+    lds_budget = 156 * 1024;
+    for (int b = 3; b >= 2; --b)
+      if ((156 * 1024 / b - fixed) / per_row >= want_rows) { lds_budget = 156 * 1024 / b; break; }
+  }
   if (lds_budget < fixed + 24 * 1024) lds_budget = (int)(fixed + 24 * 1024);   // big tables: trade occupancy for segment length
   if (lds_budget > 156 * 1024) lds_budget = 156 * 1024;
   long rows = (lds_budget - fixed) / per_row;                 // parked rows that fit

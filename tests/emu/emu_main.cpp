@@ -172,7 +172,7 @@ int emu_stats(int id, const float* tables, const uint32_t* letters, int n, int L
   CFG_DISPATCH(id, {
     const ModelShape ms = shape_of<C>();
     const int Lh = L - C::M + 1;
-    StatsLayout st = stats_layout(ms, want_sparsity, Lh, n, 48 * 1024);
+    StatsLayout st = stats_layout(ms, want_sparsity, Lh, n, 0);
     if (force_ls > 0) {   // cut every chain into segments of force_ls hidden positions
       st.S = 1; st.LS = force_ls; st.nseg = (Lh + force_ls - 1) / force_ls;
       st.Rrow = st.LS + 2 * (C::M - 1);
