@@ -75,6 +75,7 @@ SIGNATURES = {
     "crbm_dataset_upload_codes": (_I32, [_H, _U8P, _I32, _I32]),
     "crbm_dataset_select": (_I32, [_H, _I32]),
     "crbm_train_step_resident": (_I32, [_H, _I32, _I32]),
+    "crbm_train_epoch_resident": (_I32, [_H, _I32]),
     "crbm_gibbs_steps": (_I32, [_H, _I32]),
     "crbm_gibbs_steps_async": (_I32, [_H, _I32]),
     "crbm_sync": (_I32, [_H]),

@@ -446,9 +446,9 @@ class CRBM(object):
             ntest = ntrain if same else self._upload(test_data, 1)[0]
         for epoch in range(self.epochs):
             self._call("crbm_dataset_select", 0)
-            for [start, end] in self._iterateBatchIndices(ntrain, self.batchsize):
-                lo, hi = self._shard_rows(start, end)
-                self._call("crbm_train_step_resident", lo, hi)
+            # the batch loop of convRBM.py:612-615 runs inside the library: the steps are
+            # enqueued back to back, with one host synchronisation per epoch
+            self._call("crbm_train_epoch_resident", self.batchsize)
             meanfe = 0.0
             meannmh = 0.0
             nb = 0

@@ -846,6 +846,27 @@ int crbm_train_step_resident(crbm_handle* h, int32_t start, int32_t end) {
   return refresh_activity(h, false);
 }
 
+// One pass over the resident data set in sequential mini-batches of `batchsize`
+// rows (the slices of convRBM.py:722-726, last one short), each a full PCD-k
+// update; rank r of a communicator takes its contiguous share of every batch.
+// The steps are enqueued back to back: one host synchronisation per epoch
+// instead of one per step.
+int crbm_train_epoch_resident(crbm_handle* h, int32_t batchsize) {
+  ENTER();
+  const int slot = h->slot;
+  ARGCHK(h->dataset_n[slot] > 0, "no resident data set (call crbm_dataset_upload)");
+  ARGCHK(batchsize >= 1, "batchsize must be positive");
+  const int total = h->dataset_n[slot], L = h->dataset_L[slot], LW = letter_words(L);
+  for (int start = 0; start < total; start += batchsize) {
+    const int end = std::min(total, start + batchsize), n = end - start;
+    const int lo = start + (int)(((long)n * h->rank) / h->nranks), hi = start + (int)(((long)n * (h->rank + 1)) / h->nranks);
+    int rc = train_core(h, h->dataset[slot].p + (size_t)lo * LW, hi - lo, L);
+    if (rc) return rc;
+  }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return refresh_activity(h, true);
+}
+
 int crbm_gibbs_steps_async(crbm_handle* h, int32_t k) {
   ENTER();
   ARGCHK(k >= 1, "k must be positive");

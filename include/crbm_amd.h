@@ -120,6 +120,11 @@ int crbm_dataset_upload_codes(crbm_handle* h, const uint8_t* codes, int32_t n, i
 #define CRBM_DATASET_SLOTS 2
 int crbm_dataset_select(crbm_handle* h, int32_t slot);
 int crbm_train_step_resident(crbm_handle* h, int32_t start, int32_t end);
+/* The batch loop of fit() (convRBM.py:612-615) over the selected resident data
+ * set: sequential slices of `batchsize` rows (convRBM.py:722-726), one PCD-k
+ * update each, enqueued back to back with one host synchronisation at the end.
+ * With a communicator, rank r takes rows [n*r/R, n*(r+1)/R) of every slice. */
+int crbm_train_epoch_resident(crbm_handle* h, int32_t batchsize);
 /* The persistent chain alone (convRBM.py:397-408): k Gibbs steps on all
  * fantasy chains, parameters frozen.  Benchmark entry. */
 int crbm_gibbs_steps(crbm_handle* h, int32_t k);

@@ -625,3 +625,18 @@ def test_fit_with_codes_and_test_set(capsys):
     # the status line is the batch mean of _evaluateData over the test set (convRBM.py:617-625)
     fe = np.mean([a._evaluateData(codesToOneHot(test[lo:hi]))[0] for lo, hi in a._iterateBatchIndices(30, 20)])
     assert "FE={:1.3f}".format(fe) in status(out_a)[-1]
+
+
+def test_epoch_entry_equals_step_loop():
+    """crbm_train_epoch_resident (one sync per epoch) == the per-batch loop of convRBM.py:612-615."""
+    rng = np.random.default_rng(37)
+    codes = rng.integers(0, 4, size=(70, 64), dtype=np.uint8)       # 4 batches of 20, last one short
+    a, _ = make_pair(6, 9, ds=True, batchsize=20, cd_k=2, bshift=4.0)
+    b, _ = make_pair(6, 9, ds=True, batchsize=20, cd_k=2, bshift=4.0)
+    a._upload(codes, 0)
+    b._upload(codes, 0)
+    for lo, hi in a._iterateBatchIndices(70, 20):
+        a._call("crbm_train_step_resident", lo, hi)
+    b._call("crbm_train_epoch_resident", 20)
+    np.testing.assert_array_equal(a.motifs.get_value(), b.motifs.get_value())
+    np.testing.assert_array_equal(a.get_fantasy()[0], b.get_fantasy()[0])
