@@ -478,9 +478,9 @@ GibbsGeom choose_gibbs_geometry(const ModelShape& ms, int Lf, int B, int num_cu,
       if (gl.lds_bytes > 150 * 1024 && !(forceS > 0)) continue;
       if (gl.lds_bytes > 160 * 1024 || (long)S * gl.Lrow * ms.NW >= (1 << 20)) continue;
       // lanes are used at wave granularity (an idle wave of a pass costs nothing);
-      // h|v costs ~1.5x v|h per 4-position block
+      // 4 hidden positions cost ~1.5x a 4-position visible block
       const double iv = (double)S * gl.nvb, ih = (double)S * gl.nhb;
-      const double util = (iv + 1.5 * ih) / (64.0 * (std::ceil(iv / 64.0) + 1.5 * std::ceil(ih / 64.0)));
+      const double util = (iv + 0.375 * ih) / (64.0 * (std::ceil(iv / 64.0) + 0.375 * std::ceil(ih / 64.0)));
       const double ntiles = std::ceil((double)B / S);
       const double per_cu_tiles = ntiles / num_cu;
       const double balance = per_cu_tiles / std::ceil(per_cu_tiles);

@@ -388,7 +388,7 @@ struct GibbsArgs {
   uint32_t* hmp;       // reverse strand (ds) or null
   uint32_t* vout;      // [nchains][LWs] letters of the last visible sample
   int32_t nchains, Lf, Lv, S;
-  int32_t nvb, nhb;    // 4-position blocks per chain (visible, hidden)
+  int32_t nvb, nhb;    // items per chain: 4-position visible blocks, hidden positions
   int32_t Lrow;        // padded mask row (positions), multiple of 4
   int32_t LWs;         // letter words per chain row
   FastDiv divVB, divHB, divRow, divLfw;   // / nvb, / nhb, / (Lrow*NW), / (Lf*NW)
@@ -634,39 +634,27 @@ __device__ void gibbs_body(const GibbsArgs& a) {
       }
       __syncthreads();
       // ---- h | v : x[k,s] = b[k] + sum_j W[k, letter[s+j], j]; h = [sigma(x) > u] ----
+      // one hidden position per item (nhb = Lf items per chain): the K units of a position
+      // already give the instruction-level parallelism, and single positions spread evenly
+      // over the waves of the block
       for (uint32_t it = threadIdx.x; it < (uint32_t)(ns * a.nhb); it += blockDim.x) {
         const uint32_t nl = fastdiv(it, a.divHB);
-        const int s0 = 4 * (int)(it - nl * (uint32_t)a.nhb);
+        const int s = (int)(it - nl * (uint32_t)a.nhb);
         const uint32_t gn = a.rng.seq_offset + (uint32_t)(n0 + nl);
-        const uint32_t* lrow = let + (size_t)nl * a.LWs;
-        auto one_position = [&](int i) {
-          const int s = s0 + i;
-          if (s < a.Lf) {
-            const uint64_t win = letter_window<M>(lrow, s);
+        const uint64_t win = letter_window<M>(let + (size_t)nl * a.LWs, s);
 #pragma unroll
-            for (int strand = 0; strand <= C::DS; ++strand) {
-              float x[KP], p[KP];
-              conv_gather<C>(strand ? Tr : Tf, win, x);
-              uint32_t mask[NW];
-              sample_hidden<C, false>(x, gn, (uint32_t)s, KIND_CHAIN_H, (uint32_t)strand, a.rng,
-                                      a.rng.step + (uint32_t)st, mask, p);
-              uint32_t* dst = (strand ? hmp : hm) + (size_t)nl * rowW + (size_t)(s + M - 1) * NW;
+        for (int strand = 0; strand <= C::DS; ++strand) {
+          float x[KP], p[KP];
+          conv_gather<C>(strand ? Tr : Tf, win, x);
+          uint32_t mask[NW];
+          sample_hidden<C, false>(x, gn, (uint32_t)s, KIND_CHAIN_H, (uint32_t)strand, a.rng,
+                                  a.rng.step + (uint32_t)st, mask, p);
+          uint32_t* dst = (strand ? hmp : hm) + (size_t)nl * rowW + (size_t)(s + M - 1) * NW;
 #pragma unroll
-              for (int w = 0; w < NW; ++w) {
-                dst[w] = mask[w];
-                if (st == a.steps - 1) nset += __popc(mask[w]);
-              }
-            }
+          for (int w = 0; w < NW; ++w) {
+            dst[w] = mask[w];
+            if (st == a.steps - 1) nset += __popc(mask[w]);
           }
-        };
-        if constexpr (C::KP * (1 + C::DS) <= 16) {
-          // small models: the 4 positions of the block interleave (ILP)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) one_position(i);
-        } else {
-          // large models: one position at a time keeps x[] in registers
-#pragma unroll 1
-          for (int i = 0; i < 4; ++i) one_position(i);
         }
       }
     }

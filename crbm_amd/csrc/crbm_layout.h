@@ -134,8 +134,8 @@ inline int choose_group(int K, int M, int ds, int budget_bytes) {
 }
 
 // ---- Gibbs kernel -------------------------------------------------------------
-// A thread owns 4 consecutive positions.  Per chain: nvb = ceil(Lv/4) visible
-// blocks, nhb = ceil(Lf/4) hidden blocks.  Hidden position s sits at index
+// v|h: a thread owns 4 consecutive visible positions (nvb = ceil(Lv/4) items per
+// chain); h|v: one hidden position per item (nhb = Lf).  Hidden position s sits at index
 // s + M-1 of a zero-padded mask row of Lrow positions (multiple of 4).
 struct GibbsLayout {
   int S, Lv, nvb, nhb, Lrow, LWs;
@@ -146,7 +146,7 @@ inline GibbsLayout gibbs_layout(const ModelShape& ms, int Lf, int S, bool sparse
   g.S = S;
   g.Lv = Lf + ms.M - 1;
   g.nvb = cdiv(g.Lv, 4);
-  g.nhb = cdiv(Lf, 4);
+  g.nhb = Lf;
   g.Lrow = 4 * cdiv(4 * g.nvb + ms.M - 1 + 3, 4);
   g.LWs = letter_words(4 * g.nvb);
   const long words = (long)(sparse ? ms.SP_TABLES : ms.TABLES) + (long)(1 + ms.DS) * S * g.Lrow * ms.NW + (long)S * g.LWs;
