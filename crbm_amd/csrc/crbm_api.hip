@@ -308,7 +308,9 @@ int refresh_activity(crbm_handle* h, bool always) {
 }
 
 // raw statistic sums of (letters, n, L) -> sums half (data or model)
-int launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool data_half, hipStream_t s = nullptr) {
+// `defer`: hand the reduction of the partial rows back to the caller (to pair it with the other half)
+int launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool data_half, hipStream_t s = nullptr,
+                 ReduceArgs* defer = nullptr) {
   if (!s) s = h->stream;
   DevBuf<float>& pbuf = data_half ? h->partials : h->partials2;
   int rc = ensure_tables(h);
@@ -352,6 +354,7 @@ int launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool d
     r.skip_begin = h->sl.model_skip_begin; r.skip_len = h->sl.model_skip_len;
   }
   r.n_value = (float)n;
+  if (defer) { *defer = r; return CRBM_OK; }
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((st.row + 31) / 32), dim3(1024), 0, s, r);
   HIPCHK(hipGetLastError());
   return CRBM_OK;
@@ -386,12 +389,19 @@ int train_local_dev(crbm_handle* h, const uint32_t* d_letters, int n, int L) {
   }
   rc = launch_gibbs(h, h->cfg.cd_k, sm);
   if (rc) return rc;
-  rc = launch_stats(h, h->d_vf, h->B, h->Lv, false, sm);
+  // single stream: the two column reductions share one launch
+  ReducePair pair;
+  const bool paired = !h->overlap && n > 0;
+  rc = launch_stats(h, h->d_vf, h->B, h->Lv, false, sm, paired ? &pair.half[1] : nullptr);
   if (rc) return rc;
   if (h->overlap) HIPCHK(hipEventRecord(h->ev_join, h->stream2));
   if (n > 0) {
-    rc = launch_stats(h, d_letters, n, L, true);
+    rc = launch_stats(h, d_letters, n, L, true, nullptr, paired ? &pair.half[0] : nullptr);
     if (rc) return rc;
+    if (paired) {
+      hipLaunchKernelGGL(reduce_partials_pair_kernel, dim3((pair.half[0].row + 31) / 32, 2), dim3(1024), 0, h->stream, pair);
+      HIPCHK(hipGetLastError());
+    }
   } else {   // a rank may own no rows of a short last mini-batch: contribute zeros
     HIPCHK(hipMemsetAsync(h->d_sums + h->sl.data_off, 0, (size_t)(h->sl.n_d + 1 - h->sl.data_off) * sizeof(float), h->stream));
   }

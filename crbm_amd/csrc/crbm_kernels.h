@@ -1431,7 +1431,7 @@ struct ReduceArgs {
   float n_value;                  // written after the last kept column
 };
 
-__global__ void __launch_bounds__(1024) reduce_partials_kernel(ReduceArgs a) {
+__device__ __forceinline__ void reduce_partials_body(const ReduceArgs& a) {
   __shared__ float part[32][33];
   const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int r = blockIdx.x * 32 + col;
@@ -1470,6 +1470,16 @@ __global__ void __launch_bounds__(1024) reduce_partials_kernel(ReduceArgs a) {
     }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) a.sums[a.row - a.skip_len] = a.n_value;
+}
+
+__global__ void __launch_bounds__(1024) reduce_partials_kernel(ReduceArgs a) { reduce_partials_body(a); }
+
+// both halves of a training step in one launch (blockIdx.y = 0: data, 1: model)
+struct ReducePair {
+  ReduceArgs half[2];
+};
+__global__ void __launch_bounds__(1024) reduce_partials_pair_kernel(ReducePair p) {
+  reduce_partials_body(p.half[blockIdx.y]);
 }
 
 // ---------------------------------------------------------------------------
