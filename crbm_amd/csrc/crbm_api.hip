@@ -317,7 +317,7 @@ int launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool d
   if (rc) return rc;
   const int want_sp = data_half ? 1 : 0;
   const int Lh = L - h->M + 1;
-  const StatsLayout st = stats_layout(h->ms, want_sp, Lh, n, h->stats_lds_budget);
+  const StatsLayout st = stats_layout(h->ms, want_sp, Lh, n, h->stats_lds_budget, env_int("CRBM_STATS_S", 0));
   StatsArgs a;
   a.tables = h->d_tables;
   a.letters = d_letters;

@@ -164,7 +164,7 @@ struct StatsLayout {
   int off_vh[2], off_h[2], off_sw, off_sb, off_v;
   int lds_bytes;
 };
-inline StatsLayout stats_layout(const ModelShape& ms, int want_sparsity, int Lh, int n, int lds_budget) {
+inline StatsLayout stats_layout(const ModelShape& ms, int want_sparsity, int Lh, int n, int lds_budget, int force_S = 0) {
   StatsLayout s;
   const int K = ms.K, M = ms.M, KAM = K * 4 * M;
   s.npasses = 1 + ms.DS + (ms.STATS_MERGE ? 0 : want_sparsity);
@@ -195,6 +195,7 @@ inline StatsLayout stats_layout(const ModelShape& ms, int want_sparsity, int Lh,
     s.LS = Lh; s.nseg = 1;
     s.Rrow = Lh + 2 * (M - 1);
     s.S = (int)(rows / s.Rrow);
+    if (force_S > 0 && force_S < s.S) s.S = force_S;
     if (s.S > 16) s.S = 16;
     if (s.S > n) s.S = n > 0 ? n : 1;
     if (s.S < 1) s.S = 1;
