@@ -169,6 +169,13 @@ def main():
     steps_done = args.steps * k                  # Gibbs steps per rank in the timed region
     value = world * steps_done / elapsed
 
+    # informational: the same chain advanced 16 steps per launch (no per-launch fixed cost);
+    # not the headline, which stays at one step per launch (PCD-1)
+    multi_ms = ctypes.c_float()
+    model._call("crbm_time_gibbs", 16, 5, ctypes.byref(multi_ms))
+    model._call("crbm_time_gibbs", 16, 40, ctypes.byref(multi_ms))
+    us_per_step_k16 = 1e3 * multi_ms.value / (40 * 16)
+
     # hidden-unit activity of the chain (workload descriptor, after timing)
     hf, _ = model.get_fantasy()
     activity = float(hf.mean())
@@ -203,10 +210,11 @@ def main():
             "chain_steps_per_s": value * cfg["chains"],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "gibbs_kernel<NQ=%d>" % info.nq,
+                         "kernel": "crbm_gibbs_sparse" if info.gibbs_sparse else "crbm_gibbs",   # name in the rocprofv3 summaries
                          "avg_launch_us": 1e6 * avg_launch_s,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "state_bytes_per_launch": int(lib.crbm_gibbs_state_bytes(h)),
+                         "us_per_step_at_16_steps_per_launch": us_per_step_k16,
                          "note": "achieved = algorithmic bytes of the dense fp32 layout (SURVEY 8d) / launch time; "
                                  "the kernel keeps chain state bit-packed, so real HBM traffic is state_bytes_per_launch"},
             "launch": {"grid": info.gibbs_grid, "block": info.gibbs_block, "chains_per_tile": info.gibbs_seqs_per_tile,
