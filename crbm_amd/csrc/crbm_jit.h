@@ -78,7 +78,7 @@ inline std::string jit_stub(int K, int M, int DS, int G, int gibbs_wpe) {
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_hgv(crbm::HgvArgs a) { crbm::hgv_body<ModelCfg>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) CRBM_GIBBS_ATTR crbm_gibbs_sparse(crbm::GibbsArgs a) { crbm::gibbs_body<ModelCfg, true>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_gibbs(crbm::GibbsArgs a) { if constexpr (ModelCfg::DENSE) crbm::gibbs_body<ModelCfg, ModelCfg::DENSE ? false : true>(a); }\n"
-           "extern \"C\" __global__ void __launch_bounds__(256) crbm_stats(crbm::StatsArgs a) { crbm::stats_body<ModelCfg>(a); }\n"
+           "extern \"C\" __global__ void __launch_bounds__(64 * ModelCfg::STATS_WAVES) crbm_stats(crbm::StatsArgs a) { crbm::stats_body<ModelCfg>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_free_energy(crbm::FeArgs a) { crbm::free_energy_body<ModelCfg>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_hit_summary(crbm::HitArgs a) { crbm::hit_summary_body<ModelCfg>(a); }\n",
            attr, K, M, DS, G);

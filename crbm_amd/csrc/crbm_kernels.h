@@ -798,9 +798,9 @@ __device__ void stats_body(const StatsArgs& a) {
     }
 
   const bool owner = blockIdx.y == 0;   // h / sb / letter counts are accumulated once
-  float hs0[KP], hs1[KP], sb[KP];
-#pragma unroll
-  for (int q = 0; q < KP; ++q) { hs0[q] = 0.f; hs1[q] = 0.f; sb[q] = 0.f; }
+  // (the H and sparsity-bias sums are not accumulated per thread: every hidden position
+  // pairs with exactly one letter at j = 0, so sum_s P[k,s] = sum_a VH[k,a,0] -- the block
+  // derives them from its combined vh / sw sums at the end)
   float vc0 = 0.f, vc1 = 0.f, vc2 = 0.f, vc3 = 0.f;
 
   const int grp = lane >> 4, lj = lane & 15;           // letter class of this lane group, its filter column
@@ -863,20 +863,14 @@ __device__ void stats_body(const StatsArgs& a) {
         float z[KP];
         conv_gather<C>(Tf, win, z);
 #pragma unroll
-        for (int q = 0; q < KP; ++q) {
-          z[q] = sigmoid_z(z[q]);
-          if (owner) { hs0[q] += z[q]; sb[q] += z[q] * (1.f - z[q]); }
-        }
+        for (int q = 0; q < KP; ++q) z[q] = sigmoid_z(z[q]);
 #pragma unroll
         for (int q = 0; q < KP / 4; ++q)
           reinterpret_cast<float4*>(p0)[q] = make_float4(z[4 * q], z[4 * q + 1], z[4 * q + 2], z[4 * q + 3]);
         if (C::DS) {
           conv_gather<C>(Tr, win, z);
 #pragma unroll
-          for (int q = 0; q < KP; ++q) {
-            z[q] = sigmoid_z(z[q]);
-            if (owner) hs1[q] += z[q];
-          }
+          for (int q = 0; q < KP; ++q) z[q] = sigmoid_z(z[q]);
 #pragma unroll
           for (int q = 0; q < KP / 4; ++q)
             reinterpret_cast<float4*>(p1)[q] = make_float4(z[4 * q], z[4 * q + 1], z[4 * q + 2], z[4 * q + 3]);
@@ -1026,36 +1020,29 @@ __device__ void stats_body(const StatsArgs& a) {
       if (C::DS) out[a.off_vh1 + i] = buf[KAM + i];
       if (a.want_sparsity) out[a.off_sw + i] = MERGE ? buf[i] - buf[2 * KAM + i] : buf[2 * KAM + i];
     }
+    // H and sparsity-bias sums of the block: the four letters of filter column 0
+    for (int k = threadIdx.x; k < K; k += nthr) {
+      auto col0 = [&](const float* t) { return (t[(k * 4) * M] + t[(k * 4 + 1) * M]) + (t[(k * 4 + 2) * M] + t[(k * 4 + 3) * M]); };
+      const float hsum = col0(buf);
+      out[a.off_h0 + k] = hsum;
+      if (C::DS) out[a.off_h1 + k] = col0(buf + KAM);
+      if (a.want_sparsity) out[a.off_sb + k] = MERGE ? hsum - col0(buf + 2 * KAM) : col0(buf + 2 * KAM);
+    }
     __syncthreads();   // xch (below) lives in the same LDS
   }
   if (owner && !(a.debug & 8)) {
-    // per-thread sums -> wave (shuffles) -> block (one LDS exchange), fixed order;
-    // stored by one thread per value
-    float* out0 = out;
-    constexpr int NV = 3 * KP + 4;
-#pragma unroll
-    for (int q = 0; q < KP; ++q) {
-      const float s0v = wave_sum(hs0[q]), s1v = wave_sum(hs1[q]), s2v = wave_sum(sb[q]);
-      if (lane == 0) { xch[wave * NV + q] = s0v; xch[wave * NV + KP + q] = s1v; xch[wave * NV + 2 * KP + q] = s2v; }
-    }
+    // letter counts: per-thread sums -> wave (DPP) -> block (one LDS exchange), fixed order
     {
       const float c0v = wave_sum(vc0), c1v = wave_sum(vc1), c2v = wave_sum(vc2), c3v = wave_sum(vc3);
       if (lane == 0) {
-        xch[wave * NV + 3 * KP] = c0v; xch[wave * NV + 3 * KP + 1] = c1v;
-        xch[wave * NV + 3 * KP + 2] = c2v; xch[wave * NV + 3 * KP + 3] = c3v;
+        xch[wave * 4] = c0v; xch[wave * 4 + 1] = c1v; xch[wave * 4 + 2] = c2v; xch[wave * 4 + 3] = c3v;
       }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < NV; i += nthr) {
+    if (threadIdx.x < 4) {
       float t = 0.f;
-      for (int w = 0; w < nwaves; ++w) t += xch[w * NV + i];
-      const int vg = i / KP, q = i - vg * KP;
-      if (i >= 3 * KP) out0[a.off_v + (i - 3 * KP)] = t;
-      else if (q < K) {
-        if (vg == 0) out0[a.off_h0 + q] = t;
-        else if (vg == 1) { if (C::DS) out0[a.off_h1 + q] = t; }
-        else if (a.want_sparsity) out0[a.off_sb + q] = t;
-      }
+      for (int w = 0; w < nwaves; ++w) t += xch[w * 4 + threadIdx.x];
+      out[a.off_v + threadIdx.x] = t;
     }
   }
 }

@@ -84,11 +84,21 @@ struct Cfg {
 #ifndef CRBM_STATS_UNR
 #define CRBM_STATS_UNR 4
 #endif
-  static constexpr int STATS_UNR = (KP <= 16) ? CRBM_STATS_UNR : 2;   // parked rows in flight per lane
+#ifndef CRBM_STATS_UNR_BIG
+#define CRBM_STATS_UNR_BIG 2
+#endif
+  static constexpr int STATS_UNR = (KP <= 16) ? CRBM_STATS_UNR : CRBM_STATS_UNR_BIG;   // parked rows in flight per lane
   // small models: the forward vh pass also accumulates sum P^2 (sw = vh - that), so the
   // sparsity statistic costs no second walk over the parked rows; large models keep a
   // separate pass (the second accumulator set would not fit the register file)
   static constexpr bool STATS_MERGE = KP * cdiv(M, 16) <= 32;
+  // waves per block of the statistics kernel: models whose tables leave room for only one
+  // block per CU run 8 waves in it (two per SIMD) instead of 4
+  static constexpr long STATS_FIXED4 = (long)(1 + DS) * (TAB + M * KP) * 4 + 4L * 4 * STATS_CH * 2 + 4L * (3 * KP + 4) * 4;
+#ifndef CRBM_STATS_WAVES_BIG
+#define CRBM_STATS_WAVES_BIG 8
+#endif
+  static constexpr int STATS_WAVES = (STATS_FIXED4 + 24 * 1024 > 78 * 1024) ? CRBM_STATS_WAVES_BIG : 4;
   static constexpr int OFF_TR = DS ? TAB : END2;
   static constexpr int TABLES_ALL = DS ? END2 : END2 + TAB;
   // hit-summary kernel: a lane keeps the position sums of HIT_NI positions in registers
@@ -100,7 +110,7 @@ struct ModelShape {
   int K, M, DS, G;
   int NQ, KP, NW, NG, ROWS, TAB, NCH, DENSE, TV, WS, NGRP;
   int OFF_TF, OFF_TR, OFF_TV, OFF_TVR, OFF_C, TABLES, OFF_WS, END2, SP_TABLES, TABLES_ALL;
-  int HIT_NI, STATS_MERGE;
+  int HIT_NI, STATS_MERGE, STATS_WAVES;
 };
 inline ModelShape model_shape(int K, int M, int DS, int G) {
   ModelShape s;
@@ -119,6 +129,10 @@ inline ModelShape model_shape(int K, int M, int DS, int G) {
   s.OFF_TR = DS ? s.TAB : s.END2; s.TABLES_ALL = DS ? s.END2 : s.END2 + s.TAB;
   s.HIT_NI = (48 / s.KP) < 1 ? 1 : ((48 / s.KP) > 4 ? 4 : (48 / s.KP));
   s.STATS_MERGE = s.KP * cdiv(M, 16) <= 32;
+  {
+    const long fixed4 = (long)(1 + DS) * (s.TAB + M * s.KP) * 4 + 4L * 4 * 256 * 2 + 4L * (3 * s.KP + 4) * 4;
+    s.STATS_WAVES = (fixed4 + 24 * 1024 > 78 * 1024) ? 8 : 4;
+  }
   return s;
 }
 
@@ -168,7 +182,7 @@ inline StatsLayout stats_layout(const ModelShape& ms, int want_sparsity, int Lh,
   StatsLayout s;
   const int K = ms.K, M = ms.M, KAM = K * 4 * M;
   s.npasses = 1 + ms.DS + (ms.STATS_MERGE ? 0 : want_sparsity);
-  const int waves = 4;
+  const int waves = ms.STATS_WAVES;
   s.threads = 64 * waves;
   s.PB = s.npasses <= 1 ? 1 : (s.npasses == 2 ? 2 : 4);
   s.parts = waves / s.PB;
