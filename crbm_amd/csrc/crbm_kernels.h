@@ -883,17 +883,19 @@ __device__ void stats_body(const StatsArgs& a) {
         }
       }
     }
-    // letter counts: every visible position exactly once (segment 0 of each chain)
+    // letter counts: every visible position exactly once (segment 0 of each chain), 16
+    // positions per word with four popcounts on the low / high bit planes
     if (owner && seg == 0) {
-      const uint32_t vitems = (uint32_t)ns * (uint32_t)a.L;
-      for (uint32_t i = threadIdx.x; i < vitems; i += nthr) {
-        const uint32_t nl = fastdiv(i, a.divL);
-        const int p = (int)(i - nl * (uint32_t)a.L);
+      const int nw16 = (a.L + 15) >> 4;                         // letter words that hold positions
+      for (int i = threadIdx.x; i < ns * nw16; i += nthr) {
+        const int nl = i / nw16, w = i - nl * nw16;
         // whole rows are staged when a chain is one segment; otherwise read the row from global memory
-        const uint32_t word = a.nseg == 1 ? lw[(size_t)nl * a.LWt + (p >> 4)] : a.letters[(size_t)(n0 + nl) * a.LW + (p >> 4)];
-        const uint32_t l = (word >> (2 * (p & 15))) & 3u;
-        vc0 += l == 0u ? 1.f : 0.f; vc1 += l == 1u ? 1.f : 0.f;
-        vc2 += l == 2u ? 1.f : 0.f; vc3 += l == 3u ? 1.f : 0.f;
+        const uint32_t word = a.nseg == 1 ? lw[(size_t)nl * a.LWt + w] : a.letters[(size_t)(n0 + nl) * a.LW + w];
+        const int valid = min(16, a.L - 16 * w);                // positions of this word inside the sequence
+        const uint32_t plane = valid >= 16 ? 0x55555555u : ((1u << (2 * valid)) - 1u) & 0x55555555u;
+        const uint32_t lo = word & plane, hi = (word >> 1) & plane;
+        vc0 += (float)__popc(plane & ~lo & ~hi); vc1 += (float)__popc(lo & ~hi);
+        vc2 += (float)__popc(hi & ~lo);          vc3 += (float)__popc(lo & hi);
       }
     }
     __syncthreads();
