@@ -1,0 +1,59 @@
+"""Randomised parity soak: random model shapes / batch shapes, one PCD-k training step and a
+few Gibbs steps against the float64 oracle.  usage: python tools/soak_parity.py [n_cases] [seed]
+(test infrastructure: imports the oracle)"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle.crbm_oracle import synthetic_onehot  # noqa: E402
+import test_gpu_parity as T  # noqa: E402
+
+if __name__ == "__main__":
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    bad = 0
+    for case in range(n_cases):
+        big = case % 4 == 3                              # every fourth case: large model / long sequences
+        K = int(rng.integers(1, 65 if big else 41))
+        M = int(rng.integers(1, 33 if big else 29))
+        ds = bool(rng.integers(0, 2))
+        Lf = int(rng.integers(1, 400 if big else 120))
+        B = int(rng.integers(1, 40))
+        n = int(rng.integers(1, 40))
+        L = M + int(rng.integers(0, 700 if big else 150))
+        k = int(rng.integers(1, 4))
+        variant = ["", "dense", "sparse"][int(rng.integers(0, 3))]
+        if variant:
+            os.environ["CRBM_TOPDOWN"] = variant
+        else:
+            os.environ.pop("CRBM_TOPDOWN", None)
+        t0 = time.time()
+        try:
+            m, o = T.make_pair(K, M, ds=ds, batchsize=B, cd_k=k, Lf=Lf, bshift=float(rng.uniform(2, 7)), wscale=float(rng.uniform(0.3, 1.5)))
+            D = synthetic_onehot(n, L, seed=case)
+            m._trainingFct(D)
+            o.train_step(D)
+            np.testing.assert_allclose(m.motifs.get_value(), o.W, rtol=2e-4, atol=2e-5)
+            np.testing.assert_allclose(m.bias.get_value(), o.b, rtol=2e-4, atol=2e-5)
+            np.testing.assert_allclose(m.c.get_value(), o.c, rtol=2e-4, atol=2e-5)
+            h, hp = m.get_fantasy()
+            mism = float((h != o.fantasy_h).mean())
+            assert mism < 2e-3, ("chain mismatch", mism)
+            np.testing.assert_allclose(m.freeEnergy(D), o.freeEnergy(D), rtol=2e-4, atol=1e-5)
+            P = o.motifHitProbs(D)
+            s = m.motifHitSummary(D)
+            np.testing.assert_allclose(s["max"], P.max(axis=(2, 3)), rtol=2e-4, atol=1e-6)
+            np.testing.assert_allclose(s["position_mean"], P.mean(axis=(0, 2)), rtol=2e-4, atol=1e-6)
+            status = "ok"
+        except Exception as e:   # report every failing shape, keep going
+            bad += 1
+            status = "FAIL %s" % (str(e)[:300].replace("\n", " "))
+        print("case %d K=%d M=%d ds=%d Lf=%d B=%d n=%d L=%d k=%d td=%s: %s (%.1fs)" % (
+            case, K, M, ds, Lf, B, n, L, k, variant or "auto", status, time.time() - t0), flush=True)
+    print("SOAK DONE, failures:", bad)
+    sys.exit(1 if bad else 0)
