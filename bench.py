@@ -191,13 +191,15 @@ def main():
         alg_bytes = algorithmic_bytes_per_seq(cfg["K"], cfg["M"], cfg["L"], cfg["ds"]) * cfg["chains"] * k
         avg_launch_s = kernel_s / launches
         achieved = alg_bytes / avg_launch_s / 1e9
-        traffic = None
+        traffic = valu_insts = None
         tfile = os.path.join(ROOT, "profiles", "gibbs_traffic.json")
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get(args.config, {}).get("hbm_bytes_per_launch")
+                pmc = json.load(open(tfile)).get(args.config, {})
+                traffic = pmc.get("hbm_bytes_per_launch")
+                valu_insts = pmc.get("valu_wave_insts_per_launch")
             except Exception:
-                traffic = None
+                traffic = valu_insts = None
         out = {
             "metric": "Gibbs-steps/sec (PCD-1) at batch 8192x4x200, 10 motifs len 15" if args.config == "cfg2"
                       else "Gibbs-steps/sec, " + cfg["desc"],
@@ -219,6 +221,9 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "state_bytes_per_launch": int(lib.crbm_gibbs_state_bytes(h)),
                          "us_per_step_at_16_steps_per_launch": us_per_step_k16,
+                         # what actually binds the kernel (PMC, profiles/): VALU issue time of one launch
+                         "valu_wave_insts_per_launch": valu_insts,
+                         "valu_issue_us": (valu_insts * 4 / (256 * 4) / 2.4e3) if valu_insts else None,
                          "note": "achieved = algorithmic bytes of the dense fp32 layout (SURVEY 8d) / launch time; "
                                  "the kernel keeps chain state bit-packed, so real HBM traffic is state_bytes_per_launch"},
             "launch": {"grid": info.gibbs_grid, "block": info.gibbs_block, "chains_per_tile": info.gibbs_seqs_per_tile,
