@@ -112,7 +112,8 @@ struct crbm_handle {
   uint32_t* d_flags = nullptr;
   unsigned long long* d_ones = nullptr;
   DevBuf<float> stage, stage2, out_a, out_b, out_c;
-  DevBuf<uint32_t> letters, masks_tmp;
+  DevBuf<uint32_t> letters, letters2, masks_tmp;   // (…2: second set of the double-buffered host-input sweeps)
+  DevBuf<float> out_a2, out_b2;
   DevBuf<uint32_t> dataset[CRBM_DATASET_SLOTS];   // resident data sets (slot 0: training, slot 1: test by convention)
   DevBuf<float> partials, partials2;
   float* d_sums = nullptr;
@@ -650,7 +651,7 @@ int crbm_destroy(crbm_handle* h) {
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   h->stage.release(); h->stage2.release(); h->out_a.release(); h->out_b.release(); h->out_c.release();
-  h->letters.release(); h->masks_tmp.release();
+  h->letters.release(); h->letters2.release(); h->masks_tmp.release(); h->out_a2.release(); h->out_b2.release();
   for (auto& d : h->dataset) d.release(); h->partials.release(); h->partials2.release();
   if (h->jk.module) (void)hipModuleUnload(h->jk.module);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1037,6 +1038,73 @@ int resident_source(crbm_handle* h, int start, int end, RowSource* src) {
   return CRBM_OK;
 }
 
+// ---- double-buffered sweeps over host input ---------------------
+// Slab i is staged, encoded and processed on stream (i & 1) with buffer set (i & 1);
+// its outputs are collected only after slab i+1 has been enqueued, so the host->device
+// copy of one slab overlaps the kernels of the other.  Resident sources use set 0 only.
+struct SweepSet {
+  hipStream_t st;
+  DevBuf<float>* stage;
+  DevBuf<uint32_t>* letters;
+  DevBuf<float>* oa;
+  DevBuf<float>* ob;
+};
+SweepSet sweep_set(crbm_handle* h, int i) {
+  if (i & 1) return SweepSet{h->stream2, &h->stage2, &h->letters2, &h->out_a2, &h->out_b2};
+  return SweepSet{h->stream, &h->stage, &h->letters, &h->out_a, &h->out_b};
+}
+// rows per slab: host input uses small slabs so that there is something to overlap
+int sweep_slab(const RowSource& src, size_t out_bytes_per_row) {
+  const size_t per_row = src.in_bytes_per_row() + out_bytes_per_row;
+  int slab = slab_rows(src.n, per_row);
+  if (!src.resident && !getenv("CRBM_SLAB_BYTES")) slab = std::min<size_t>(slab, std::max<size_t>(1, (32u << 20) / std::max<size_t>(per_row, 1)));
+  return slab;
+}
+// enqueue staging + encoding of rows [start, start+cnt) on the set's stream (no flag check: sweep_finish)
+int sweep_rows(crbm_handle* h, const RowSource& src, int start, int cnt, const SweepSet& set, const uint32_t** out) {
+  const int L = src.L, LW = letter_words(L);
+  if (src.resident) {
+    *out = src.resident + (size_t)start * LW;
+    return CRBM_OK;
+  }
+  HIPCHK(set.letters->ensure((size_t)cnt * LW));
+  *out = set.letters->p;
+  const int grid = grid_for((long)cnt * LW, 256, h->num_cu * 8);
+  if (src.onehot) {
+    const size_t count = (size_t)cnt * 4 * L;
+    HIPCHK(set.stage->ensure(count));
+    HIPCHK(hipMemcpyAsync(set.stage->p, src.onehot + (size_t)start * 4 * L, count * sizeof(float), hipMemcpyHostToDevice, set.st));
+    EncodeArgs a;
+    a.v = set.stage->p; a.letters = set.letters->p; a.flags = h->d_flags;
+    a.n = cnt; a.L = L; a.LW = LW;
+    hipLaunchKernelGGL(encode_onehot_kernel, dim3(grid), dim3(256), 0, set.st, a);
+  } else {
+    const size_t bytes = (size_t)cnt * L;
+    HIPCHK(set.stage->ensure((bytes + 3) / 4));
+    HIPCHK(hipMemcpyAsync(set.stage->p, src.codes + (size_t)start * L, bytes, hipMemcpyHostToDevice, set.st));
+    EncodeCodesArgs a;
+    a.codes = reinterpret_cast<const unsigned char*>(set.stage->p);
+    a.letters = set.letters->p; a.flags = h->d_flags;
+    a.n = cnt; a.L = L; a.LW = LW;
+    hipLaunchKernelGGL(encode_codes_kernel, dim3(grid), dim3(256), 0, set.st, a);
+  }
+  HIPCHK(hipGetLastError());
+  return CRBM_OK;
+}
+// tables built and visible to both streams before a sweep starts
+int sweep_begin(crbm_handle* h) {
+  int rc = ensure_tables(h);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return CRBM_OK;
+}
+// both streams idle, then the one-hot / code validity flags of every slab at once
+int sweep_finish(crbm_handle* h, const RowSource& src) {
+  HIPCHK(hipStreamSynchronize(h->stream2));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return src.resident ? CRBM_OK : check_flags(h);
+}
+
 int hit_probs_any(crbm_handle* h, const RowSource& src, float* out) {
   int rc = check_data_shape(h, src.n, src.L);
   if (rc) return rc;
@@ -1059,38 +1127,52 @@ int hit_probs_any(crbm_handle* h, const RowSource& src, float* out) {
   return CRBM_OK;
 }
 
-// free energies of n packed rows into h->out_a (per sequence) / h->out_b (per motif), no copy
-int launch_free_energy(crbm_handle* h, const uint32_t* rows, int n, int L) {
-  int rc = ensure_tables(h);
+// free energies of n packed rows into the set's outputs (per sequence / per motif), no copy
+int launch_free_energy(crbm_handle* h, const uint32_t* rows, int n, int L, const SweepSet& set) {
+  int rc = ensure_tables(h);   // no-op inside a sweep (sweep_begin has done it)
   if (rc) return rc;
-  HIPCHK(h->out_a.ensure((size_t)n));
-  HIPCHK(h->out_b.ensure((size_t)n * h->K));
+  HIPCHK(set.oa->ensure((size_t)n));
+  HIPCHK(set.ob->ensure((size_t)n * h->K));
   FeArgs a;
   a.tables = h->d_tables;
   a.letters = rows;
   a.n = n; a.L = L; a.Lh = L - h->M + 1; a.LW = letter_words(L);
-  a.fe = h->out_a.p; a.fem = h->out_b.p;
+  a.fe = set.oa->p; a.fem = set.ob->p;
   const unsigned gx = (unsigned)std::max(1, std::min((n + 3) / 4, h->num_cu * 8));
-  HIPCHK(jit_launch(h->jk.free_energy, a, gx, 1, 256, (unsigned)((1 + h->ds) * tab_bytes(h)), h->stream));
+  HIPCHK(jit_launch(h->jk.free_energy, a, gx, 1, 256, (unsigned)((1 + h->ds) * tab_bytes(h)), set.st));
   return CRBM_OK;
 }
 
 int free_energy_any(crbm_handle* h, const RowSource& src, float* fe, float* fem) {
   int rc = check_data_shape(h, src.n, src.L);
   if (rc) return rc;
-  const int slab = slab_rows(src.n, src.in_bytes_per_row() + ((size_t)h->K + 1) * sizeof(float));
-  for (int start = 0; start < src.n; start += slab) {
+  rc = sweep_begin(h);
+  if (rc) return rc;
+  const int slab = sweep_slab(src, ((size_t)h->K + 1) * sizeof(float));
+  int prev_start = -1, prev_cnt = 0;
+  SweepSet prev = sweep_set(h, 0);
+  auto collect = [&]() -> int {     // outputs of the previous slab -> host
+    if (prev_start < 0) return CRBM_OK;
+    if (fe) HIPCHK(hipMemcpyAsync(fe + prev_start, prev.oa->p, (size_t)prev_cnt * sizeof(float), hipMemcpyDeviceToHost, prev.st));
+    if (fem) HIPCHK(hipMemcpyAsync(fem + (size_t)prev_start * h->K, prev.ob->p, (size_t)prev_cnt * h->K * sizeof(float), hipMemcpyDeviceToHost, prev.st));
+    HIPCHK(hipStreamSynchronize(prev.st));
+    return CRBM_OK;
+  };
+  for (int start = 0, i = 0; start < src.n; start += slab, ++i) {
     const int cnt = std::min(slab, src.n - start);
+    const SweepSet set = sweep_set(h, src.resident ? 0 : i);
     const uint32_t* rows = nullptr;
-    rc = source_rows(h, src, start, cnt, &rows);
+    rc = sweep_rows(h, src, start, cnt, set, &rows);
     if (rc) return rc;
-    rc = launch_free_energy(h, rows, cnt, src.L);
+    rc = launch_free_energy(h, rows, cnt, src.L, set);
     if (rc) return rc;
-    if (fe && (rc = copy_out(h, fe + start, h->out_a.p, (size_t)cnt))) return rc;
-    if (fem && (rc = copy_out(h, fem + (size_t)start * h->K, h->out_b.p, (size_t)cnt * h->K))) return rc;
-    HIPCHK(hipStreamSynchronize(h->stream));
+    rc = collect();
+    if (rc) return rc;
+    prev = set; prev_start = start; prev_cnt = cnt;
   }
-  return CRBM_OK;
+  rc = collect();
+  if (rc) return rc;
+  return sweep_finish(h, src);
 }
 
 int eval_data_any(crbm_handle* h, const RowSource& src, float* mfe, float* nmh) {
@@ -1106,7 +1188,7 @@ int eval_data_any(crbm_handle* h, const RowSource& src, float* mfe, float* nmh) 
     const uint32_t* rows = nullptr;
     rc = source_rows(h, src, start, cnt, &rows);
     if (rc) return rc;
-    rc = launch_free_energy(h, rows, cnt, L);
+    rc = launch_free_energy(h, rows, cnt, L, sweep_set(h, 0));
     if (rc) return rc;
     rc = copy_out(h, fe.data(), h->out_a.p, (size_t)cnt);
     if (rc) return rc;
@@ -1129,8 +1211,6 @@ int eval_data_any(crbm_handle* h, const RowSource& src, float* mfe, float* nmh) 
 int hit_summary_any(crbm_handle* h, const RowSource& src, float* hmax, float* hmean, float* posmean) {
   int rc = check_data_shape(h, src.n, src.L);
   if (rc) return rc;
-  rc = ensure_tables(h);
-  if (rc) return rc;
   const int n = src.n, L = src.L, Lh = L - h->M + 1, K = h->K;
   const int tabs = (h->ds ? 1 : 2) * tab_bytes(h);
   // a block covers one chunk of 64*HIT_NI positions; its (PC,K) sums share the LDS with the tables
@@ -1138,39 +1218,51 @@ int hit_summary_any(crbm_handle* h, const RowSource& src, float* hmax, float* hm
   const int nchunks = (Lh + PC - 1) / PC;
   const unsigned lds = (unsigned)(tabs + (size_t)PC * K * 4);
   ARGCHK(lds <= 160u * 1024u, "model too large for the hit-summary kernel");
-  const int slab = slab_rows(n, src.in_bytes_per_row() + (size_t)2 * K * sizeof(float));
-  HIPCHK(h->out_a.ensure((size_t)slab * K));
-  HIPCHK(h->out_b.ensure((size_t)slab * K));
   if (posmean) {
     HIPCHK(h->out_c.ensure((size_t)K * Lh));
     HIPCHK(hipMemsetAsync(h->out_c.p, 0, (size_t)K * Lh * 4, h->stream));
   }
-  std::vector<float> sums;
-  for (int start = 0; start < n; start += slab) {
+  rc = sweep_begin(h);          // also orders the memset before both streams' kernels
+  if (rc) return rc;
+  const int slab = sweep_slab(src, (size_t)2 * K * sizeof(float));
+  int prev_start = -1, prev_cnt = 0;
+  SweepSet prev = sweep_set(h, 0);
+  auto collect = [&]() -> int {
+    if (prev_start < 0) return CRBM_OK;
+    if (hmax) HIPCHK(hipMemcpyAsync(hmax + (size_t)prev_start * K, prev.oa->p, (size_t)prev_cnt * K * sizeof(float), hipMemcpyDeviceToHost, prev.st));
+    if (hmean) HIPCHK(hipMemcpyAsync(hmean + (size_t)prev_start * K, prev.ob->p, (size_t)prev_cnt * K * sizeof(float), hipMemcpyDeviceToHost, prev.st));
+    HIPCHK(hipStreamSynchronize(prev.st));
+    return CRBM_OK;
+  };
+  for (int start = 0, i = 0; start < n; start += slab, ++i) {
     const int cnt = std::min(slab, n - start);
+    const SweepSet set = sweep_set(h, src.resident ? 0 : i);
     const uint32_t* rows = nullptr;
-    rc = source_rows(h, src, start, cnt, &rows);
+    rc = sweep_rows(h, src, start, cnt, set, &rows);
     if (rc) return rc;
+    HIPCHK(set.oa->ensure((size_t)cnt * K));
+    HIPCHK(set.ob->ensure((size_t)cnt * K));
     if (nchunks > 1) {
-      HIPCHK(hipMemsetAsync(h->out_a.p, 0, (size_t)cnt * K * 4, h->stream));
-      HIPCHK(hipMemsetAsync(h->out_b.p, 0, (size_t)cnt * K * 4, h->stream));
+      HIPCHK(hipMemsetAsync(set.oa->p, 0, (size_t)cnt * K * 4, set.st));
+      HIPCHK(hipMemsetAsync(set.ob->p, 0, (size_t)cnt * K * 4, set.st));
     }
     HitArgs a;
     a.tables = h->d_tables; a.letters = rows;
     a.n = cnt; a.L = L; a.Lh = Lh; a.LW = letter_words(L);
-    a.hmax = hmax ? h->out_a.p : nullptr;
-    a.hsum = hmean ? h->out_b.p : nullptr;
-    a.pos = posmean ? h->out_c.p : nullptr;
+    a.hmax = hmax ? set.oa->p : nullptr;
+    a.hsum = hmean ? set.ob->p : nullptr;
+    a.inv_Lh = 1.0f / (float)Lh;
+    a.pos = posmean ? h->out_c.p : nullptr;     // both streams add atomically
     const unsigned gx = (unsigned)std::max(1, std::min((cnt + 3) / 4, std::max(1, h->num_cu * 8 / nchunks)));
-    HIPCHK(jit_launch(h->jk.hit_summary, a, gx, (unsigned)nchunks, 256, lds, h->stream));
-    if (hmax && (rc = copy_out(h, hmax + (size_t)start * K, h->out_a.p, (size_t)cnt * K))) return rc;
-    if (hmean && (rc = copy_out(h, hmean + (size_t)start * K, h->out_b.p, (size_t)cnt * K))) return rc;
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(jit_launch(h->jk.hit_summary, a, gx, (unsigned)nchunks, 256, lds, set.st));
+    rc = collect();
+    if (rc) return rc;
+    prev = set; prev_start = start; prev_cnt = cnt;
   }
-  if (hmean) {
-    const float inv = 1.0f / (float)Lh;
-    for (size_t i = 0; i < (size_t)n * K; ++i) hmean[i] *= inv;
-  }
+  rc = collect();
+  if (rc) return rc;
+  rc = sweep_finish(h, src);
+  if (rc) return rc;
   if (posmean) {
     rc = copy_out(h, posmean, h->out_c.p, (size_t)K * Lh);
     if (rc) return rc;

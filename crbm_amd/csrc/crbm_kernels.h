@@ -1133,7 +1133,8 @@ struct HitArgs {
   const uint32_t* letters;
   int32_t n, L, Lh, LW;
   float* hmax;      // (n,K) max over positions   (zero-initialised when gridDim.y > 1)
-  float* hsum;      // (n,K) sum over positions   (zero-initialised when gridDim.y > 1)
+  float* hsum;      // (n,K) mean over positions  (zero-initialised when gridDim.y > 1)
+  float inv_Lh;     // 1 / Lh
   float* pos;       // (K,Lh) sum over sequences, accumulated atomically (zero-initialised), or null
 };
 
@@ -1187,10 +1188,10 @@ __device__ void hit_summary_body(const HitArgs& a) {
         const size_t idx = (size_t)nn * K + q;
         if (gridDim.y == 1) {
           if (a.hmax) a.hmax[idx] = m;
-          if (a.hsum) a.hsum[idx] = t;
+          if (a.hsum) a.hsum[idx] = t * a.inv_Lh;
         } else {   // probabilities are >= 0: their bit patterns order like unsigned integers
           if (a.hmax) atomicMax(reinterpret_cast<unsigned int*>(a.hmax) + idx, __float_as_uint(m));
-          if (a.hsum) atomicAdd(a.hsum + idx, t);
+          if (a.hsum) atomicAdd(a.hsum + idx, t * a.inv_Lh);
         }
       }
     }

@@ -248,7 +248,7 @@ int emu_hit_summary(int id, const float* tables, const uint32_t* letters, int n,
                      float* pos, int grid, int threads) {
   HitArgs a;
   a.tables = tables; a.letters = letters; a.n = n; a.L = L; a.LW = letter_words(L);
-  a.hmax = hmax; a.hsum = hsum; a.pos = pos;
+  a.hmax = hmax; a.hsum = hsum; a.pos = pos; a.inv_Lh = 1.0f;   // the harness divides by Lh itself
   CFG_DISPATCH(id, (a.Lh = L - C::M + 1,
                     emu::launch([&] { hit_summary_body<C>(a); }, dim3(grid, (a.Lh + 64 * C::HIT_NI - 1) / (64 * C::HIT_NI)),
                                 dim3(threads), (size_t)(C::DS ? 1 : 2) * C::TAB * 4 + (size_t)64 * C::HIT_NI * C::K * 4)));
