@@ -803,7 +803,19 @@ __device__ void stats_body(const StatsArgs& a) {
   // derives them from its combined vh / sw sums at the end)
   float vc0 = 0.f, vc1 = 0.f, vc2 = 0.f, vc3 = 0.f;
 
-  const int grp = lane >> 4, lj = lane & 15;           // letter class of this lane group, its filter column
+  // letter class of this lane and its filter column.  The 16 lanes of a class are one of the
+  // four lane groups the LDS serves a ds_read_b128 in ({0-3,12-15,20-27}, {4-11,16-19,28-31}
+  // and the same + 32): the 16 consecutive parked rows they read then fall on 16 different
+  // 16-byte bank slots (row stride 12 dwords: slot = 3*row mod 16 is a bijection) and the read
+  // is conflict-free.  With contiguous 16-lane classes every hardware group mixed two classes
+  // at unrelated offsets and almost always took two cycles.
+  int grp, lj;
+  {
+    const int l5 = lane & 31;
+    const bool second = (l5 >= 4 && l5 < 12) || (l5 >= 16 && l5 < 20) || l5 >= 28;
+    grp = 2 * (lane >> 5) + (second ? 1 : 0);
+    lj = l5 < 4 ? l5 : l5 < 12 ? l5 - 4 : l5 < 20 ? l5 - 8 : l5 < 28 ? l5 - 12 : l5 - 16;
+  }
   const int ngroups = (a.n + a.S - 1) / a.S;
   const int ntiles = ngroups * a.nseg;
   // software prefetch of a tile's letter words (global memory latency is otherwise
