@@ -580,6 +580,7 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
   hh->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   // launch geometry, then the model-specific kernels (hiprtc; cached on disk)
   if (hh->ms.STATS_WAVES == 8) hh->ms.STATS_WAVES = env_int("CRBM_STATS_WAVES_BIG", 8);   // experiment knob; must match -DCRBM_STATS_WAVES_BIG
+  else hh->ms.STATS_WAVES = env_int("CRBM_STATS_WAVES_SMALL", 4);                        // experiment knob; must match -DCRBM_STATS_WAVES_SMALL
   hh->has_dense = hh->ms.DENSE != 0;
   for (int v = hh->has_dense ? 0 : 1; v < 2; ++v) {
     const GibbsGeom geom = choose_gibbs_geometry(hh->ms, hh->Lf, hh->B, hh->num_cu, v == 1);

@@ -98,7 +98,10 @@ struct Cfg {
 #ifndef CRBM_STATS_WAVES_BIG
 #define CRBM_STATS_WAVES_BIG 8
 #endif
-  static constexpr int STATS_WAVES = (STATS_FIXED4 + 24 * 1024 > 78 * 1024) ? CRBM_STATS_WAVES_BIG : 4;
+#ifndef CRBM_STATS_WAVES_SMALL
+#define CRBM_STATS_WAVES_SMALL 4
+#endif
+  static constexpr int STATS_WAVES = (STATS_FIXED4 + 24 * 1024 > 78 * 1024) ? CRBM_STATS_WAVES_BIG : CRBM_STATS_WAVES_SMALL;
   static constexpr int OFF_TR = DS ? TAB : END2;
   static constexpr int TABLES_ALL = DS ? END2 : END2 + TAB;
   // hit-summary kernel: a lane keeps the position sums of HIT_NI positions in registers
