@@ -2,22 +2,34 @@
 """Benchmark of the CRBM hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ...`)
+
+N > 1 without a launcher: this process starts the N ranks itself (plain child
+processes, created before anything here touches a GPU; RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* set for each) and relays rank 0's line.  Under a launcher
+(`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`)
+the ranks read the same variables from the environment.  No torch anywhere:
+rendezvous, barriers and the max-over-ranks ride on crbm_amd.dist.ControlPlane
+(one TCP connection per rank), the data path is Python -> ctypes -> HIP, and
+the per-step all-reduce of the training section is RCCL inside the library.
 
 A *step* is one Gibbs step (v ~ P(v|h), then h ~ P(h|v)) of the persistent
 chain applied to one batch of 8192 chains per GPU -- the PCD-1 Gibbs step of
 BASELINE.json's metric, config #2 (10 motifs of length 15, visible 4x200,
 single-stranded); chains are sharded over ranks with no data-path collective
 (weak scaling), so `value` = N_gpus * K / T in "8192-chain batch Gibbs steps
-per second".  Inputs (chain state, parameters) are resident in HBM when the
-timed region starts.  torch is used only for the rendezvous, the barrier and
-the max-over-ranks; the product path is Python -> ctypes -> HIP.
+per second", T = the HIP-event time of the K launches on the library's stream
+(max over ranks).  The host wall clock around the same region is reported as
+`wall_ms_per_step`.  Inputs (chain state, parameters) are resident in HBM when
+the timed region starts.
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -34,8 +46,9 @@ CONFIGS = {
     "cfg5": dict(K=20, M=15, L=500, ds=True, chains=8192, k=1,
                  desc="20 motifs len 15, doublestranded, batch 8192/GPU x 4x500, PCD-1"),
 }
-TRAIN_WATCHDOG_S = 180
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+TRAIN_WATCHDOG_S = 240
+SPAWN_TIMEOUT_S = 900
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec; the measured copy rate is reported next to it
 
 
 def algorithmic_bytes_per_seq(K, M, L, ds):
@@ -53,11 +66,11 @@ def synthetic_onehot(n, L, seed):
     return out
 
 
-def build_model(cfg, world, rank):
+def build_model(cfg, world, rank, device):
     from crbm_amd import CRBM
     K, M, L = cfg["K"], cfg["M"], cfg["L"]
     model = CRBM(K, M, doublestranded=cfg["ds"], batchsize=cfg["chains"] * world, cd_k=cfg["k"],
-                 fantasy_hidden_len=L - M + 1, seed=2026, device=int(os.environ.get("LOCAL_RANK", "0")))
+                 fantasy_hidden_len=L - M + 1, seed=2026, device=device)
     # W ~ N(0,1) from default_rng(42); b = norm.ppf(rho); c = 0
     W = np.random.default_rng(42).standard_normal((K, 1, 4, M)).astype(np.float32)
     model.motifs.set_value(W)
@@ -65,10 +78,10 @@ def build_model(cfg, world, rank):
     return model
 
 
-def cpu_baseline(cfg, budget_s=12.0):
-    """The oracle's C restatement (oracle/crbm_cpu.c) timed on this host's
-    cores on the same workload: whole 8192-chain batch, as many steps as fit
-    the budget (at least 2)."""
+def cpu_baseline(cfg, budget_s=10.0):
+    """The oracle's C restatement (oracle/crbm_cpu.c) timed on this host's cores on the same
+    workload: whole 8192-chain batch on all cores, a 1/16 batch on one core, plus the NumPy
+    oracle's PCD-5 training step of BASELINE config #1 (the reference's own CPU-runnable case)."""
     from oracle import build_cpu
     lib = ctypes.CDLL(build_cpu.build())
     K, M, L, ds, n = cfg["K"], cfg["M"], cfg["L"], cfg["ds"], cfg["chains"]
@@ -77,26 +90,93 @@ def cpu_baseline(cfg, budget_s=12.0):
     W = np.random.default_rng(42).standard_normal((K, 4, M)).astype(np.float32)
     b = np.full(K, scipy.stats.norm.ppf(0.01, 0, np.sqrt(M)), dtype=np.float32)
     c = np.zeros(4, dtype=np.float32)
-    h = np.zeros((n, K, Lh), dtype=np.float32)
-    hp = np.zeros((n, K, Lh), dtype=np.float32)
-    v = np.zeros((n, 4, L), dtype=np.float32)
     F = ctypes.POINTER(ctypes.c_float)
     P = lambda a: a.ctypes.data_as(F)
     cores = lib.crbm_cpu_max_threads()
 
-    def step(t):
-        lib.crbm_cpu_gibbs_step(P(W), P(b), P(c), K, M, int(ds), P(h), P(hp), P(v), None, None, n, Lh,
-                                ctypes.c_uint64(2026), ctypes.c_uint32(t), ctypes.c_uint32(0), cores)
-    step(0)                                  # warm-up (also burn-in of the chain)
-    t0 = time.perf_counter()
-    done = 0
-    while done < 2 or (time.perf_counter() - t0 < budget_s and done < 1000):
-        step(1 + done)
-        done += 1
-    dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "8192-chain Gibbs steps/s", "cores": int(cores), "kind": "port",
-            "sample": "%d Gibbs steps of the full %d-chain batch (oracle/crbm_cpu.c, dense fp32, OpenMP, %d threads), %.1f s"
-                      % (done, n, cores, dt)}
+    def run(nchains, threads, budget, max_steps):
+        h = np.zeros((nchains, K, Lh), dtype=np.float32)
+        hp = np.zeros((nchains, K, Lh), dtype=np.float32)
+        v = np.zeros((nchains, 4, L), dtype=np.float32)
+
+        def step(t):
+            lib.crbm_cpu_gibbs_step(P(W), P(b), P(c), K, M, int(ds), P(h), P(hp), P(v), None, None, nchains, Lh,
+                                    ctypes.c_uint64(2026), ctypes.c_uint32(t), ctypes.c_uint32(0), threads)
+        step(0)                              # warm-up (also burn-in of the chain)
+        t0 = time.perf_counter()
+        done = 0
+        while done < 2 or (time.perf_counter() - t0 < budget and done < max_steps):
+            step(1 + done)
+            done += 1
+        return done, time.perf_counter() - t0
+
+    done, dt = run(n, cores, budget_s, 1000)
+    sub = max(64, n // 16)
+    done1, dt1 = run(sub, 1, 3.0, 50)
+    out = {"value": done / dt, "unit": "8192-chain Gibbs steps/s", "cores": int(cores), "kind": "port",
+           "sample": "%d Gibbs steps of the full %d-chain batch (oracle/crbm_cpu.c, dense fp32, OpenMP, %d threads), %.1f s"
+                     % (done, n, cores, dt),
+           "value_1thread": (done1 / dt1) * sub / n,
+           "sample_1thread": "%d Gibbs steps of %d chains on 1 thread (%.1f s), scaled to the %d-chain batch"
+                             % (done1, sub, dt1, n)}
+    try:
+        # BASELINE config #1 (1000 x 200 bp, 10 motifs len 15, reference defaults batchsize 20, cd_k 5,
+        # doublestranded): float64 NumPy restatement of convRBM.py:373-438, a bounded number of its
+        # 50 steps per epoch, extrapolated
+        from oracle.crbm_oracle import OracleCRBM, synthetic_onehot as oracle_onehot
+        D = oracle_onehot(1000, 200, seed=1234)
+        o = OracleCRBM(10, 15, doublestranded=True, batchsize=20, cd_k=5, seed=2026,
+                       W=np.random.default_rng(42).standard_normal((10, 1, 4, 15)))
+        t0 = time.perf_counter()
+        nst = 0
+        while nst < 2 or (time.perf_counter() - t0 < 4.0 and nst < 50):
+            o.train_step(D[20 * nst:20 * (nst + 1)])
+            nst += 1
+        per = (time.perf_counter() - t0) / nst
+        out["cfg1_fit_seconds"] = per * 50
+        out["cfg1_sample"] = "%d of the 50 PCD-5 steps of one epoch of config #1 (oracle/crbm_oracle.py, float64 NumPy, " \
+                             "1 thread), %.2f s per step, extrapolated to the epoch" % (nst, per)
+    except Exception as e:                    # the baseline is a report, never a reason to lose the line
+        out["cfg1_fit_seconds"] = None
+        out["cfg1_sample"] = "failed: %s" % str(e)[:200]
+    return out
+
+
+def free_port():
+    s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(n, argv):
+    """Start n ranks of this script (nothing in this process has touched a GPU), relay rank 0's
+    stdout, fail if any rank fails."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out = b""
+    deadline = time.time() + SPAWN_TIMEOUT_S
+    try:
+        out, _ = procs[0].communicate(timeout=SPAWN_TIMEOUT_S)
+        for p in procs[1:]:
+            p.wait(timeout=max(1.0, deadline - time.time()))
+    except subprocess.TimeoutExpired:
+        pass
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    sys.stdout.write(out.decode(errors="replace"))
+    sys.stdout.flush()
+    codes = [p.returncode if p.returncode is not None else 124 for p in procs]
+    return max(abs(c) for c in codes)
 
 
 def main():
@@ -109,66 +189,50 @@ def main():
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--multi-step", action="store_true", help="also time 16 Gibbs steps per launch (informational)")
     args = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+
     cfg = CONFIGS[args.config]
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-
-    import torch
-    # CRBM_BENCH_BACKEND=gloo rehearses the N>1 plumbing on a box with ONE GPU
-    # (all ranks share device 0, no RCCL communicator); the driver's runs use nccl.
-    backend = os.environ.get("CRBM_BENCH_BACKEND", "nccl")
-    if backend == "gloo":
-        local_rank = 0
-        os.environ["LOCAL_RANK"] = "0"
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "gloo":
-            dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    red_dev = "cpu" if backend == "gloo" else "cuda"
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    # CRBM_BENCH_SHARE_GPU=1 rehearses the N > 1 plumbing on a box with ONE GPU: all ranks share
+    # device 0 and the training section runs without the RCCL communicator (which refuses two
+    # ranks on one device).  The driver's runs never set it.
+    share_gpu = os.environ.get("CRBM_BENCH_SHARE_GPU", "0") == "1"
+    device = 0 if share_gpu else local_rank
 
     from crbm_amd import _lib
     from crbm_amd import dist as cdist
     from crbm_amd._lib import fptr
-    model = build_model(cfg, world, rank)
+    control = cdist.ControlPlane(rank, world)
+    model = build_model(cfg, world, rank, device)
     h = model._h()
     lib = model._lib
     k = cfg["k"]
+
+    def barrier():
+        model._call("crbm_sync")      # this rank's stream is idle ...
+        control.barrier()             # ... and so is everybody else's
 
     # chains start at h = 0 (convRBM.py:168); 10 burn-in steps, then warm-up
     model._call("crbm_gibbs_steps", 10)
     for _ in range(args.warmup):
         model._call("crbm_gibbs_steps_async", k)
-    model._call("crbm_sync")
 
-    # ---- timed region: exactly K steps, HIP events on the library's stream ----
+    # ---- timed region: exactly K launches, HIP events on the library's stream ----
     total_ms = ctypes.c_float()
     barrier()
     t0 = time.perf_counter()
     model._call("crbm_time_gibbs", k, args.steps, ctypes.byref(total_ms))
     barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed, total_ms.value / 1e3], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, kernel_s = float(t[0]), float(t[1])
-    else:
-        kernel_s = total_ms.value / 1e3
+    wall = time.perf_counter() - t0
+    wall, kernel_s = control.allreduce_max([wall, total_ms.value / 1e3])
     launches = args.steps
     steps_done = args.steps * k                  # Gibbs steps per rank in the timed region
-    value = world * steps_done / elapsed
+    value = world * steps_done / kernel_s
 
     # informational, opt-in (--multi-step): the same chain advanced 16 steps per launch (no
     # per-launch fixed cost).  Off by default so that every crbm_gibbs launch of a default
@@ -188,24 +252,30 @@ def main():
     if rank == 0:
         info = _lib.CrbmLaunchInfo()
         lib.crbm_get_launch_info(h, ctypes.byref(info))
+        copy_gbs = ctypes.c_float()
+        model._call("crbm_copy_bandwidth", 1 << 30, 5, ctypes.byref(copy_gbs))
         alg_bytes = algorithmic_bytes_per_seq(cfg["K"], cfg["M"], cfg["L"], cfg["ds"]) * cfg["chains"] * k
         avg_launch_s = kernel_s / launches
         achieved = alg_bytes / avg_launch_s / 1e9
-        traffic = valu_insts = None
+        # HBM bytes per launch come from separate rocprofv3 --pmc passes of the same command (they
+        # cannot be collected inside this process); the tracked summary is quoted, with its source
+        traffic = valu_insts = traffic_src = None
         tfile = os.path.join(ROOT, "profiles", "gibbs_traffic.json")
         if os.path.exists(tfile):
             try:
                 pmc = json.load(open(tfile)).get(args.config, {})
                 traffic = pmc.get("hbm_bytes_per_launch")
                 valu_insts = pmc.get("valu_wave_insts_per_launch")
+                traffic_src = pmc.get("source")
             except Exception:
-                traffic = valu_insts = None
+                traffic = valu_insts = traffic_src = None
         out = {
             "metric": "Gibbs-steps/sec (PCD-1) at batch 8192x4x200, 10 motifs len 15" if args.config == "cfg2"
                       else "Gibbs-steps/sec, " + cfg["desc"],
             "value": value, "unit": "8192-chain batch Gibbs steps/s (summed over GPUs)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step": 1e3 * kernel_s / args.steps,
+            "wall_ms_per_step": 1e3 * wall / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.config + ": " + cfg["desc"], "chains_per_gpu": cfg["chains"],
@@ -213,9 +283,13 @@ def main():
                        "hidden": "%dx%d" % (cfg["K"], cfg["L"] - cfg["M"] + 1),
                        "parallelism": "chains sharded over %d GPU(s), no collective in the Gibbs step" % world,
                        "hidden_activity": activity},
+            "timing": "HIP events on the library's stream around the K launches, max over ranks; "
+                      "wall_ms_per_step is the host clock around the same region (barrier + synchronise on both sides)",
             "chain_steps_per_s": value * cfg["chains"],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "measured_copy_gbs": float(copy_gbs.value),
+                         "frac_of_measured_copy": achieved / float(copy_gbs.value) if copy_gbs.value > 0 else None,
                          "kernel": "crbm_gibbs_sparse" if info.gibbs_sparse else "crbm_gibbs",   # name in the rocprofv3 summaries
                          "avg_launch_us": 1e6 * avg_launch_s,
                          "algorithmic_bytes_per_launch": alg_bytes,
@@ -232,7 +306,7 @@ def main():
 
     # The headline line is complete before the secondary section starts.  With N > 1 a
     # watchdog prints it anyway if the RCCL part of the training section should hang on
-    # some rank (a hang must not cost the Gibbs measurement).
+    # some rank (a hang must not cost the Gibbs measurement) -- and exits non-zero.
     done = {"printed": False}
 
     def emit(train_result):
@@ -247,26 +321,26 @@ def main():
 
     watchdog = None
     if world > 1 and not args.no_train:
-        import threading
-
         def bail():
             emit({"error": "training section did not finish within %d s" % TRAIN_WATCHDOG_S})
-            os._exit(0)
+            os._exit(3)
         watchdog = threading.Timer(TRAIN_WATCHDOG_S, bail)
         watchdog.daemon = True
         watchdog.start()
 
     # ---- secondary: full PCD-k training steps (with the RCCL all-reduce when N > 1) ----
     train = None
+    failed = False
     if not args.no_train:
         try:
-            if world > 1 and backend != "gloo":
-                # the 128-byte RCCL id travels over the process group that is already up
-                box = [cdist.make_unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(box, src=0)
-                uid = box[0]
+            rccl = world > 1 and not share_gpu
+            if rccl:
+                # the 128-byte RCCL id travels over the control plane; all ranks were built from the
+                # same seeded parameters, the broadcast makes that a guarantee
+                uid = cdist.exchange_unique_id(rank, world, control=control)
                 buf = (ctypes.c_uint8 * _lib.UNIQUE_ID_BYTES).from_buffer_copy(uid)
                 model._call("crbm_comm_init", buf, world, rank)
+                model._call("crbm_comm_broadcast_state", 0)
             n = cfg["chains"]
             D = synthetic_onehot(n, cfg["L"], seed=1234 + rank)
             model._call("crbm_dataset_upload", fptr(D), n, cfg["L"])
@@ -277,21 +351,25 @@ def main():
             t1 = time.perf_counter()
             model._call("crbm_time_train", 0, n, tsteps, ctypes.byref(tms))
             barrier()
-            tel = time.perf_counter() - t1
-            if dist is not None:
-                tt = torch.tensor([tel], dtype=torch.float64, device=red_dev)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                tel = float(tt[0])
-            train = {"train_steps_per_s": tsteps / tel, "global_batch": n * world, "cd_k": k,
-                     "all_reduce": "rccl" if (world > 1 and backend != "gloo") else "none", "ms_per_train_step": 1e3 * tel / tsteps}
+            twall = time.perf_counter() - t1
+            twall, tdev = control.allreduce_max([twall, tms.value / 1e3])
+            train = {"train_steps_per_s": tsteps / tdev, "global_batch": n * world, "cd_k": k,
+                     "all_reduce": "rccl" if rccl else "none", "ms_per_train_step": 1e3 * tdev / tsteps,
+                     "wall_ms_per_train_step": 1e3 * twall / tsteps, "steps": tsteps}
+            if rccl:
+                sums = control.gather(cdist.replica_checksum(model))
+                train["replicas_identical"] = len(set(sums)) == 1
+                failed = failed or not train["replicas_identical"]
         except Exception as e:                      # report, never hide: the headline is the Gibbs metric
             train = {"error": str(e)[:300]}
+            failed = True
 
     if watchdog is not None:
         watchdog.cancel()
     emit(train)
-    if dist is not None:
-        dist.destroy_process_group()
+    control.close()
+    if failed:
+        sys.exit(4)
 
 
 if __name__ == "__main__":

@@ -76,6 +76,7 @@ SIGNATURES = {
     "crbm_dataset_select": (_I32, [_H, _I32]),
     "crbm_train_step_resident": (_I32, [_H, _I32, _I32]),
     "crbm_train_epoch_resident": (_I32, [_H, _I32]),
+    "crbm_train_epoch_sharded": (_I32, [_H, _I32, _I32]),
     "crbm_gibbs_steps": (_I32, [_H, _I32]),
     "crbm_gibbs_steps_async": (_I32, [_H, _I32]),
     "crbm_sync": (_I32, [_H]),
@@ -99,10 +100,12 @@ SIGNATURES = {
     "crbm_comm_unique_id": (_I32, [_U8P]),
     "crbm_comm_init": (_I32, [_H, _U8P, _I32, _I32]),
     "crbm_comm_destroy": (_I32, [_H]),
+    "crbm_comm_broadcast_state": (_I32, [_H, _I32]),
     "crbm_sums_count": (_I32, [_H]),
     "crbm_train_local": (_I32, [_H, _F, _I32, _I32, _F]),
     "crbm_train_apply": (_I32, [_H, _F, _I32]),
     "crbm_get_launch_info": (_I32, [_H, ctypes.POINTER(CrbmLaunchInfo)]),
+    "crbm_copy_bandwidth": (_I32, [_H, ctypes.c_int64, _I32, _F]),
     "crbm_gibbs_state_bytes": (ctypes.c_int64, [_H]),
 }
 

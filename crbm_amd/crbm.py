@@ -89,6 +89,11 @@ class CRBM(object):
         device = extra.pop("device", None)
         if extra:
             raise TypeError("unexpected keyword arguments: %s" % sorted(extra))
+        # limits of the HIP kernels (README "Limits"): refuse at construction, not in the middle of fit()
+        if num_motifs > 64:
+            raise Exception("num_motifs > 64 is not supported by the HIP kernels (K-bit hidden masks of at most 64 bits).")
+        if motif_length > 32:
+            raise Exception("motif_length > 32 is not supported by the HIP kernels (64-bit letter windows).")
 
         # convRBM.py:111-123
         self.num_motifs = num_motifs
@@ -124,7 +129,8 @@ class CRBM(object):
         c = np.zeros((1, input_dims), dtype=np.float32)                  # :151
         self._host = {"motifs": W, "bias": b, "c": c}
         self._handle = None
-        self._comm_ready = False
+        self._control = None          # crbm_amd.dist.ControlPlane of a data-parallel job
+        self._pending_state = None    # velocities / chains / counters to install when the handle is created
         self.motifs = _DeviceShared(self, "motifs", W.shape)
         self.bias = _DeviceShared(self, "bias", b.shape)
         self.c = _DeviceShared(self, "c", c.shape)
@@ -161,6 +167,9 @@ class CRBM(object):
         self._call("crbm_set_params", fptr(self._host["motifs"]), fptr(self._host["bias"]),
                                         fptr(self._host["c"]))
         self._call("crbm_set_shard", self.rank * (self.batchsize // self.world_size))
+        if self._pending_state is not None:
+            st, self._pending_state = self._pending_state, None
+            self._install_state(st)
         return handle
 
     def _call(self, name, *args):
@@ -252,25 +261,51 @@ class CRBM(object):
         obj.c.set_value(c)
         return obj
 
+    def _full_state(self):
+        """velocities, chains of ALL ranks (bit-packed) and sampler counters; collective in a
+        data-parallel job (every rank calls it, every rank gets the global state)."""
+        h = self._h()
+        seed, gstep, estep = ctypes.c_uint64(), ctypes.c_uint32(), ctypes.c_uint32()
+        self._check(self._lib.crbm_get_rng(h, ctypes.byref(seed), ctypes.byref(gstep), ctypes.byref(estep)))
+        fh, fhp = self.get_fantasy()
+        mine = (np.packbits(fh.astype(np.uint8), axis=None),
+                None if fhp is None else np.packbits(fhp.astype(np.uint8), axis=None))
+        parts = [mine] if self.world_size == 1 else self._control.gather(mine)
+        shape = (self.batchsize, self.num_motifs, 1, self.fantasy_hidden_len)
+        per = (self.batchsize // self.world_size) * self.num_motifs * self.fantasy_hidden_len
+
+        def unpack(i):
+            if parts[0][i] is None:
+                return None
+            rows = [np.unpackbits(p[i], count=per) for p in parts]
+            return np.packbits(np.concatenate(rows).reshape(shape), axis=3)   # along Lf, one byte per 8 positions
+        return {"velocities": self.get_velocities(), "fantasy_bits": (unpack(0), unpack(1)),
+                "fantasy_hidden_len": self.fantasy_hidden_len, "world_size": self.world_size,
+                "rng": (int(seed.value), int(gstep.value), int(estep.value))}
+
     def saveState(self, filename):
         """Full training state: the reference tuple of
         saveModel plus velocities, persistent chains and the sampler counters,
-        so that training resumes exactly.  A joblib file whose first two
-        entries are the reference's (numpyParams, hyperparams)."""
+        so that training resumes exactly (the reference's loadModel restarts
+        momentum and chains from zero, convRBM.py:226-235).  A joblib file whose
+        first two entries are the reference's (numpyParams, hyperparams).  In a
+        data-parallel job every rank calls it; the chains of all ranks are
+        gathered and rank 0 writes the one file, which loads at any world size."""
         numpyParams = (self.motifs.get_value(), self.bias.get_value(), self.c.get_value())
         hyperparams = (self.num_motifs, self.motif_length, self.input_dims, self.doublestranded,
                        self.batchsize, self.learning_rate, self.momentum, self.rho, self.lambda_rate,
                        self.pooling, self.cd_k, self.epochs, self.spmethod)
-        h = self._h()
-        seed, gstep, estep = ctypes.c_uint64(), ctypes.c_uint32(), ctypes.c_uint32()
-        self._check(self._lib.crbm_get_rng(h, ctypes.byref(seed), ctypes.byref(gstep), ctypes.byref(estep)))
-        extra = {"velocities": self.get_velocities(), "fantasy": self.get_fantasy(),
-                 "fantasy_hidden_len": self.fantasy_hidden_len,
-                 "rng": (int(seed.value), int(gstep.value), int(estep.value))}
-        joblib.dump((numpyParams, hyperparams, extra), filename, protocol=2)
+        extra = self._full_state()
+        if self.rank == 0:
+            joblib.dump((numpyParams, hyperparams, extra), filename, protocol=2)
+        if self._control is not None:
+            self._control.barrier()
 
     @classmethod
     def loadState(cls, filename):
+        """Counterpart of saveState.  The device state (velocities, chains, counters) is
+        installed when the handle is created, so `crbm_amd.dist.attach()` can still be called
+        on the returned model; each rank then takes its own chains out of the global state."""
         numpyParams, hyperparams, extra = joblib.load(filename)
         (num_motifs, motif_length, input_dims, doublestranded, batchsize, learning_rate,
          momentum, rho, lambda_rate, pooling, cd_k, epochs, spmethod) = hyperparams
@@ -283,10 +318,29 @@ class CRBM(object):
         obj.motifs.set_value(motifs)
         obj.bias.set_value(bias)
         obj.c.set_value(c)
-        obj.set_velocities(*extra["velocities"])
-        obj.set_fantasy(*extra["fantasy"])
-        obj.set_rng(seed, gstep, estep)
+        if "fantasy_bits" not in extra:      # files written before the chains were bit-packed
+            fh, fhp = extra["fantasy"]
+            extra = dict(extra, fantasy_bits=(np.packbits(fh.astype(np.uint8), axis=3),
+                                              None if fhp is None else np.packbits(fhp.astype(np.uint8), axis=3)))
+        obj._pending_state = {"velocities": extra["velocities"], "fantasy_bits": extra["fantasy_bits"],
+                              "rng": (seed, gstep, estep)}
         return obj
+
+    def _install_state(self, st):
+        nb = self.batchsize // self.world_size
+        lo = self.rank * nb
+
+        def rows(bits):
+            if bits is None:
+                return None
+            if bits.shape[0] != self.batchsize:
+                raise Exception("saved state holds %d chains, the model has %d" % (bits.shape[0], self.batchsize))
+            return np.unpackbits(bits[lo:lo + nb], axis=3, count=self.fantasy_hidden_len).astype(np.float32)
+        self.set_velocities(*st["velocities"])
+        fb, fbp = st["fantasy_bits"]
+        self.set_fantasy(rows(fb), rows(fbp))
+        seed, gstep, estep = st["rng"]
+        self.set_rng(seed, gstep, estep)
 
     # ------------------------------------------- graph builders as plain calls
     def _hgv(self, data, flip, want, rng_step=0):
@@ -394,14 +448,13 @@ class CRBM(object):
         return out
 
     def getPFMs(self):
-        """convRBM.py:640-655 (host NumPy there too)."""
-        def softmax_(x):
-            x_exp = np.exp(x)
-            y = np.zeros(x.shape)
-            for i in range(x.shape[1]):
-                y[:, i] = x_exp[:, i] / np.sum(x_exp[:, i])
-            return y
-        return [softmax_(m[0, :, :]) for m in self.motifs.get_value()]
+        """Position frequency matrices of the filters: per motif a (4,M) float64 array whose
+        columns are the softmax of the filter column over the four letters (what
+        convRBM.py:640-655 returns; host NumPy there too)."""
+        W = self.motifs.get_value().astype(np.float64)[:, 0]      # (K,4,M)
+        e = np.exp(W)
+        pfm = e / e.sum(axis=1, keepdims=True)
+        return [pfm[k] for k in range(self.num_motifs)]
 
     # --------------------------------------------------------------- training
     def gibbsSteps(self, k=1):
@@ -436,23 +489,43 @@ class CRBM(object):
         same = test_data is None
         test_data = training_data if same else self._truncate(test_data)
 
-        print(("BatchSize: " + str(self.batchsize)))
-        print("Start training the model...")
+        sharded = self.world_size > 1
+        evaluates = self.rank == 0          # data-parallel: rank 0 alone evaluates and prints
+        if evaluates:
+            print(("BatchSize: " + str(self.batchsize)))
+            print("Start training the model...")
         starttime = time.time()
         self._h()
         ntrain = ntest = 0
         if self.epochs > 0:
-            ntrain, _ = self._upload(training_data, 0)
-            ntest = ntrain if same else self._upload(test_data, 1)[0]
+            ntrain = training_data.shape[0]
+            if sharded:
+                # each rank uploads only the rows it owns of every mini-batch (1/world of the set)
+                from . import dist
+                mine = dist.shard_rows(ntrain, self.batchsize, self.rank, self.world_size)
+                if mine.size == 0:
+                    raise Exception("fewer training rows than ranks: rank %d owns none" % self.rank)
+                self._upload(training_data[mine], 0)
+                if evaluates:
+                    ntest = self._upload(test_data, 1)[0]
+            else:
+                self._upload(training_data, 0)
+                ntest = ntrain if same else self._upload(test_data, 1)[0]
+        test_slot = 1 if (sharded or not same) else 0
         for epoch in range(self.epochs):
             self._call("crbm_dataset_select", 0)
             # the batch loop of convRBM.py:612-615 runs inside the library: the steps are
             # enqueued back to back, with one host synchronisation per epoch
-            self._call("crbm_train_epoch_resident", self.batchsize)
+            if sharded:
+                self._call("crbm_train_epoch_sharded", self.batchsize, ntrain)
+            else:
+                self._call("crbm_train_epoch_resident", self.batchsize)
+            if not evaluates:
+                continue
             meanfe = 0.0
             meannmh = 0.0
             nb = 0
-            self._call("crbm_dataset_select", 0 if same else 1)
+            self._call("crbm_dataset_select", test_slot)
             mfe, nmh = ctypes.c_float(), ctypes.c_float()
             for [start, end] in self._iterateBatchIndices(ntest, self.batchsize):
                 # convRBM.py:619-625 on rows of the resident test set
@@ -462,13 +535,13 @@ class CRBM(object):
                 nb = nb + 1
             self._call("crbm_dataset_select", 0)
             [twn_, ic_, medic_] = self._evaluateParams()
-            if self.rank == 0:
-                print(("Epoch {:d}: ".format(epoch) +
-                       "FE={:1.3f} ".format(meanfe / nb) +
-                       "NumH={:1.4f} ".format(meannmh / nb) +
-                       "WNorm={:2.2f} ".format(float(twn_)) +
-                       "IC={:1.3f} medIC={:1.3f}".format(float(ic_), float(medic_))))
-        print(("Training finished after: {:5.2f} seconds!".format(time.time() - starttime)))
+            print(("Epoch {:d}: ".format(epoch) +
+                   "FE={:1.3f} ".format(meanfe / nb) +
+                   "NumH={:1.4f} ".format(meannmh / nb) +
+                   "WNorm={:2.2f} ".format(float(twn_)) +
+                   "IC={:1.3f} medIC={:1.3f}".format(float(ic_), float(medic_))))
+        if evaluates:
+            print(("Training finished after: {:5.2f} seconds!".format(time.time() - starttime)))
 
     # the name BASELINE.json's north_star uses for the same entry point
     trainModel = fit
@@ -488,23 +561,16 @@ class CRBM(object):
                 else [i, totalsize] for i in range(totalsize)[0::nbatchsize]]
 
     def __repr__(self):
-        # convRBM.py:704-720 (no line breaks between hyper-parameters there either)
-        st = "Parameters:\n\n"
-        st += "Number of motifs: {}\n".format(self.num_motifs)
-        st += "Motif length: {}\n".format(self.motif_length)
-        st += "\n"
-        st += "Hyper-parameters:\n\n"
-        st += "input dims: {:d}".format(self.input_dims)
-        st += "doublestranded: {}".format(self.doublestranded)
-        st += "batchsize: {:d}".format(self.batchsize)
-        st += "learning rate: {:1.3f}".format(self.learning_rate)
-        st += "momentum: {:1.3f}".format(self.momentum)
-        st += "rho: {:1.4f}".format(self.rho)
-        st += "lambda: {:1.3f}".format(self.lambda_rate)
-        st += "pooling: {:d}".format(self.pooling)
-        st += "cd_k: {:d}".format(self.cd_k)
-        st += "epochs: {:d}".format(self.epochs)
-        return st
+        """Same text as the reference prints (convRBM.py:704-720): two headed sections, the
+        hyper-parameters run together without separators."""
+        fields = [("input dims: {:d}", self.input_dims), ("doublestranded: {}", self.doublestranded),
+                  ("batchsize: {:d}", self.batchsize), ("learning rate: {:1.3f}", self.learning_rate),
+                  ("momentum: {:1.3f}", self.momentum), ("rho: {:1.4f}", self.rho),
+                  ("lambda: {:1.3f}", self.lambda_rate), ("pooling: {:d}", self.pooling),
+                  ("cd_k: {:d}", self.cd_k), ("epochs: {:d}", self.epochs)]
+        head = "Parameters:\n\nNumber of motifs: %s\nMotif length: %s\n\nHyper-parameters:\n\n" \
+            % (self.num_motifs, self.motif_length)
+        return head + "".join(fmt.format(val) for fmt, val in fields)
 
     # ------------------------------------------- state the reference never saves
     def get_velocities(self):
@@ -515,8 +581,12 @@ class CRBM(object):
         return vW, vb, vc
 
     def set_velocities(self, vW, vb, vc):
-        self._call("crbm_set_velocities", fptr(as_f32(vW)), fptr(as_f32(vb)),
-                                                  fptr(as_f32(vc)))
+        vW, vb, vc = as_f32(vW), as_f32(vb), as_f32(vc)
+        want = ((self.num_motifs, 1, 4, self.motif_length), (1, self.num_motifs), (1, 4))
+        for name, arr, shape in zip(("vW", "vb", "vc"), (vW, vb, vc), want):
+            if arr.shape != shape:          # the C side reads exactly these many floats
+                raise ValueError("%s: expected shape %s, got %s" % (name, shape, arr.shape))
+        self._call("crbm_set_velocities", fptr(vW), fptr(vb), fptr(vc))
 
     def get_fantasy(self):
         """(fantasy_h, fantasy_h_prime or None), dense float32 (convRBM.py:168-173)."""
@@ -529,9 +599,17 @@ class CRBM(object):
         return a, b
 
     def set_fantasy(self, hid, hid_prime=None):
-        h = self._h()
-        self._call("crbm_set_fantasy", fptr(as_f32(hid)),
-                                               fptr(None if hid_prime is None else as_f32(hid_prime)))
+        """This rank's chains: (batchsize / world_size, K, 1, fantasy_hidden_len), exactly 0/1."""
+        self._h()
+        shape = (self.batchsize // self.world_size, self.num_motifs, 1, self.fantasy_hidden_len)
+        hid = as_f32(hid)
+        hid_prime = None if hid_prime is None else as_f32(hid_prime)
+        for name, arr in (("hid", hid), ("hid_prime", hid_prime)):
+            if arr is not None and arr.shape != shape:      # the C side reads exactly B*K*Lf floats
+                raise ValueError("%s: expected shape %s, got %s" % (name, shape, arr.shape))
+        if self.doublestranded and hid_prime is None:
+            raise ValueError("a doublestranded model needs hid_prime")
+        self._call("crbm_set_fantasy", fptr(hid), fptr(hid_prime))
 
     def get_fantasy_visible(self):
         h = self._h()

@@ -31,6 +31,7 @@ struct RcclApi {
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   std::string error;
 };
@@ -59,6 +60,7 @@ bool load_rccl() {
   CRBM_SYM(CommInitRank, "ncclCommInitRank")
   CRBM_SYM(CommDestroy, "ncclCommDestroy")
   CRBM_SYM(AllReduce, "ncclAllReduce")
+  CRBM_SYM(Broadcast, "ncclBroadcast")
   CRBM_SYM(GetErrorString, "ncclGetErrorString")
 #undef CRBM_SYM
   return true;
@@ -131,12 +133,14 @@ struct crbm_handle {
   bool has_dense = false;
   int gibbs_wpe = 0;                   // register-allocation hint compiled into the sparse Gibbs kernel
   int variant = 1;
-  int topdown_mode = 0;                // CRBM_TOPDOWN: 0 auto (by measured hidden activity), 1 dense, 2 sparse
+  int topdown_mode = 0;                // CRBM_TOPDOWN: 1 dense, anything else the set-bit walk (fixed per handle)
   uint32_t* d_nset = nullptr;          // per wave of the last Gibbs launch: set bits of the final state
   int nset_slots = 0;
-  uint32_t launches_since_read = 0, activity_reads = 0;
+  uint32_t launches_since_read = 0;
   double activity = -1.0;              // fraction of hidden units on after the last launch that was read back
   int stats_rows = 0, stats_lds_budget = 0;
+  bool stats_mfma = true;              // CRBM_STATS=walk selects the letter-bucketed LDS walk (A/B runs)
+  bool fuse_stats = false;             // model half of the statistics inside the Gibbs kernel (Cfg::FUSE_STATS; CRBM_STATS=split: off)
   SumsLayout sl;
   // data parallel
   ncclComm_t comm = nullptr;
@@ -260,10 +264,15 @@ void use_variant(crbm_handle* h, int v) {
   h->gibbs_grid = h->gridv[v];
 }
 
-int launch_gibbs(crbm_handle* h, int steps, hipStream_t s = nullptr) {
+StatsGeom stats_geom(const StatsMfmaLayout& st, float* partials, long ngroups);
+
+// with_stats: the fused variant -- the launch also leaves the model half of the gradient statistics
+// as one partial row per block in h->partials2 (reduction handed back through `model_reduce`)
+int launch_gibbs(crbm_handle* h, int steps, hipStream_t s = nullptr, ReduceArgs* model_reduce = nullptr) {
   if (!s) s = h->stream;
   int rc = ensure_tables(h);
   if (rc) return rc;
+  const bool with_stats = model_reduce != nullptr;
   GibbsArgs a;
   a.tables = h->d_tables;
   a.hm = h->d_hm; a.hmp = h->ds ? h->d_hmp : nullptr; a.vout = h->d_vf;
@@ -278,40 +287,55 @@ int launch_gibbs(crbm_handle* h, int steps, hipStream_t s = nullptr) {
   a.ones = h->d_nset;
   a.debug = env_int("CRBM_GIBBS_DEBUG", 0);
   h->nset_slots = h->gibbs_grid * (h->gibbs_threads / 64);
-  HIPCHK(jit_launch(h->variant ? h->jk.gibbs_sparse : h->jk.gibbs, a, (unsigned)h->gibbs_grid, 1,
-                    (unsigned)h->gibbs_threads, (unsigned)h->gl.lds_bytes, s));
+  a.stats_off = 0;
+  a.sg = StatsGeom();
+  unsigned lds = (unsigned)h->gl.lds_bytes;
+  hipFunction_t fn = h->variant ? h->jk.gibbs_sparse : h->jk.gibbs;
+  if (with_stats) {
+    const StatsMfmaLayout st = stats_mfma_layout(h->ms, 0, h->Lf, h->gibbs_threads);
+    HIPCHK(h->partials2.ensure((size_t)h->gibbs_grid * st.row));
+    a.stats_off = (h->gl.lds_bytes / 4 + 3) & ~3;
+    a.sg = stats_geom(st, h->partials2.p, (long)h->gl.S * st.GPC);
+    lds = (unsigned)std::max((a.stats_off + st.region_floats) * 4, st.combine_bytes);
+    fn = h->jk.gibbs_sparse_stats;
+    ReduceArgs& r = *model_reduce;
+    r.partials = h->partials2.p;
+    r.nrows = h->gibbs_grid; r.row = st.row;
+    r.K = h->K; r.KAM = h->KAM; r.ds = h->ds; r.want_sparsity = 0;
+    r.sums = h->d_sums + h->sl.model_off;
+    r.skip_begin = h->sl.model_skip_begin; r.skip_len = h->sl.model_skip_len;
+    r.n_value = (float)h->B;
+  }
+  HIPCHK(jit_launch(fn, a, (unsigned)h->gibbs_grid, 1, (unsigned)h->gibbs_threads, lds, s));
   h->gibbs_step += (uint32_t)steps;
   h->launches_since_read += 1;
   return CRBM_OK;
 }
 
-// Called after a stream synchronisation: reads the activity monitor of the Gibbs
-// kernel back (every call when `always`, else every 16th) and, in auto mode, picks
-// the top-down variant for the next launches: the set-bit walk wins while few
-// hidden units are on (its cost grows with their number), the dense tables above
-// that.  The variants round differently in the last bit, so a switch can flip
-// samples that sit on a p == u tie.
-int refresh_activity(crbm_handle* h, bool always) {
+// Reads the activity monitor of the last Gibbs launch back (crbm_sync /
+// crbm_gibbs_steps only: a blocking copy, kept out of every timed or training
+// path).  It is a monitor, nothing else: the top-down variant is fixed per
+// handle, so every rank of a data-parallel job -- and a 1-GPU run of the same
+// chains -- rounds identically and draws identical samples.
+int refresh_activity(crbm_handle* h) {
   if (h->launches_since_read == 0) return CRBM_OK;
-  if (!always && (h->activity_reads++ & 15u) != 0) return CRBM_OK;
   std::vector<uint32_t> slots((size_t)h->nset_slots);
   HIPCHK(hipMemcpy(slots.data(), h->d_nset, slots.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
   unsigned long long last = 0;
   for (uint32_t v : slots) last += v;
   h->launches_since_read = 0;
   h->activity = (double)last / ((double)h->B * h->Lf * h->K * (1 + h->ds));
-  if (h->topdown_mode == 0 && h->has_dense) {
-    const double hi = 0.03, lo = 0.02;   // hysteresis around the measured break-even (2.3 % at config #2)
-    if (h->variant == 1 && h->activity > hi) use_variant(h, 0);
-    else if (h->variant == 0 && h->activity < lo) use_variant(h, 1);
-  }
   return CRBM_OK;
 }
 
 // raw statistic sums of (letters, n, L) -> sums half (data or model)
 // `defer`: hand the reduction of the partial rows back to the caller (to pair it with the other half)
+int launch_stats_mfma(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool data_half, hipStream_t s,
+                      ReduceArgs* defer);
+
 int launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool data_half, hipStream_t s = nullptr,
                  ReduceArgs* defer = nullptr) {
+  if (h->stats_mfma) return launch_stats_mfma(h, d_letters, n, L, data_half, s, defer);
   if (!s) s = h->stream;
   DevBuf<float>& pbuf = data_half ? h->partials : h->partials2;
   int rc = ensure_tables(h);
@@ -361,6 +385,65 @@ int launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool d
   return CRBM_OK;
 }
 
+StatsGeom stats_geom(const StatsMfmaLayout& st, float* partials, long ngroups) {
+  StatsGeom g;
+  g.GPC = st.GPC;
+  g.off_slices = st.off_slices; g.slice = st.slice;
+  g.off_win = st.off_win; g.off_gw = st.off_gw; g.off_pt = st.off_pt;
+  g.divGPC = make_fastdiv((uint32_t)st.GPC, (uint64_t)std::max<long>(ngroups, 1));
+  g.row = st.row; g.off_vh0 = st.off_vh[0]; g.off_vh1 = st.off_vh[1]; g.off_h0 = st.off_h[0]; g.off_h1 = st.off_h[1];
+  g.off_sw = st.off_sw; g.off_sb = st.off_sb; g.off_v = st.off_v;
+  g.partials = partials;
+  return g;
+}
+
+// MFMA statistics kernel (stats_mfma_body): raw sums of (letters, n, L) -> partial rows; the column
+// reduction is handed back to the caller (ReduceArgs) or launched here.
+int launch_stats_mfma(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool data_half, hipStream_t s,
+                      ReduceArgs* defer) {
+  if (!s) s = h->stream;
+  DevBuf<float>& pbuf = data_half ? h->partials : h->partials2;
+  int rc = ensure_tables(h);
+  if (rc) return rc;
+  const int want_sp = data_half ? 1 : 0;
+  const int Lh = L - h->M + 1;
+  const int tabs = (1 + h->ds) * tab_bytes(h);
+  const StatsMfmaLayout st = stats_mfma_layout(h->ms, want_sp, Lh, env_int("CRBM_STATS_THREADS", 0), tabs);
+  StatsMfmaArgs a;
+  a.tables = h->d_tables;
+  a.letters = d_letters;
+  a.n = n; a.L = L; a.Lh = Lh; a.LW = letter_words(L);
+  const long ngroups = (long)n * st.GPC;
+  const long nunits = (ngroups + 1) / 2;
+  a.off_tab = st.region_floats;
+  const int lds = std::max(st.region_floats * 4 + tabs, st.combine_bytes);
+  ARGCHK(lds <= 160 * 1024, "model too large for the statistics kernel");
+  const int wpr = (st.threads / 64) / st.NR;                  // waves per role = units a block works on at a time
+  const int per_cu = std::max(1, std::min(2048 / st.threads, (160 * 1024) / std::max(1, lds)));
+  const int cap = h->stats_rows > 0 ? h->stats_rows : h->num_cu * per_cu;
+  const int gx = (int)std::max<long>(1, std::min<long>((nunits + wpr - 1) / wpr, cap));
+  HIPCHK(pbuf.ensure((size_t)gx * st.row));
+  a.sg = stats_geom(st, pbuf.p, ngroups);
+  HIPCHK(jit_launch(data_half ? h->jk.stats_mfma_data : h->jk.stats_mfma_model, a, (unsigned)gx, 1, (unsigned)st.threads,
+                    (unsigned)lds, s));
+  ReduceArgs r;
+  r.partials = pbuf.p;
+  r.nrows = gx; r.row = st.row;
+  r.K = h->K; r.KAM = h->KAM; r.ds = h->ds; r.want_sparsity = want_sp;
+  if (data_half) {
+    r.sums = h->d_sums + h->sl.data_off;
+    r.skip_begin = st.row; r.skip_len = 0;
+  } else {
+    r.sums = h->d_sums + h->sl.model_off;
+    r.skip_begin = h->sl.model_skip_begin; r.skip_len = h->sl.model_skip_len;
+  }
+  r.n_value = (float)n;
+  if (defer) { *defer = r; return CRBM_OK; }
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((st.row + 31) / 32), dim3(1024), 0, s, r);
+  HIPCHK(hipGetLastError());
+  return CRBM_OK;
+}
+
 int launch_update(crbm_handle* h, int L_data) {
   UpdateArgs u;
   u.sums = h->d_sums;
@@ -388,13 +471,26 @@ int train_local_dev(crbm_handle* h, const uint32_t* d_letters, int n, int L) {
     HIPCHK(hipEventRecord(h->ev_fork, h->stream));          // tables ready, earlier work on the chains done
     HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
   }
-  rc = launch_gibbs(h, h->cfg.cd_k, sm);
-  if (rc) return rc;
   // single stream: the two column reductions share one launch
   ReducePair pair;
   const bool paired = !h->overlap && n > 0;
-  rc = launch_stats(h, h->d_vf, h->B, h->Lv, false, sm, paired ? &pair.half[1] : nullptr);
-  if (rc) return rc;
+  if (h->fuse_stats) {
+    // the Gibbs launch itself leaves the model half of the statistics (last-step probabilities
+    // and visible sample never leave the chip)
+    ReduceArgs mr;
+    rc = launch_gibbs(h, h->cfg.cd_k, sm, &mr);
+    if (rc) return rc;
+    if (paired) pair.half[1] = mr;
+    else {
+      hipLaunchKernelGGL(reduce_partials_kernel, dim3((mr.row + 31) / 32), dim3(1024), 0, sm, mr);
+      HIPCHK(hipGetLastError());
+    }
+  } else {
+    rc = launch_gibbs(h, h->cfg.cd_k, sm);
+    if (rc) return rc;
+    rc = launch_stats(h, h->d_vf, h->B, h->Lv, false, sm, paired ? &pair.half[1] : nullptr);
+    if (rc) return rc;
+  }
   if (h->overlap) HIPCHK(hipEventRecord(h->ev_join, h->stream2));
   if (n > 0) {
     rc = launch_stats(h, d_letters, n, L, true, nullptr, paired ? &pair.half[0] : nullptr);
@@ -594,10 +690,11 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
     hh->gridv[v] = geom.grid;
   }
   {
+    // The set-bit walk is the variant of every model (its cost follows the hidden activity,
+    // ~2 % under the reference's sparsity target); CRBM_TOPDOWN=dense pins the table variant
+    // of small models for A/B runs.  Never switched at run time: the two round differently.
     const char* td = getenv("CRBM_TOPDOWN");
-    hh->topdown_mode = (td && !strcmp(td, "dense")) ? 1 : (td && !strcmp(td, "sparse")) ? 2 : 0;
-    if (hh->topdown_mode == 1 && !hh->has_dense) hh->topdown_mode = 2;
-    // chains start at h = 0 (convRBM.py:168): begin with the set-bit walk
+    hh->topdown_mode = (td && !strcmp(td, "dense") && hh->has_dense) ? 1 : 2;
     use_variant(hh, hh->topdown_mode == 1 ? 0 : 1);
   }
   {
@@ -636,6 +733,16 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
   TRY(hipMalloc((void**)&hh->d_sums, (size_t)hh->sl.count * 4)); TRY(hipMemset(hh->d_sums, 0, (size_t)hh->sl.count * 4));
 #undef TRY
   hh->tables_dirty = true;
+  {
+    const char* sv = getenv("CRBM_STATS");
+    hh->stats_mfma = !(sv && !strcmp(sv, "walk"));
+    hh->fuse_stats = hh->stats_mfma && hh->ms.FUSE_STATS && hh->variant == 1 && !(sv && !strcmp(sv, "split"));
+    if (hh->fuse_stats) {   // the fused launch appends the statistics slices to the chain image: it must fit the LDS
+      const StatsMfmaLayout st = stats_mfma_layout(hh->ms, 0, hh->Lf, hh->gibbs_threads);
+      const int lds = std::max((((hh->gl.lds_bytes / 4 + 3) & ~3) + st.region_floats) * 4, st.combine_bytes);
+      if (lds > 160 * 1024) hh->fuse_stats = false;
+    }
+  }
   hh->stats_rows = env_int("CRBM_STATS_ROWS", 0);   // 0: one resident wave of blocks
   hh->stats_lds_budget = env_int("CRBM_STATS_LDS", 0);   // 0: chosen per model (stats_layout)
   *out = hh;
@@ -797,7 +904,7 @@ int crbm_train_step(crbm_handle* h, const float* D, int32_t n, int32_t L) {
   rc = train_core(h, h->letters.p, n, L);
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(h->stream));
-  return refresh_activity(h, false);
+  return CRBM_OK;
 }
 
 int crbm_dataset_select(crbm_handle* h, int32_t slot) {
@@ -856,7 +963,7 @@ int crbm_train_step_resident(crbm_handle* h, int32_t start, int32_t end) {
   int rc = train_core(h, h->dataset[slot].p + (size_t)start * LW, end - start, h->dataset_L[slot]);
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(h->stream));
-  return refresh_activity(h, false);
+  return CRBM_OK;
 }
 
 // One pass over the resident data set in sequential mini-batches of `batchsize`
@@ -877,7 +984,36 @@ int crbm_train_epoch_resident(crbm_handle* h, int32_t batchsize) {
     if (rc) return rc;
   }
   HIPCHK(hipStreamSynchronize(h->stream));
-  return refresh_activity(h, true);
+  return CRBM_OK;
+}
+
+// The same loop when the selected slot holds only THIS rank's rows: for every
+// slice [start, end) of the global data set of `total_rows` rows, rank r owns rows
+// [start + n*r/R, start + n*(r+1)/R) (n = end - start) and the resident set is their
+// concatenation in slice order (crbm_amd.dist.shard_rows builds it), so a rank
+// uploads 1/R of the data instead of all of it.
+int crbm_train_epoch_sharded(crbm_handle* h, int32_t batchsize, int32_t total_rows) {
+  ENTER();
+  const int slot = h->slot;
+  ARGCHK(batchsize >= 1 && total_rows >= 1, "batchsize and total_rows must be positive");
+  const int L = h->dataset_L[slot], LW = letter_words(std::max(L, 1));
+  long have = 0;
+  for (int start = 0; start < total_rows; start += batchsize) {
+    const long n = std::min(total_rows, start + batchsize) - start;
+    have += (n * (h->rank + 1)) / h->nranks - (n * h->rank) / h->nranks;
+  }
+  ARGCHK(have == h->dataset_n[slot], "resident rows do not match this rank's share of total_rows");
+  ARGCHK(have > 0 || h->comm, "no resident data set (call crbm_dataset_upload)");
+  size_t off = 0;
+  for (int start = 0; start < total_rows; start += batchsize) {
+    const long n = std::min(total_rows, start + batchsize) - start;
+    const int mine = (int)((n * (h->rank + 1)) / h->nranks - (n * h->rank) / h->nranks);
+    int rc = train_core(h, h->dataset[slot].p + off * LW, mine, L);
+    if (rc) return rc;
+    off += (size_t)mine;
+  }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return CRBM_OK;
 }
 
 int crbm_gibbs_steps_async(crbm_handle* h, int32_t k) {
@@ -889,7 +1025,7 @@ int crbm_gibbs_steps_async(crbm_handle* h, int32_t k) {
 int crbm_sync(crbm_handle* h) {
   ENTER();
   HIPCHK(hipStreamSynchronize(h->stream));
-  return refresh_activity(h, true);
+  return refresh_activity(h);
 }
 
 int crbm_gibbs_steps(crbm_handle* h, int32_t k) {
@@ -909,7 +1045,7 @@ int crbm_time_gibbs(crbm_handle* h, int32_t k, int32_t launches, float* total_ms
   HIPCHK(hipEventRecord(h->ev1, h->stream));
   HIPCHK(hipEventSynchronize(h->ev1));
   HIPCHK(hipEventElapsedTime(total_ms, h->ev0, h->ev1));
-  return refresh_activity(h, true);
+  return CRBM_OK;
 }
 
 int crbm_time_train(crbm_handle* h, int32_t start, int32_t end, int32_t launches, float* total_ms) {
@@ -926,7 +1062,7 @@ int crbm_time_train(crbm_handle* h, int32_t start, int32_t end, int32_t launches
   HIPCHK(hipEventRecord(h->ev1, h->stream));
   HIPCHK(hipEventSynchronize(h->ev1));
   HIPCHK(hipEventElapsedTime(total_ms, h->ev0, h->ev1));
-  return refresh_activity(h, true);
+  return CRBM_OK;
 }
 
 // ---- stand-alone passes ------------------------------------------------------
@@ -1440,16 +1576,38 @@ int crbm_comm_destroy(crbm_handle* h) {
   return CRBM_OK;
 }
 
+// Replicas must start identical: only raw statistic sums are all-reduced, so a
+// rank that begins from different parameters would apply the common update to a
+// different model for ever.  ncclBroadcast of W, b, c and the three velocities
+// from `root` (no-op without a communicator).
+int crbm_comm_broadcast_state(crbm_handle* h, int32_t root) {
+  ENTER();
+  if (!h->comm) return CRBM_OK;
+  ARGCHK(root >= 0 && root < h->nranks, "root out of range");
+  struct { float* p; size_t n; } bufs[] = {{h->dW, (size_t)h->KAM}, {h->db, (size_t)h->K}, {h->dc, 4},
+                                           {h->dvW, (size_t)h->KAM}, {h->dvb, (size_t)h->K}, {h->dvc, 4}};
+  for (auto& b : bufs) {
+    ncclResult_t r = g_rccl.Broadcast(b.p, b.p, b.n, ncclFloat, root, h->comm, h->stream);
+    if (r != ncclSuccess) return fail(h, CRBM_ERR_RCCL, std::string("ncclBroadcast: ") + g_rccl.GetErrorString(r));
+  }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->tables_dirty = true;
+  return CRBM_OK;
+}
+
 int crbm_sums_count(const crbm_handle* h) { return h ? h->sl.count : 0; }
 
 int crbm_train_local(crbm_handle* h, const float* D, int32_t n, int32_t L, float* sums_out) {
   ENTER();
-  ARGCHK(D && sums_out, "null argument");
-  int rc = check_data_shape(h, n, L);
+  ARGCHK(sums_out && (D || n == 0), "null argument");
+  int rc = check_data_shape(h, std::max(n, 1), L);
   if (rc) return rc;
-  HIPCHK(h->letters.ensure((size_t)n * letter_words(L)));
-  rc = encode_host(h, D, n, L, h->letters.p);
-  if (rc) return rc;
+  ARGCHK(n >= 0, "n must be non-negative");
+  if (n > 0) {   // n == 0: a rank that owns no row of a short last mini-batch contributes zeros
+    HIPCHK(h->letters.ensure((size_t)n * letter_words(L)));
+    rc = encode_host(h, D, n, L, h->letters.p);
+    if (rc) return rc;
+  }
   rc = train_local_dev(h, h->letters.p, n, L);
   if (rc) return rc;
   rc = copy_out(h, sums_out, h->d_sums, (size_t)h->sl.count);
@@ -1479,6 +1637,33 @@ int crbm_get_launch_info(const crbm_handle* h, crbm_launch_info* out) {
   out->stats_block = st.threads; out->stats_lds_bytes = st.lds_bytes;
   out->gibbs_sparse = h->variant;
   out->activity_ppm = h->activity < 0.0 ? -1 : (int32_t)(h->activity * 1e6 + 0.5);
+  return CRBM_OK;
+}
+
+// Device-copy bandwidth of this GPU, measured with a float4 copy kernel on the
+// library's stream (HIP events): the practical ceiling next to the 8 TB/s spec
+// that bench.py quotes its roofline fraction against as well.
+int crbm_copy_bandwidth(crbm_handle* h, int64_t bytes, int32_t reps, float* gb_per_s) {
+  ENTER();
+  ARGCHK(bytes >= (1 << 20) && reps >= 1 && gb_per_s, "bad argument");
+  const size_t n4 = (size_t)bytes / 16;
+  float4 *src = nullptr, *dst = nullptr;
+  HIPCHK(hipMalloc((void**)&src, n4 * 16));
+  hipError_t e = hipMalloc((void**)&dst, n4 * 16);
+  if (e != hipSuccess) { (void)hipFree(src); return fail(h, CRBM_ERR_HIP, "hipMalloc (copy buffer)"); }
+  (void)hipMemsetAsync(src, 1, n4 * 16, h->stream);
+  const int grid = h->num_cu * 16;
+  for (int i = 0; i < 1 + reps; ++i) {
+    if (i == 1) (void)hipEventRecord(h->ev0, h->stream);
+    hipLaunchKernelGGL(copy_float4_kernel, dim3(grid), dim3(256), 0, h->stream, src, dst, n4);
+  }
+  (void)hipEventRecord(h->ev1, h->stream);
+  e = hipEventSynchronize(h->ev1);
+  float ms = 0.f;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, h->ev0, h->ev1);
+  (void)hipFree(src); (void)hipFree(dst);
+  if (e != hipSuccess) return fail(h, CRBM_ERR_HIP, std::string("copy bandwidth: ") + hipGetErrorString(e));
+  *gb_per_s = (float)(2.0 * (double)n4 * 16.0 * reps / (ms * 1e-3) / 1e9);   // bytes read + written
   return CRBM_OK;
 }
 

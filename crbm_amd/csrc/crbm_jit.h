@@ -27,8 +27,8 @@ namespace crbm {
 struct JitKernels {
   hipModule_t module = nullptr;
   hipFunction_t build_tables = nullptr, hgv = nullptr, gibbs = nullptr /* dense top-down; null if the model has none */,
-                gibbs_sparse = nullptr, stats = nullptr, free_energy = nullptr,
-                hit_summary = nullptr;
+                gibbs_sparse = nullptr, gibbs_sparse_stats = nullptr /* null unless Cfg::FUSE_STATS */, stats = nullptr, stats_mfma_data = nullptr, stats_mfma_model = nullptr,
+                free_energy = nullptr, hit_summary = nullptr;
   bool from_cache = false;
   std::string cache_file;
 };
@@ -67,21 +67,30 @@ inline uint64_t jit_fnv1a(const std::string& s, uint64_t h = 1469598103934665603
 // below 4 (LDS-limited large models): tells the register allocator not to squeeze
 // the kernel for an occupancy it will never see; 0 = no hint.
 inline std::string jit_stub(int K, int M, int DS, int G, int gibbs_wpe) {
-  char attr[96] = "";
+  char attr[96] = "", sattr[96] = "";
   if (gibbs_wpe > 0) snprintf(attr, sizeof(attr), "__attribute__((amdgpu_waves_per_eu(1, %d)))", gibbs_wpe);
-  char buf[4096];
+  // the variant that also carries the statistics accumulators must keep the occupancy of the plain
+  // kernel's geometry (4 blocks of 4 waves per CU for small models): cap it at 128 registers there
+  if (gibbs_wpe > 0) snprintf(sattr, sizeof(sattr), "__attribute__((amdgpu_waves_per_eu(1, %d)))", gibbs_wpe);
+  else snprintf(sattr, sizeof(sattr), "__attribute__((amdgpu_waves_per_eu(4)))");
+  char buf[8192];
   snprintf(buf, sizeof(buf),
            "#include \"crbm_kernels.h\"\n"
            "#ifndef CRBM_GIBBS_ATTR\n#define CRBM_GIBBS_ATTR %s\n#endif\n"
+           "#ifndef CRBM_GIBBS_STATS_ATTR\n#define CRBM_GIBBS_STATS_ATTR %s\n#endif\n"
            "using ModelCfg = crbm::Cfg<%d, %d, %d, %d>;\n"
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_build_tables(crbm::TablesArgs a) { crbm::build_tables_body<ModelCfg>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_hgv(crbm::HgvArgs a) { crbm::hgv_body<ModelCfg>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) CRBM_GIBBS_ATTR crbm_gibbs_sparse(crbm::GibbsArgs a) { crbm::gibbs_body<ModelCfg, true>(a); }\n"
+           "extern \"C\" __global__ void __launch_bounds__(256) CRBM_GIBBS_STATS_ATTR crbm_gibbs_sparse_stats(crbm::GibbsArgs a) { if constexpr (ModelCfg::FUSE_STATS) crbm::gibbs_body<ModelCfg, true, true>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_gibbs(crbm::GibbsArgs a) { if constexpr (ModelCfg::DENSE) crbm::gibbs_body<ModelCfg, ModelCfg::DENSE ? false : true>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(64 * ModelCfg::STATS_WAVES) crbm_stats(crbm::StatsArgs a) { crbm::stats_body<ModelCfg>(a); }\n"
+           "using RoleData = crbm::StatsRole<ModelCfg, true>;\nusing RoleModel = crbm::StatsRole<ModelCfg, false>;\n"
+           "extern \"C\" __global__ void __launch_bounds__(RoleData::THREADS) crbm_stats_mfma_data(crbm::StatsMfmaArgs a) { crbm::stats_mfma_body<ModelCfg, true>(a); }\n"
+           "extern \"C\" __global__ void __launch_bounds__(RoleModel::THREADS) crbm_stats_mfma_model(crbm::StatsMfmaArgs a) { crbm::stats_mfma_body<ModelCfg, false>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_free_energy(crbm::FeArgs a) { crbm::free_energy_body<ModelCfg>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_hit_summary(crbm::HitArgs a) { crbm::hit_summary_body<ModelCfg>(a); }\n",
-           attr, K, M, DS, G);
+           attr, sattr, K, M, DS, G);
   return buf;
 }
 
@@ -169,8 +178,9 @@ inline int jit_load(int K, int M, int DS, int G, int gibbs_wpe, JitKernels* out,
   }
   struct { const char* name; hipFunction_t* f; } syms[] = {
       {"crbm_build_tables", &out->build_tables}, {"crbm_hgv", &out->hgv}, {"crbm_gibbs", &out->gibbs},
-      {"crbm_gibbs_sparse", &out->gibbs_sparse},
-      {"crbm_stats", &out->stats}, {"crbm_free_energy", &out->free_energy},
+      {"crbm_gibbs_sparse", &out->gibbs_sparse}, {"crbm_gibbs_sparse_stats", &out->gibbs_sparse_stats},
+      {"crbm_stats", &out->stats}, {"crbm_stats_mfma_data", &out->stats_mfma_data},
+      {"crbm_stats_mfma_model", &out->stats_mfma_model}, {"crbm_free_energy", &out->free_energy},
       {"crbm_hit_summary", &out->hit_summary}};
   for (auto& s : syms) {
     e = hipModuleGetFunction(s.f, out->module, s.name);
@@ -187,8 +197,12 @@ inline hipError_t jit_launch(hipFunction_t f, const Args& args, unsigned gx, uns
                              hipStream_t stream) {
   Args copy = args;
   void* params[] = {&copy};
-  if (lds > 48 * 1024)
+  if (lds > 48 * 1024) {
+    // opt-in for large dynamic LDS where the runtime wants one; module functions do not need it on
+    // ROCm and the call may fail for them -- its error must not linger for a later hipGetLastError()
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipGetLastError();
+  }
   return hipModuleLaunchKernel(f, gx, gy, 1, block, 1, 1, lds, stream, params, nullptr);
 }
 

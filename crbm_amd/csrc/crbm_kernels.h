@@ -41,14 +41,58 @@ struct Philox4 {
   uint32_t v[4];
 };
 
+// ---------------------------------------------------------------------------
+// The one place that depends on the compiler: hipcc / hiprtc (clang) get the
+// gfx950 instructions, the CPU emulation build of the same header (g++,
+// tests/emu) gets portable equivalents supplied by its shim.
+// ---------------------------------------------------------------------------
+struct HalfFrag {     // eight f16 = one A or B fragment of v_mfma_f32_16x16x32_f16
+  uint32_t r[4];
+};
+#if defined(__clang__)
+typedef float floatx4 __attribute__((ext_vector_type(4)));
 // a ^ b ^ c in one instruction (v_bitop3_b32, truth table 0x96); the compiler does not fuse it itself
-__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
-#if defined(__clang__)   // hipcc / hiprtc; the CPU emulation build (g++) takes the plain form
-  return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
-#else
-  return a ^ b ^ c;
-#endif
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+// 16-byte store that does not linger in the caches (the chain state is written once
+// per launch and next read by another launch: measured 0.45 us per launch at config #2)
+__device__ __forceinline__ void store4_streaming(uint32_t* dst, uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
+  typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+  const u4v val = {x, y, z, w};
+  __builtin_nontemporal_store(val, reinterpret_cast<u4v*>(dst));
 }
+// x = hi + lo with both halves f16 (round to nearest): 22 significant bits, v_cvt_pk_f16_f32 +
+// v_cvt_f32_f16 + v_pk_add_f32 per pair
+__device__ __forceinline__ void split_f16(const float (&x)[8], HalfFrag& hi, HalfFrag& lo) {
+  typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+  half8 h, l;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    h[e] = (_Float16)x[e];
+    l[e] = (_Float16)(x[e] - (float)h[e]);
+  }
+  hi = __builtin_bit_cast(HalfFrag, h);
+  lo = __builtin_bit_cast(HalfFrag, l);
+}
+// D = A (16 x 32) * B (32 x 16) + C on the matrix core.  Lane l holds A[row l&15][8(l>>4) .. +7],
+// B[8(l>>4) .. +7][col l&15] and D[rows 4(l>>4) .. +3][col l&15] (checked with integer data on gfx950:
+// tools/mfma_probe.hip)
+__device__ __forceinline__ floatx4 mfma_16x16x32_f16(const HalfFrag& a, const HalfFrag& b, floatx4 c) {
+  typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
+}
+#else   // CPU emulation build (tests/emu/shim/hip/hip_runtime.h implements the wave-wide parts)
+typedef float floatx4 __attribute__((vector_size(16)));
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return a ^ b ^ c; }
+__device__ __forceinline__ void store4_streaming(uint32_t* dst, uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
+  *reinterpret_cast<uint4*>(dst) = make_uint4(x, y, z, w);
+}
+__device__ __forceinline__ void split_f16(const float (&x)[8], HalfFrag& hi, HalfFrag& lo) { emu::split_f16(x, hi.r, lo.r); }
+__device__ __forceinline__ floatx4 mfma_16x16x32_f16(const HalfFrag& a, const HalfFrag& b, floatx4 c) {
+  float d[4] = {c[0], c[1], c[2], c[3]};
+  emu::mfma_16x16x32_f16(a.r, b.r, d);
+  return floatx4{d[0], d[1], d[2], d[3]};
+}
+#endif
 
 __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                                  uint32_t k0, uint32_t k1) {
@@ -93,9 +137,15 @@ __device__ __forceinline__ uint32_t rng_word2(uint32_t kind, uint32_t strand, ui
 }
 
 __device__ __forceinline__ uint32_t fastdiv(uint32_t i, const FastDiv& f) {
-  return f.d <= 1 ? i : __umulhi(i, f.inv);
+  if (f.d <= 1) return i;
+  uint32_t q = __umulhi(i, f.inv);
+  if (f.fix && q * f.d > i) --q;   // long rows only (crbm_layout.h): the estimate is q or q + 1
+  return q;
 }
 
+// The MFMA statistics carry probabilities scaled by 2^14 (and a one-hot operand of 2^-14):
+// the f16 halves of P then stay normal numbers down to P ~ 4e-9 instead of 6e-5.
+constexpr float STATS_PSCALE_INV = 6.103515625e-05f;   // 2^-14
 // z = -x*log2(e) (what conv_gather returns): exp(-x) = 2^z
 __device__ __forceinline__ float exp_neg_x(float z) { return __builtin_amdgcn_exp2f(z); }
 // v_rcp_f32 (1 ulp); __fdividef expands to a full division sequence under hiprtc
@@ -153,7 +203,8 @@ __device__ __forceinline__ float wave_max_nonneg(float v) {
 // and the fine call is made only when some lane of the wave lands in between
 // (2^-12 per unit).  Returns the K-bit mask; optionally the probabilities.
 // ---------------------------------------------------------------------------
-template <class C, bool WANT_P>
+// WANT_P: 0 none, 1 p = sigma(x), 2 p = 2^14 * sigma(x) (the scale of the MFMA statistics, below)
+template <class C, int WANT_P>
 __device__ __forceinline__ void sample_hidden(const float (&z)[C::KP], uint32_t n, uint32_t s, uint32_t kind,
                                               uint32_t strand, const RngView& rng, uint32_t step,
                                               uint32_t (&mask)[C::NW], float (&p)[C::KP]) {
@@ -174,7 +225,8 @@ __device__ __forceinline__ void sample_hidden(const float (&z)[C::KP], uint32_t 
         const uint32_t one = x2 <= 4096.0f ? 1u : 0u;
         amb |= (x1 <= 4096.0f && !(x2 <= 4096.0f)) ? (1u << i) : 0u;
         mask[k >> 5] |= one << (k & 31);
-        if (WANT_P) p[k] = fast_rcp(1.0f + e);
+        if (WANT_P == 1) p[k] = fast_rcp(1.0f + e);
+        if (WANT_P == 2) p[k] = fast_rcp(fmaf(e, STATS_PSCALE_INV, STATS_PSCALE_INV));
       }
     };
     unit(IC<0>{}); unit(IC<1>{}); unit(IC<2>{}); unit(IC<3>{}); unit(IC<4>{});
@@ -364,7 +416,7 @@ __device__ void hgv_body(const HgvArgs& a) {
       uint32_t mask[C::NW];
       float p[KP];
       if (want_sample) {
-        sample_hidden<C, true>(x, a.rng.seq_offset + (uint32_t)nn, (uint32_t)s, a.kind, strand, a.rng, a.rng.step,
+        sample_hidden<C, 1>(x, a.rng.seq_offset + (uint32_t)nn, (uint32_t)s, a.kind, strand, a.rng, a.rng.step,
                                mask, p);
       } else {
 #pragma unroll
@@ -386,6 +438,329 @@ __device__ void hgv_body(const HgvArgs& a) {
   if (a.ones && cnt) atomicAdd(a.ones, cnt);
 }
 
+// ===========================================================================
+// Gradient statistics on the matrix cores.
+//
+// VH[k,a,j] = sum_{n,s} P[n,k,s] * [letter(n, s+j) == a]   (convRBM.py:327-337)
+// is a K x (4*M) output contracted over N*Lh positions: a GEMM whose one operand
+// (the unfolded one-hot) is exact in any float format and whose other operand, P,
+// is split into two f16 halves (22 significant bits, products exact in f32).  One
+// v_mfma_f32_16x16x32_f16 contracts 32 consecutive hidden positions of a chain:
+//   A (16 x 32): row i = filter column j = 16*jt + i of letter a, element (i, t) =
+//                2^-14 * [letter(s0 + t + j) == a] -- eight consecutive bits of the
+//                letter's bit plane, expanded to eight f16 by one 16-byte LUT read;
+//   B (32 x 16): column i = motif 16*nt + i of one column kind (P of the forward
+//                strand, P' of the rc strand, Q = P(1-P) for the sparsity gradient,
+//                convRBM.py:440-451), element (t, i) = 2^14 * P[k, s0 + t], read
+//                from an LDS image the h|v pass writes transposed ([column][position]).
+// The accumulators (one 16x16 f32 tile per letter x column tile x motif tile) stay in
+// registers for the whole kernel; waves of a block are combined through LDS at the
+// end and the block writes one partial row.  Against the letter-bucketed walk this
+// replaces (stats_body: one LDS read and one VALU add per (k, j, position)), the
+// parked rows are read once instead of M times and the adds run on the matrix pipe
+// beside the VALU work of the next chunk's h|v pass.
+// north_star's "no MFMA" is about the convolution and its transpose (4-wide output,
+// one-hot operand: gathers); this contraction is the one dense product on the path.
+// ===========================================================================
+struct StatsGeom {
+  int32_t GPC;                                   // groups per chain
+  int32_t off_slices, slice, off_win, off_gw, off_pt;   // LDS layout (floats): first slice, slice size, offsets inside a slice
+  FastDiv divGPC;
+  int32_t row, off_vh0, off_vh1, off_h0, off_h1, off_sw, off_sb, off_v;
+  float* partials;                               // [gridDim.x][row]
+};
+
+// kinds, motif tiles per wave, roles; mirrors stats_mfma_layout()
+template <class C, bool SP>
+struct StatsRole {
+  static constexpr int KINDS = 1 + C::DS + (SP ? 1 : 0);
+  static constexpr int NTW = stats_ntw(C::NT, C::JT, KINDS);
+  static constexpr int NR = C::NT / NTW;
+  static constexpr int KW = 16 * NTW < C::K ? 16 * NTW : C::K;
+  static constexpr int ROWS = KINDS * KW + 1;
+  static constexpr int NACC = 4 * C::JT * KINDS * NTW;
+  static constexpr int THREADS = stats_mfma_threads(NR);
+  static constexpr int NQW = 4 * NTW;            // float4 quads of motifs a wave gathers
+};
+
+// nibble -> four f16: bit e set -> 2^-14 (0x0400), else 0 (16 entries of 8 bytes)
+__device__ __forceinline__ void stats_build_lut(uint32_t* lut) {
+  if (threadIdx.x < 32) {
+    const uint32_t n = threadIdx.x >> 1, q = threadIdx.x & 1u;
+    lut[threadIdx.x] = ((n >> (2 * q)) & 1u ? 0x0400u : 0u) | ((n >> (2 * q + 1)) & 1u ? 0x04000000u : 0u);
+  }
+}
+
+// bit t of the result = [letter t of the packed word == a], t = 0..15
+__device__ __forceinline__ uint32_t letter_plane16(uint32_t word, uint32_t a) {
+  uint32_t x = word ^ (a * 0x55555555u);          // 00 where the letter is a
+  x = ~(x | (x >> 1)) & 0x55555555u;
+  x = (x | (x >> 1)) & 0x33333333u;
+  x = (x | (x >> 2)) & 0x0F0F0F0Fu;
+  x = (x | (x >> 4)) & 0x00FF00FFu;
+  return (x | (x >> 8)) & 0xFFFFu;
+}
+
+// The letter windows of a unit (2 groups x 4 letters x 64 bits) are built by 32 lanes: lane t owns
+// letter (t & 3), letter word (t >> 2) & 3 (16 positions) of group slot (t >> 4) and stores its 16
+// plane bits straight into the window (win as 16-bit pieces: piece index slot*16 + letter*4 + word).
+// Returns the number of its positions that count for the letter statistics: a group owns its 32
+// positions (words 0, 1), the last group of a chain also the tail up to L (words 2, 3).
+__device__ __forceinline__ float stats_window_piece(unsigned short* win16, int t, uint32_t word, bool group_valid, int gi, int GPC, int L) {
+  const int a = t & 3, w = (t >> 2) & 3, slot = t >> 4;
+  const uint32_t bits = group_valid ? letter_plane16(word, (uint32_t)a) : 0u;
+  win16[slot * 16 + a * 4 + w] = (unsigned short)bits;
+  const int p0 = 32 * gi + 16 * w;                              // first position of this piece
+  const int limit = (w < 2 || gi == GPC - 1) ? L : 0;           // positions >= limit do not count
+  const int nbits = limit - p0 < 0 ? 0 : (limit - p0 > 16 ? 16 : limit - p0);
+  return (float)__popc(bits & ((1u << nbits) - 1u));
+}
+
+// z[] = the gather of motif quads [q0, q0 + NQW) (clamped to the model's NQ); z = -log2(e) * activation
+template <class C, int NQW>
+__device__ __forceinline__ void conv_gather_quads(const float* T, uint64_t win, int q0, float (&z)[4 * NQW]) {
+#pragma unroll
+  for (int i = 0; i < 4 * NQW; ++i) z[i] = 0.f;   // quads beyond the model's NQ
+  auto group = [&](int g, auto FIRST) {
+    constexpr bool first = decltype(FIRST)::value != 0;   // the first group assigns
+    const uint32_t r = (uint32_t)(win >> (2 * C::G * g)) & (uint32_t)(C::ROWS - 1);
+    const float4* row = reinterpret_cast<const float4*>(T + (size_t)g * C::ROWS * C::KP) + (size_t)r * C::NQ + q0;
+#pragma unroll
+    for (int q = 0; q < NQW; ++q)
+      if (q0 + q < C::NQ) {        // wave-uniform
+        const float4 t = row[q];
+        if (first) {
+          z[4 * q + 0] = t.x; z[4 * q + 1] = t.y; z[4 * q + 2] = t.z; z[4 * q + 3] = t.w;
+        } else {
+          z[4 * q + 0] += t.x; z[4 * q + 1] += t.y; z[4 * q + 2] += t.z; z[4 * q + 3] += t.w;
+        }
+      }
+  };
+  group(0, IC<1>{});
+  if constexpr (C::NG * NQW <= 48) {
+#pragma unroll
+    for (int g = 1; g < C::NG; ++g) group(g, IC<0>{});
+  } else {
+#pragma unroll 1
+    for (int g = 1; g < C::NG; ++g) group(g, IC<0>{});
+  }
+}
+
+// One 32-position group (slot 0 or 1 of the wave's unit): all accumulator tiles of the wave.
+//   Pt  : the wave's column image (row kind*KW + i, stride STATS_RS, position slot*32 + t)
+//   win : the group's four 64-bit letter windows
+template <class C, int KINDS, int NTW>
+__device__ __forceinline__ void stats_mfma_group(const float* Pt, const uint2* win, const uint2* lut, int nt0, int slot,
+                                                 floatx4 (&acc)[4 * C::JT * KINDS * NTW]) {
+  constexpr int KW = 16 * NTW < C::K ? 16 * NTW : C::K, ZROW = KINDS * KW;
+  const int lane = threadIdx.x & 63, i16 = lane & 15, g = lane >> 4;
+  HalfFrag bhi[KINDS * NTW], blo[KINDS * NTW];
+#pragma unroll
+  for (int kind = 0; kind < KINDS; ++kind)
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      const int kl = 16 * t + i16;
+      const int row = (16 * (nt0 + t) + i16 < C::K) ? kind * KW + kl : ZROW;     // motifs beyond K: the all-zero row
+      const float4* src = reinterpret_cast<const float4*>(Pt + (size_t)row * STATS_RS + slot * 32 + 8 * g);
+      const float4 x0 = src[0], x1 = src[1];
+      const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+      split_f16(x, bhi[kind * NTW + t], blo[kind * NTW + t]);
+    }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const uint2 w = win[a];
+    const unsigned long long bits = (unsigned long long)w.x | ((unsigned long long)w.y << 32);
+#pragma unroll
+    for (int jt = 0; jt < C::JT; ++jt) {
+      const uint32_t byte = (uint32_t)(bits >> (8 * g + i16 + 16 * jt));
+      const uint2 f0 = lut[byte & 15u], f1 = lut[(byte >> 4) & 15u];
+      HalfFrag af;
+      af.r[0] = f0.x; af.r[1] = f0.y; af.r[2] = f1.x; af.r[3] = f1.y;
+#pragma unroll
+      for (int c = 0; c < KINDS * NTW; ++c) {
+        floatx4& d = acc[(a * C::JT + jt) * KINDS * NTW + c];
+        d = mfma_16x16x32_f16(af, bhi[c], d);
+        d = mfma_16x16x32_f16(af, blo[c], d);
+      }
+    }
+  }
+}
+
+// Combines the waves of a block (fixed order) and writes the block's partial row:
+// vh / vh' / sw blocks, the H and sparsity-bias sums (filter column 0 pairs every hidden
+// position with exactly one letter: sum_s P[k,s] = sum_a VH[k,a,0]) and the letter counts.
+// Uses the LDS of the block from its base on (everything is dead by now); all threads call it.
+template <class C, bool SP>
+__device__ __forceinline__ void stats_mfma_finish(const StatsGeom& sg, float* lds, int nt0, int wave_in_role, int waves_per_role,
+                                                  const floatx4 (&acc)[StatsRole<C, SP>::NACC], float vcount) {
+  using R = StatsRole<C, SP>;
+  constexpr int K = C::K, M = C::M, KAM = K * 4 * M, KINDS = R::KINDS, NTW = R::NTW;
+  const int nthr = blockDim.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = nthr >> 6;
+  const int i16 = lane & 15, g = lane >> 4;
+  float* buf = lds;                   // [KINDS][KAM]
+  float* xch = lds + KINDS * KAM;     // [nwaves][4]
+  float* out = sg.partials + (size_t)blockIdx.x * sg.row;
+  __syncthreads();
+  for (int p = 0; p < waves_per_role; ++p) {
+    if (wave_in_role == p) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int jt = 0; jt < C::JT; ++jt)
+#pragma unroll
+          for (int kind = 0; kind < KINDS; ++kind)
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+              const int k = 16 * (nt0 + t) + i16;
+              const floatx4 d = acc[((a * C::JT + jt) * KINDS + kind) * NTW + t];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int j = 16 * jt + 4 * g + r;
+                if (j < M && k < K) {
+                  const int idx = kind * KAM + (k * 4 + a) * M + j;
+                  buf[idx] = p == 0 ? d[r] : buf[idx] + d[r];
+                }
+              }
+            }
+    }
+    __syncthreads();
+  }
+  constexpr int KIND_Q = 1 + C::DS;
+  for (int i = threadIdx.x; i < KAM; i += nthr) {
+    out[sg.off_vh0 + i] = buf[i];
+    if (C::DS) out[sg.off_vh1 + i] = buf[KAM + i];
+    if (SP) out[sg.off_sw + i] = buf[KIND_Q * KAM + i];
+  }
+  for (int k = threadIdx.x; k < K; k += nthr) {
+    auto col0 = [&](const float* t) { return (t[(k * 4) * M] + t[(k * 4 + 1) * M]) + (t[(k * 4 + 2) * M] + t[(k * 4 + 3) * M]); };
+    out[sg.off_h0 + k] = col0(buf);
+    if (C::DS) out[sg.off_h1 + k] = col0(buf + KAM);
+    if (SP) out[sg.off_sb + k] = col0(buf + KIND_Q * KAM);
+  }
+  // letter counts: lane l counted letter (l & 3); lanes of one class -> wave -> block, fixed order
+  const float cls = class_sum(vcount);
+  if (lane < 4) xch[wave * 4 + lane] = cls;
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    float t = 0.f;
+    for (int w = 0; w < nwaves; ++w) t += xch[w * 4 + threadIdx.x];
+    out[sg.off_v + threadIdx.x] = t;
+  }
+}
+
+struct StatsMfmaArgs {
+  const float* tables;
+  const uint32_t* letters;
+  int32_t n, L, Lh, LW;
+  int32_t off_tab;      // gather tables inside LDS (floats), after the slices
+  StatsGeom sg;
+};
+
+// Stand-alone statistics of (letters, n, L): the data half of a training step (SP: with the
+// sparsity columns) and the model half of models whose accumulator set is too large to ride
+// in the Gibbs kernel.  A wave loops over units of two groups: lanes 0-7 stage the groups'
+// letter words (fetched one unit ahead) and build the letter windows, every lane computes P of
+// one hidden position for the wave's motifs and parks it transposed, then the MFMA steps run.
+template <class C, bool SP>
+__device__ void stats_mfma_body(const StatsMfmaArgs& a) {
+  using R = StatsRole<C, SP>;
+  constexpr int K = C::K, M = C::M, KINDS = R::KINDS, NTW = R::NTW, NR = R::NR, KW = R::KW;
+  HIP_DYNAMIC_SHARED(float, smem);
+  const StatsGeom& sg = a.sg;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  uint32_t* lut = reinterpret_cast<uint32_t*>(smem);
+  float* slice = smem + sg.off_slices + (size_t)wave * sg.slice;
+  uint2* win = reinterpret_cast<uint2*>(slice + sg.off_win);
+  uint32_t* gw = reinterpret_cast<uint32_t*>(slice + sg.off_gw);
+  float* Pt = slice + sg.off_pt;
+  float* Tf = smem + a.off_tab;
+  float* Tr = Tf + C::TAB;
+  copy_tables<C::TAB>(Tf, a.tables + C::OFF_TF);
+  if (C::DS) copy_tables<C::TAB>(Tr, a.tables + C::OFF_TR);
+  stats_build_lut(lut);
+  for (int i = lane; i < R::ROWS * STATS_RS; i += 64) Pt[i] = 0.f;   // the zero row (and the pad columns) stay zero
+  __syncthreads();
+
+  const int role = wave % NR, wave_in_role = wave / NR, waves_per_role = nwaves / NR;
+  const int nt0 = role * NTW;
+  floatx4 acc[R::NACC];
+#pragma unroll
+  for (int t = 0; t < R::NACC; ++t) acc[t] = floatx4{0.f, 0.f, 0.f, 0.f};
+  float vcount = 0.f;                                  // letter (lane & 3), lanes 0-7 of role-0 waves
+
+  const int GPC = sg.GPC;
+  const long ngroups = (long)a.n * GPC;
+  const long nunits = (ngroups + 1) / 2;
+  const long ustride = (long)gridDim.x * waves_per_role;
+  // letter words of a unit: lane t < 32 fetches word (t >> 2) & 3 of group slot (t >> 4) (four lanes,
+  // one per letter, fetch the same word: one transaction) and later turns it into its window piece
+  unsigned short* win16 = reinterpret_cast<unsigned short*>(win);
+  auto fetch_word = [&](long u) -> uint32_t {
+    if (lane >= 32 || u >= nunits) return 0u;
+    const long G = 2 * u + (lane >> 4);
+    if (G >= ngroups) return 0u;
+    const uint32_t chain = fastdiv((uint32_t)G, sg.divGPC);
+    const int w = 2 * (int)(G - (long)chain * GPC) + ((lane >> 2) & 3);
+    return w < a.LW ? a.letters[(size_t)chain * a.LW + w] : 0u;
+  };
+  long u = (long)blockIdx.x * waves_per_role + wave_in_role;
+  uint32_t pre = fetch_word(u);
+  for (; u < nunits; u += ustride) {
+    const long G0 = 2 * u;
+    if (lane < 32) {
+      const long G = G0 + (lane >> 4);
+      int gi = 0;
+      if (G < ngroups) gi = (int)(G - (long)fastdiv((uint32_t)G, sg.divGPC) * GPC);
+      if ((lane & 3) == 0) gw[lane >> 2] = pre;        // the packed words themselves feed the h|v gather below
+      const float cnt = stats_window_piece(win16, lane, pre, G < ngroups, gi, GPC, a.L);
+      if (role == 0) vcount += cnt;
+    }
+    __builtin_amdgcn_wave_barrier();
+    pre = fetch_word(u + ustride);                     // in flight during this unit
+    // ---- P (and P', Q) of this lane's hidden position for the wave's motifs, parked transposed ----
+    {
+      const int slot = lane >> 5, e = lane & 31;
+      const long G = G0 + slot;
+      bool valid = G < ngroups;
+      if (valid) {
+        const uint32_t chain = fastdiv((uint32_t)G, sg.divGPC);
+        valid = 32 * (int)(G - (long)chain * GPC) + e < a.Lh;
+      }
+      float* col = Pt + lane;
+      if (valid) {
+        const uint64_t wl = letter_window<M>(gw + 4 * slot, e);
+        float z[4 * R::NQW];
+        conv_gather_quads<C, R::NQW>(Tf, wl, 4 * nt0, z);
+#pragma unroll
+        for (int kl = 0; kl < KW; ++kl)
+          if (16 * nt0 + kl < K) {                     // wave-uniform
+            const float ps = fast_rcp(fmaf(exp_neg_x(z[kl]), STATS_PSCALE_INV, STATS_PSCALE_INV));   // 2^14 * sigma(x)
+            col[(size_t)kl * STATS_RS] = ps;
+            if (SP) col[(size_t)((1 + C::DS) * KW + kl) * STATS_RS] = fmaf(-ps * STATS_PSCALE_INV, ps, ps);   // 2^14 * P(1-P)
+          }
+        if (C::DS) {
+          conv_gather_quads<C, R::NQW>(Tr, wl, 4 * nt0, z);
+#pragma unroll
+          for (int kl = 0; kl < KW; ++kl)
+            if (16 * nt0 + kl < K)
+              col[(size_t)(KW + kl) * STATS_RS] = fast_rcp(fmaf(exp_neg_x(z[kl]), STATS_PSCALE_INV, STATS_PSCALE_INV));
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < KINDS * KW; ++r) col[(size_t)r * STATS_RS] = 0.f;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- the MFMA steps of the unit ----
+#pragma unroll
+    for (int slot = 0; slot < 2; ++slot)
+      if (G0 + slot < ngroups)
+        stats_mfma_group<C, KINDS, NTW>(Pt, win + 4 * slot, reinterpret_cast<const uint2*>(lut), nt0, slot, acc);
+    __builtin_amdgcn_wave_barrier();                   // the slice is rewritten by the next unit
+  }
+  stats_mfma_finish<C, SP>(sg, smem, nt0, wave_in_role, waves_per_role, acc, vcount);
+}
+
 // ---------------------------------------------------------------------------
 // The persistent-chain kernel: `steps` Gibbs steps
 //   v ~ P(v|h,h')  (convRBM.py:317-325)   then   h,h' ~ P(h|v)  (:269-275)
@@ -405,6 +780,9 @@ struct GibbsArgs {
   RngView rng;
   uint32_t* ones;      // [gridDim.x * waves per block] set bits of the final hidden state per wave (activity monitor), may be null
   int32_t debug;       // profiling only: 1 skips the table copy, 2 the state load, 4 the state store
+  // STATS variant only: the model half of the gradient statistics rides in the last h|v pass
+  int32_t stats_off;   // statistics region inside LDS (floats, 16-byte aligned), after the chain image
+  StatsGeom sg;        // divGPC divides group indices of one tile
 };
 
 // letter of one visible position from its 4 top-down activations
@@ -413,18 +791,6 @@ __device__ __forceinline__ uint32_t sample_letter(float y0, float y1, float y2, 
   const float e0 = __expf(y0 - mx), e1 = __expf(y1 - mx), e2 = __expf(y2 - mx), e3 = __expf(y3 - mx);
   const float t = u * ((e0 + e1) + (e2 + e3));
   return (uint32_t)(t >= e0) + (uint32_t)(t >= e0 + e1) + (uint32_t)(t >= (e0 + e1) + e2);
-}
-
-// 16-byte store that does not linger in the caches (the chain state is written once
-// per launch and next read by another launch: measured 0.45 us per launch at config #2)
-__device__ __forceinline__ void store4_streaming(uint32_t* dst, uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
-#ifdef __clang__
-  typedef uint32_t u4v __attribute__((ext_vector_type(4)));
-  const u4v val = {x, y, z, w};
-  __builtin_nontemporal_store(val, reinterpret_cast<u4v*>(dst));
-#else   // CPU emulation build (tests/emu)
-  *reinterpret_cast<uint4*>(dst) = make_uint4(x, y, z, w);
-#endif
 }
 
 // Adds the top-down contributions of every set bit of one window word to the 4
@@ -461,10 +827,17 @@ __device__ __forceinline__ void topdown_bits(unsigned long long w, const char* t
 
 // SPARSE selects the top-down variant (Cfg comment in crbm_layout.h); the LDS image
 // differs accordingly.  The dense variant exists only for Cfg::DENSE models.
-template <class C, bool SPARSE>
+// STATS: the last h|v pass also produces the model half of the gradient statistics
+// (convRBM.py:411-413: last-step probabilities, last-step visible sample): the pass runs
+// in wave units of two 32-position groups, every lane parks the probabilities it has in
+// registers anyway in the wave's LDS slice, and the wave contracts them with the visible
+// sample (still in LDS) on the matrix cores -- no second read of v, no recomputation of P.
+template <class C, bool SPARSE, bool STATS = false>
 __device__ void gibbs_body(const GibbsArgs& a) {
   constexpr int KP = C::KP, M = C::M, NW = C::NW, NCH = C::NCH;
   static_assert(SPARSE || C::DENSE, "no dense top-down tables for this model");
+  using SR = StatsRole<C, false>;
+  static_assert(!STATS || SR::NR == 1, "the fused statistics need all motifs of a position in one wave");
   constexpr int LTAB = SPARSE ? C::SP_TABLES : C::TABLES;
   HIP_DYNAMIC_SHARED(float, smem);
   const float* Tf = smem;
@@ -487,6 +860,20 @@ __device__ void gibbs_body(const GibbsArgs& a) {
   const uint32_t per = (uint32_t)(a.Lf * NW);           // state words per chain
   const int ntiles = (a.nchains + a.S - 1) / a.S;
   int nset = 0;
+  // statistics state (STATS): the wave's LDS slice, accumulator tiles, letter counts
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  float* sreg = smem + a.stats_off;
+  float* sslice = sreg + a.sg.off_slices + (size_t)wave * a.sg.slice;
+  uint2* swin = reinterpret_cast<uint2*>(sslice + a.sg.off_win);
+  float* sPt = sslice + a.sg.off_pt;
+  floatx4 sacc[STATS ? SR::NACC : 1];
+  float vcount = 0.f;
+  if constexpr (STATS) {
+#pragma unroll
+    for (int t = 0; t < SR::NACC; ++t) sacc[t] = floatx4{0.f, 0.f, 0.f, 0.f};
+    stats_build_lut(reinterpret_cast<uint32_t*>(sreg));
+    for (int i = lane; i < SR::ROWS * STATS_RS; i += 64) sPt[i] = 0.f;   // the zero row stays zero
+  }
   // the pads of the mask rows (M-1 positions in front, the rest behind) stay zero for the whole kernel
   {
     const int padw = rowW - (int)per, front = (M - 1) * NW;
@@ -654,6 +1041,70 @@ __device__ void gibbs_body(const GibbsArgs& a) {
         reinterpret_cast<unsigned char*>(let + (size_t)nl * a.LWs)[pb] = (unsigned char)byte;
       }
       __syncthreads();
+      bool fused_pass = false;
+      if constexpr (STATS) if (st == a.steps - 1) {
+        fused_pass = true;
+        // ---- last h | v with the model statistics: wave units of two 32-position groups ----
+        constexpr int KW = SR::KW;
+        const int GPC = a.sg.GPC, ngl = ns * GPC;
+        for (int u = wave; 2 * u < ngl; u += nwaves) {
+          const int G0 = 2 * u;
+          if (lane < 32) {                      // letter windows of the two groups (and the letter counts)
+            const int G = G0 + (lane >> 4), w = (lane >> 2) & 3;
+            int gi = 0;
+            uint32_t word = 0u;
+            if (G < ngl) {
+              const uint32_t nl = fastdiv((uint32_t)G, a.sg.divGPC);
+              gi = G - (int)nl * GPC;
+              if (2 * gi + w < a.LWs) word = let[(size_t)nl * a.LWs + 2 * gi + w];
+            }
+            vcount += stats_window_piece(reinterpret_cast<unsigned short*>(swin), lane, word, G < ngl, gi, GPC, a.Lv);
+          }
+          __builtin_amdgcn_wave_barrier();
+          {
+            const int slot = lane >> 5, G = G0 + slot;
+            bool valid = G < ngl;
+            uint32_t nl = 0u;
+            int s = 0;
+            if (valid) {
+              nl = fastdiv((uint32_t)G, a.sg.divGPC);
+              s = 32 * (G - (int)nl * GPC) + (lane & 31);
+              valid = s < a.Lf;
+            }
+            float* col = sPt + lane;
+            if (valid) {
+              const uint32_t gn = a.rng.seq_offset + (uint32_t)(n0 + nl);
+              const uint64_t win = letter_window<M>(let + (size_t)nl * a.LWs, s);
+#pragma unroll
+              for (int strand = 0; strand <= C::DS; ++strand) {
+                float x[KP], p[KP];
+                conv_gather<C>(strand ? Tr : Tf, win, x);
+                uint32_t mask[NW];
+                sample_hidden<C, 2>(x, gn, (uint32_t)s, KIND_CHAIN_H, (uint32_t)strand, a.rng,
+                                    a.rng.step + (uint32_t)st, mask, p);
+                uint32_t* dst = (strand ? hmp : hm) + (size_t)nl * rowW + (size_t)(s + M - 1) * NW;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                  dst[w] = mask[w];
+                  nset += __popc(mask[w]);
+                }
+#pragma unroll
+                for (int k = 0; k < C::K; ++k) col[(size_t)(strand * KW + k) * STATS_RS] = p[k];
+              }
+            } else {
+#pragma unroll
+              for (int r = 0; r < SR::KINDS * KW; ++r) col[(size_t)r * STATS_RS] = 0.f;
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int slot = 0; slot < 2; ++slot)
+            if (G0 + slot < ngl)
+              stats_mfma_group<C, SR::KINDS, SR::NTW>(sPt, swin + 4 * slot, reinterpret_cast<const uint2*>(sreg), 0, slot, sacc);
+          __builtin_amdgcn_wave_barrier();       // the slice is rewritten by the next unit
+        }
+      }
+      if (!fused_pass)
       // ---- h | v : x[k,s] = b[k] + sum_j W[k, letter[s+j], j]; h = [sigma(x) > u] ----
       // one hidden position per item (nhb = Lf items per chain): the K units of a position
       // already give the instruction-level parallelism, and single positions spread evenly
@@ -668,7 +1119,7 @@ __device__ void gibbs_body(const GibbsArgs& a) {
           float x[KP], p[KP];
           conv_gather<C>(strand ? Tr : Tf, win, x);
           uint32_t mask[NW];
-          sample_hidden<C, false>(x, gn, (uint32_t)s, KIND_CHAIN_H, (uint32_t)strand, a.rng,
+          sample_hidden<C, 0>(x, gn, (uint32_t)s, KIND_CHAIN_H, (uint32_t)strand, a.rng,
                                   a.rng.step + (uint32_t)st, mask, p);
           uint32_t* dst = (strand ? hmp : hm) + (size_t)nl * rowW + (size_t)(s + M - 1) * NW;
 #pragma unroll
@@ -710,6 +1161,7 @@ __device__ void gibbs_body(const GibbsArgs& a) {
     const float tot = wave_sum((float)nset);
     if ((threadIdx.x & 63) == 0) a.ones[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = (uint32_t)tot;
   }
+  if constexpr (STATS) stats_mfma_finish<C, false>(a.sg, smem, 0, wave, nwaves, sacc, vcount);
 }
 
 // ---------------------------------------------------------------------------
@@ -1235,6 +1687,17 @@ __device__ void hit_summary_body(const HitArgs& a) {
 // ===========================================================================
 // Model-independent kernels, compiled ahead of time into libcrbm_hip.so.
 // ===========================================================================
+
+// plain streaming copy, 16 bytes per lane (crbm_copy_bandwidth)
+__global__ void __launch_bounds__(256) copy_float4_kernel(const float4* src, float4* dst, size_t n4) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {      // four loads in flight per lane
+    const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+    dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+  }
+  for (; i < n4; i += stride) dst[i] = src[i];
+}
 
 // one-hot fp32 (n,1,4,L) -> packed letters [n][LW]; flags[0] |= 1 on a column
 // that is not exactly one-hot.

@@ -12,14 +12,19 @@ enum : uint32_t {
   KIND_CHAIN_H = 1, KIND_CHAIN_V = 2, KIND_EVAL_H = 3, KIND_API_H = 4, KIND_API_V = 5
 };
 
-// Exact n / d for n*d < 2^31 via one mul_hi (d >= 1).
+// n / d via one mul_hi (d >= 1).  With inv = floor(2^32 / d) + 1 the estimate
+// mulhi(n, inv) is exact while n*d < 2^32 and otherwise at most one too large
+// (n*inv/2^32 = n/d + n*e/(d*2^32), 0 < e <= d): `fix` asks the device for the
+// one-step correction.  The host sets it from the largest dividend the kernel
+// will present (items of one tile), so short rows keep the single instruction.
 struct FastDiv {
-  uint32_t d, inv;
+  uint32_t d, inv, fix;
 };
-inline FastDiv make_fastdiv(uint32_t d) {
+inline FastDiv make_fastdiv(uint32_t d, uint64_t max_n = (1ull << 20)) {
   FastDiv f;
   f.d = d;
   f.inv = (d <= 1) ? 0u : (uint32_t)(0x100000000ull / d) + 1u;
+  f.fix = (max_n * (uint64_t)d >= 0x100000000ull) ? 1u : 0u;
   return f;
 }
 
@@ -102,6 +107,15 @@ struct Cfg {
 #define CRBM_STATS_WAVES_SMALL 4
 #endif
   static constexpr int STATS_WAVES = (STATS_FIXED4 + 24 * 1024 > 78 * 1024) ? CRBM_STATS_WAVES_BIG : CRBM_STATS_WAVES_SMALL;
+  // MFMA statistics (stats_mfma_body, fused tail of gibbs_body): one v_mfma_f32_16x16x32_f16
+  // contracts 32 hidden positions; its 16 output rows are 16 filter columns of one letter, its
+  // 16 output columns are 16 motifs of one column kind (P, P' of the rc strand, P(1-P))
+  static constexpr int NT = cdiv(K, 16);                  // motif tiles per column kind
+  static constexpr int JT = cdiv(M, 16);                  // filter-column tiles per letter
+  // the model half of the statistics rides in the Gibbs kernel's last h|v pass when all motifs of
+  // a position fit one wave's accumulator set of at most 8 tiles (32 registers; measured: with 16 tiles,
+  // config #5, the fused kernel drops to one wave per SIMD and loses to the separate launch)
+  static constexpr bool FUSE_STATS = 4 * JT * (1 + DS) * NT <= 8;
   static constexpr int OFF_TR = DS ? TAB : END2;
   static constexpr int TABLES_ALL = DS ? END2 : END2 + TAB;
   // hit-summary kernel: a lane keeps the position sums of HIT_NI positions in registers
@@ -110,15 +124,17 @@ struct Cfg {
 
 // Host-side mirror of Cfg (runtime values, same arithmetic).
 struct ModelShape {
-  int K, M, DS, G;
+  int K, M, DS, G, NT, JT;
   int NQ, KP, NW, NG, ROWS, TAB, NCH, DENSE, TV, WS, NGRP;
   int OFF_TF, OFF_TR, OFF_TV, OFF_TVR, OFF_C, TABLES, OFF_WS, END2, SP_TABLES, TABLES_ALL;
-  int HIT_NI, STATS_MERGE, STATS_WAVES;
+  int HIT_NI, STATS_MERGE, STATS_WAVES, FUSE_STATS;
 };
 inline ModelShape model_shape(int K, int M, int DS, int G) {
   ModelShape s;
   s.K = K; s.M = M; s.DS = DS; s.G = G;
   s.NQ = cdiv(K, 4); s.KP = 4 * s.NQ; s.NW = cdiv(K, 32);
+  s.NT = cdiv(K, 16); s.JT = cdiv(M, 16);
+  s.FUSE_STATS = 4 * s.JT * (1 + DS) * s.NT <= 8;
   s.NG = cdiv(M, G); s.ROWS = cpow4(G); s.TAB = s.NG * s.ROWS * s.KP;
   s.NCH = cdiv(K, 5);
   s.DENSE = (s.NW == 1) && (s.NCH * M * (1 + DS) <= 64);
@@ -234,6 +250,74 @@ inline StatsLayout stats_layout(const ModelShape& ms, int want_sparsity, int Lh,
   s.row = 3 * KAM + 3 * K + 4;
   s.lds_bytes = (int)(fixed + (long)s.S * s.Rrow * per_row);
   if (s.lds_bytes < 3 * KAM * 4) s.lds_bytes = 3 * KAM * 4;   // the block's waves are combined through LDS at the end
+  return s;
+}
+
+// ---- MFMA statistics ----------------------------------------------------------------
+// Hidden positions are handled in groups of 32 (one MFMA step).  A chain of Lh hidden
+// positions is GPC = ceil(Lh / 32) groups, the tail of the last one padded with P = 0.
+// A wave works on units of two consecutive groups (64 positions, one per lane; a unit may
+// span two chains) and is autonomous: it computes P of its 64 positions, parks them
+// transposed in its own LDS slice and runs the MFMA steps on them -- no block barrier in
+// the loop.  Column kinds: P (forward strand), P' (rc strand, ds), Q = P(1-P) (forward,
+// data half).  A wave owns the 16-motif tiles [nt0, nt0 + NTW) of every kind (its role,
+// NR = NT / NTW roles), so that its accumulator set stays <= 32 tiles (128 registers);
+// a unit is processed by one wave of every role.
+//   LDS of a block:  [lut 16 x 8 B][slice of wave 0][slice of wave 1] ...   (+ gather tables)
+//   slice:           win [2][4] 64-bit letter windows: bit t of win[g][a] = [letter(32*gi + t) == a]
+//                    gw  [2][4] packed letter words of the two groups (stats_mfma_body only)
+//                    Pt  [kinds*KW + 1 rows][68] floats: row kind*KW + i = motif 16*nt0 + i of the
+//                        kind, 64 positions + 4 pad (row stride 17 x 16 B: conflict-free b128 reads);
+//                        the last row is all zero (motifs beyond K)
+//   lut:             nibble -> four f16 (bit e set -> 2^-14, else 0); two reads make an A fragment
+constexpr int STATS_RS = 68;                 // Pt row stride in floats
+constexpr int stats_ntw(int NT, int JT, int kinds) {        // motif tiles per wave
+  int ntw = NT;
+  while (ntw > 1 && (4 * JT * kinds * ntw > 32 || NT % ntw != 0)) --ntw;
+  return ntw;
+}
+// block size: 8 waves, rounded down to whole sets of roles
+constexpr int stats_mfma_threads(int NR) { return 64 * NR * (8 / NR > 0 ? 8 / NR : 1); }
+struct StatsMfmaLayout {
+  int kinds, NTW, NR, KW, rows;   // column kinds, motif tiles per wave, roles, Pt rows per kind, Pt rows
+  int threads, GPC;
+  int off_win, off_gw, off_pt, slice;   // floats inside a slice / per slice
+  int off_slices;                       // first slice (after the LUT), floats
+  int region_floats;                    // LUT + all slices
+  int combine_bytes;                    // end-of-kernel combine buffer, from the LDS base (everything is dead by then)
+  int row, off_vh[2], off_h[2], off_sw, off_sb, off_v;   // partial-row layout (same as StatsLayout)
+};
+// threads = 0: as many waves per role as the LDS (160 KiB minus `other_lds_bytes`: gather tables, or the
+// chain image of the Gibbs kernel) holds, at most 8 waves in all
+inline StatsMfmaLayout stats_mfma_layout(const ModelShape& ms, int want_sparsity, int Lh, int threads = 0,
+                                         int other_lds_bytes = 0) {
+  StatsMfmaLayout s;
+  const int K = ms.K, M = ms.M, KAM = K * 4 * M;
+  s.kinds = 1 + ms.DS + (want_sparsity ? 1 : 0);
+  s.NTW = stats_ntw(ms.NT, ms.JT, s.kinds);
+  s.NR = ms.NT / s.NTW;
+  s.KW = 16 * s.NTW < K ? 16 * s.NTW : K;
+  s.rows = s.kinds * s.KW + 1;
+  s.GPC = cdiv(Lh, 32);
+  s.off_win = 0;                        // 8 windows x 2 floats
+  s.off_gw = 16;                        // 8 words
+  s.off_pt = 24;
+  s.slice = (s.off_pt + s.rows * STATS_RS + 3) & ~3;
+  s.off_slices = 32;
+  s.threads = threads > 0 ? threads : stats_mfma_threads(s.NR);
+  if (threads <= 0)
+    while (s.threads > 64 * s.NR && (s.off_slices + (s.threads / 64) * s.slice) * 4 + other_lds_bytes > 160 * 1024)
+      s.threads -= 64 * s.NR;
+  s.region_floats = s.off_slices + (s.threads / 64) * s.slice;
+  s.combine_bytes = s.kinds * KAM * 4 + 64 * 4;
+  s.off_vh[0] = 0;
+  s.off_vh[1] = KAM;
+  s.off_h[0] = 2 * KAM;
+  s.off_h[1] = 2 * KAM + K;
+  s.off_sw = 2 * KAM + 2 * K;
+  s.off_sb = 3 * KAM + 2 * K;
+  s.off_v = 3 * KAM + 3 * K;
+  s.row = 3 * KAM + 3 * K + 4;
   return s;
 }
 

@@ -125,6 +125,10 @@ int crbm_train_step_resident(crbm_handle* h, int32_t start, int32_t end);
  * update each, enqueued back to back with one host synchronisation at the end.
  * With a communicator, rank r takes rows [n*r/R, n*(r+1)/R) of every slice. */
 int crbm_train_epoch_resident(crbm_handle* h, int32_t batchsize);
+/* The same loop for a slot that holds only THIS rank's rows of every slice, in
+ * slice order (rank r of R owns rows [n*r/R, n*(r+1)/R) of a slice of n rows):
+ * every rank uploads 1/R of the `total_rows` data set instead of all of it. */
+int crbm_train_epoch_sharded(crbm_handle* h, int32_t batchsize, int32_t total_rows);
 /* The persistent chain alone (convRBM.py:397-408): k Gibbs steps on all
  * fantasy chains, parameters frozen.  Benchmark entry. */
 int crbm_gibbs_steps(crbm_handle* h, int32_t k);
@@ -196,6 +200,11 @@ int crbm_hit_summary_resident(crbm_handle* h, int32_t start, int32_t end, float*
 int crbm_comm_unique_id(uint8_t id[CRBM_UNIQUE_ID_BYTES]);
 int crbm_comm_init(crbm_handle* h, const uint8_t id[CRBM_UNIQUE_ID_BYTES], int32_t nranks, int32_t rank);
 int crbm_comm_destroy(crbm_handle* h);
+/* ncclBroadcast of W, b, c and the velocities from rank `root`: replicas must
+ * start identical because only the statistic sums are reduced afterwards (the
+ * reference's randn initialisation, convRBM.py:127-131, differs per process).
+ * No-op without a communicator. */
+int crbm_comm_broadcast_state(crbm_handle* h, int32_t root);
 int crbm_sums_count(const crbm_handle* h);
 /* Split form of crbm_train_step for hosts that reduce the sums themselves:
  * local phase -> sums in `sums_out` (host, crbm_sums_count floats);
@@ -209,11 +218,14 @@ typedef struct crbm_launch_info {
   int32_t group;         /* letters per gather-table group (G)                    */
   int32_t gibbs_grid, gibbs_block, gibbs_seqs_per_tile, gibbs_lds_bytes;
   int32_t stats_grid_x, stats_grid_y, stats_block, stats_lds_bytes;
-  int32_t gibbs_sparse;  /* top-down variant of the next Gibbs launch: 1 = walk over set bits, 0 = dense tables.
-                            Chosen from the measured hidden activity unless CRBM_TOPDOWN=dense|sparse.      */
-  int32_t activity_ppm;  /* hidden units on per million after the last launch read back, -1 = not read yet  */
+  int32_t gibbs_sparse;  /* top-down variant of the Gibbs kernel: 1 = walk over set bits (default of every
+                            model), 0 = dense tables (CRBM_TOPDOWN=dense, small models); fixed per handle  */
+  int32_t activity_ppm;  /* hidden units on per million after the last crbm_sync / crbm_gibbs_steps, -1 = not read yet */
 } crbm_launch_info;
 int crbm_get_launch_info(const crbm_handle* h, crbm_launch_info* out);
+/* Device-copy bandwidth (float4 copy kernel, HIP events, read + written bytes
+ * per second in GB/s) -- the measured ceiling bench.py reports beside the spec. */
+int crbm_copy_bandwidth(crbm_handle* h, int64_t bytes, int32_t reps, float* gb_per_s);
 /* Actual bytes of chain state one Gibbs launch reads+writes in HBM. */
 int64_t crbm_gibbs_state_bytes(const crbm_handle* h);
 

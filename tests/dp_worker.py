@@ -1,0 +1,73 @@
+"""TEST INFRASTRUCTURE: one rank of a data-parallel training run (tests/test_gpu_parity.py starts
+two of these as child processes).  Every rank builds its model the way a user would -- default,
+unseeded filters and its own sampler seed -- so the run only succeeds if crbm_amd.dist makes the
+replicas identical.
+
+    python tests/dp_worker.py <mode> <out.npz>      RANK / WORLD_SIZE / MASTER_* from the environment
+
+mode "rccl": crbm_amd.dist.attach() + CRBM.fit() (sharded upload, RCCL all-reduce inside the library;
+             needs one GPU per rank).
+mode "host": all ranks share GPU 0; the packed sums of crbm_train_local are summed over the control
+             plane and applied with crbm_train_apply (same kernels, same sharding, no communicator).
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+K, M, B, LF, N, L, BS, EPOCHS = 5, 6, 8, 33, 17, 40, 8, 2     # 17 rows: slices of 8, 8 and 1 (rank 0 owns none of the last)
+
+
+def data():
+    letters = np.random.default_rng(77).integers(0, 4, size=(N, L))
+    out = np.zeros((N, 1, 4, L), dtype=np.float32)
+    out[np.arange(N)[:, None], 0, letters, np.arange(L)[None, :]] = 1
+    return out
+
+
+def main():
+    mode, outfile = sys.argv[1], sys.argv[2]
+    from crbm_amd import CRBM, dist
+    from crbm_amd._lib import fptr
+    rank, world = dist.env_rank_world()
+    np.random.seed(500 + rank)                         # different filters on every rank ...
+    model = CRBM(K, M, epochs=EPOCHS, doublestranded=True, batchsize=B, cd_k=2, fantasy_hidden_len=LF,
+                 seed=9000 + rank,                    # ... and a different sampler seed
+                 device=rank if mode == "rccl" else 0)
+    D = data()
+    if mode == "rccl":
+        dist.attach(model, rank, world)
+        W0, seed0 = model.motifs.get_value(), model.seed
+        model.fit(D)
+    else:
+        cp = dist.ControlPlane(rank, world)
+        dist.sync_replicas(model, cp)
+        model.rank, model.world_size, model._control = rank, world, cp
+        W0, seed0 = model.motifs.get_value(), model.seed
+        h = model._h()
+        count = model._lib.crbm_sums_count(h)
+        for _ in range(EPOCHS):
+            for start in range(0, N, BS):
+                n = min(N, start + BS) - start
+                lo, hi = dist.shard_range(n, rank, world)
+                rows = np.ascontiguousarray(D[start + lo:start + hi])
+                sums = np.zeros(count, dtype=np.float32)
+                model._call("crbm_train_local", fptr(rows) if hi > lo else None, hi - lo, L, fptr(sums))
+                tot = cp.allreduce_sum(sums).astype(np.float32)
+                model._call("crbm_train_apply", fptr(np.ascontiguousarray(tot)), L)
+    fh, fhp = model.get_fantasy()
+    vW, vb, vc = model.get_velocities()
+    state = os.path.splitext(outfile)[0] + ".state"
+    model.saveState(state)                             # collective: rank 0 writes the global chains
+    np.savez(outfile, W0=W0, seed0=seed0, W=model.motifs.get_value(), b=model.bias.get_value(),
+             c=model.c.get_value(), fh=fh, fhp=fhp, vW=vW, vb=vb, vc=vc, checksum=dist.replica_checksum(model))
+    if model._control is not None:
+        model._control.barrier()
+
+
+if __name__ == "__main__":
+    main()

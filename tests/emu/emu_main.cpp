@@ -22,11 +22,13 @@ void launch(F kernel, dim3 grid, dim3 block, size_t lds) {
       std::vector<pthread_barrier_t> wb(nwaves);
       for (unsigned w = 0; w < nwaves; ++w) pthread_barrier_init(&wb[w], nullptr, std::min(64u, nthr - w * 64));
       std::vector<float> scratch(nwaves * 64);
+      std::vector<uint32_t> frag((size_t)nwaves * 64 * 8);
       // exact size (16-byte aligned base): out-of-bounds LDS accesses trip AddressSanitizer
       std::vector<float4> smem((lds + 15) / 16 + 1);
       memset(smem.data(), 0xAB, smem.size() * 16);
       ctx.wave_bar = wb.data();
       ctx.wave_scratch = scratch.data();
+      ctx.wave_frag = frag.data();
       ctx.smem = reinterpret_cast<unsigned char*>(smem.data());
       std::vector<std::thread> threads;
       threads.reserve(nthr);
@@ -66,6 +68,7 @@ RngView make_rng(uint64_t seed, uint32_t step, uint32_t off) {
     case 5: { using C = Cfg<50, 25, 0, 2>; __VA_ARGS__; break; }        \
     case 6: { using C = Cfg<7, 32, 1, 3>; __VA_ARGS__; break; }         \
     case 7: { using C = Cfg<10, 15, 0, 3>; __VA_ARGS__; break; }        \
+    case 8: { using C = Cfg<64, 32, 1, 1>; __VA_ARGS__; break; }        \
     default: return -1;                                          \
   }
 
@@ -213,6 +216,112 @@ int emu_stats(int id, const float* tables, const uint32_t* letters, int n, int L
     sums[st.row - sl] = (float)n;
     row = st.row;
   });
+  return row;
+}
+
+// fills the StatsGeom of a layout
+static StatsGeom geom_of(const StatsMfmaLayout& st, float* partials, long ngroups) {
+  StatsGeom g;
+  g.GPC = st.GPC;
+  g.off_slices = st.off_slices; g.slice = st.slice;
+  g.off_win = st.off_win; g.off_gw = st.off_gw; g.off_pt = st.off_pt;
+  g.divGPC = make_fastdiv((uint32_t)st.GPC, (uint64_t)ngroups);
+  g.row = st.row; g.off_vh0 = st.off_vh[0]; g.off_vh1 = st.off_vh[1]; g.off_h0 = st.off_h[0]; g.off_h1 = st.off_h[1];
+  g.off_sw = st.off_sw; g.off_sb = st.off_sb; g.off_v = st.off_v;
+  g.partials = partials;
+  return g;
+}
+
+// column sums of the partial rows on the host, same validity rules as reduce_partials_kernel
+static void host_reduce(const float* partials, int rows, int row, int K, int KAM, int ds, int want_sparsity, int skip_begin,
+                        int skip_len, float n_value, float* sums) {
+  const int sb = skip_begin < 0 ? row : skip_begin, sl = skip_begin < 0 ? 0 : skip_len;
+  for (int r = 0; r < row; ++r) {
+    if (r >= sb && r < sb + sl) continue;
+    bool valid;
+    if (r < KAM) valid = true;
+    else if (r < 2 * KAM) valid = ds != 0;
+    else if (r < 2 * KAM + K) valid = true;
+    else if (r < 2 * KAM + 2 * K) valid = ds != 0;
+    else if (r < 3 * KAM + 3 * K) valid = want_sparsity != 0;
+    else valid = true;
+    float t = 0.f;
+    if (valid)
+      for (int i = 0; i < rows; ++i) t += partials[(size_t)i * row + r];
+    sums[r < sb ? r : r - sl] = t;
+  }
+  sums[row - sl] = n_value;
+}
+
+// MFMA statistics of one half + deterministic reduction into `sums` (row floats + n).
+// threads > 0 overrides the block size (a multiple of 64 * roles).
+int emu_stats_mfma(int id, const float* tables, const uint32_t* letters, int n, int L, int LW, int want_sparsity,
+                   int threads, int gx, float* partials, int partials_cap, float* sums, int skip_begin, int skip_len) {
+  StatsMfmaArgs a;
+  a.tables = tables; a.letters = letters; a.n = n; a.L = L; a.LW = LW;
+  int row = -1;
+  CFG_DISPATCH(id, {
+    const ModelShape ms = shape_of<C>();
+    const int Lh = L - C::M + 1;
+    a.Lh = Lh;
+    const StatsMfmaLayout st = stats_mfma_layout(ms, want_sparsity, Lh, threads, (1 + C::DS) * C::TAB * 4);
+    if ((st.threads / 64) % st.NR != 0) return -3;
+    const long ngroups = (long)n * st.GPC;
+    const long nunits = (ngroups + 1) / 2;
+    const int wpr = (st.threads / 64) / st.NR;
+    if (gx > (nunits + wpr - 1) / wpr) gx = (int)((nunits + wpr - 1) / wpr);
+    if ((long)gx * st.row > partials_cap) return -2;
+    for (size_t i = 0; i < (size_t)gx * st.row; ++i) partials[i] = 1e30f;   // never cleared on the GPU either
+    a.sg = geom_of(st, partials, ngroups);
+    a.off_tab = st.region_floats;
+    const size_t lds = std::max((size_t)st.region_floats * 4 + (size_t)(1 + C::DS) * C::TAB * 4, (size_t)st.combine_bytes);
+    if (want_sparsity) emu::launch([&] { stats_mfma_body<C, true>(a); }, dim3(gx), dim3(st.threads), lds);
+    else emu::launch([&] { stats_mfma_body<C, false>(a); }, dim3(gx), dim3(st.threads), lds);
+    host_reduce(partials, gx, st.row, C::K, C::K * 4 * C::M, C::DS, want_sparsity, skip_begin, skip_len, (float)n, sums);
+    row = st.row;
+  });
+  return row;
+}
+
+}  // extern "C"
+
+// The fused launch: `steps` Gibbs steps whose last h|v pass also leaves the model half of the
+// statistics (gibbs_body<C, true, true>); the partial rows are reduced into `sums` on the host.
+// Returns the partial-row length, -3 if the model has no fused variant.
+template <class C>
+static int run_gibbs_stats(GibbsArgs a, int Lf, int S, int grid, int threads, float* partials, int partials_cap, float* sums,
+                           int skip_begin, int skip_len) {
+  if constexpr (C::FUSE_STATS) {
+    const ModelShape ms = shape_of<C>();
+    const GibbsLayout gl = gibbs_layout(ms, Lf, S, true);
+    a.Lv = gl.Lv; a.nvb = gl.nvb; a.nhb = gl.nhb; a.Lrow = gl.Lrow; a.LWs = gl.LWs;
+    a.divVB = make_fastdiv((uint32_t)gl.nvb); a.divHB = make_fastdiv((uint32_t)gl.nhb);
+    a.divRow = make_fastdiv((uint32_t)(gl.Lrow * ms.NW)); a.divLfw = make_fastdiv((uint32_t)(Lf * ms.NW));
+    if (!C::DS) a.hmp = nullptr;
+    const StatsMfmaLayout st = stats_mfma_layout(ms, 0, Lf, threads);
+    if ((long)grid * st.row > partials_cap) return -2;
+    for (size_t i = 0; i < (size_t)grid * st.row; ++i) partials[i] = 1e30f;
+    a.stats_off = (gl.lds_bytes / 4 + 3) & ~3;
+    a.sg = geom_of(st, partials, (long)S * st.GPC);
+    const size_t lds = std::max((size_t)(a.stats_off + st.region_floats) * 4, (size_t)st.combine_bytes);
+    emu::launch([&] { gibbs_body<C, true, true>(a); }, dim3(grid), dim3(threads), lds);
+    host_reduce(partials, grid, st.row, C::K, C::K * 4 * C::M, C::DS, 0, skip_begin, skip_len, (float)a.nchains, sums);
+    return st.row;
+  } else {
+    return -3;
+  }
+}
+
+extern "C" {
+
+int emu_gibbs_stats(int id, const float* tables, uint32_t* hm, uint32_t* hmp, uint32_t* vout, int nchains, int Lf, int S,
+                    int steps, uint64_t seed, uint32_t step, uint32_t off, int grid, int threads, float* partials,
+                    int partials_cap, float* sums, int skip_begin, int skip_len) {
+  GibbsArgs a;
+  a.tables = tables; a.hm = hm; a.hmp = hmp; a.vout = vout; a.ones = nullptr; a.debug = 0;
+  a.nchains = nchains; a.Lf = Lf; a.S = S; a.steps = steps; a.rng = make_rng(seed, step, off);
+  int row = -1;
+  CFG_DISPATCH(id, row = run_gibbs_stats<C>(a, Lf, S, grid, threads, partials, partials_cap, sums, skip_begin, skip_len));
   return row;
 }
 

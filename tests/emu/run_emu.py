@@ -97,13 +97,14 @@ def make_oracle(K, M, ds, seed=0, batch=4, Lf=20, cd_k=2, wscale=1.0, **kw):
 # case ids of the Cfg<K,M,DS,G> instantiations in emu_main.cpp:
 # 0 (10,5,ss,G2) 1 (10,15,ds,G3) 2 (2,5,ds,G4) 3 (3,4,ss,G1) 4 (20,15,ds,G2: sparse v|h)
 # 5 (50,25,ss,G2: two mask words) 6 (7,32,ds,G3: sparse, 96-bit letter window) 7 (10,15,ss,G3: config #2)
+# 8 (64,32,ds,G1: the largest model the kernels take; statistics only -- three column roles)
 ALL_CASES = list(range(8))
 # One OS thread per GPU thread makes barrier-heavy kernels slow on 8 cores: the
 # default run keeps the CPU suite to a few minutes, CRBM_EMU_FULL=1 runs all.
 FULL = os.environ.get("CRBM_EMU_FULL", "0") == "1"
 CASES = ALL_CASES if FULL else [1, 2, 3]
 GIBBS_CASES = ALL_CASES if FULL else [1, 5, 7]
-TRAIN_CASES = ALL_CASES[:6] if FULL else [1, 2]
+TRAIN_CASES = ALL_CASES[:6] if FULL else [1, 2, 5]
 
 
 def oracle_for(cid, **kw):
@@ -265,10 +266,13 @@ def test_gibbs():
 
 
 def test_train_step():
+    """One PCD-k update through the kernels of the product path: data half = stats_mfma_body (SP),
+    model half = the fused tail of the Gibbs kernel where the model has one (else Gibbs kernel +
+    stand-alone stats_mfma_body on its visible sample), then apply_update; all against the oracle."""
     for cid in TRAIN_CASES:
         info = case_info(cid)
-        K, M, ds = info["K"], info["M"], info["ds"]
-        B, Lf, n, L = 4, 18, 5, M + 20
+        K, M, ds, NW = info["K"], info["M"], info["ds"], info["NW"]
+        B, Lf, n, L = 4, 18 if cid != 1 else 40, 5, M + 20
         o = make_oracle(K, M, ds, seed=3, batch=B, Lf=Lf, cd_k=2, rho=0.05)
         o.vW = f32(np.random.default_rng(1).standard_normal(o.W.shape) * 0.01).astype(np.float64)
         D = synthetic_onehot(n, L, seed=21)
@@ -283,20 +287,35 @@ def test_train_step():
         row = 3 * K * 4 * M + 3 * K + 4
         partials = np.zeros(32 * row, dtype=np.float32)
         tables = build_tables(cid, o)
-        # the data half goes through the segmented path (chains cut into segments of
-        # 8 hidden positions), the model half uses whole chains
-        r = lib.emu_stats(cid, fp(tables), up(letters), n, L, lib.emu_letter_words(L), 1, 8, 3,
-                          fp(partials), partials.size, fp(sums[data_off:]), -1, 0)
+        r = lib.emu_stats_mfma(cid, fp(tables), up(letters), n, L, lib.emu_letter_words(L), 1, 0, 3,
+                               fp(partials), partials.size, fp(sums[data_off:]), -1, 0)
         assert r == row, r
-        _, _, v, vout, lws = run_gibbs(cid, o, tables, 2, o.cd_k, 2, threads)
         Lv = Lf + M - 1
-        r = lib.emu_stats(cid, fp(tables), up(vout), B, Lv, lws, 0, 0, 2,
-                          fp(partials), partials.size, fp(sums[model_off:]), skipb, skipl)
-        assert r == row, r
+        # fused: Gibbs steps + model statistics in one launch
+        hm, _ = pack_hidden(f32(o.fantasy_h), NW)
+        hmp = pack_hidden(f32(o.fantasy_h_prime), NW)[0] if ds else np.zeros_like(hm)
+        lws = lib.emu_gibbs(cid, fp(tables), up(hm), up(hmp), None, B, Lf, 2, o.cd_k,
+                            ctypes.c_uint64(o.seed), o.gibbs_step, o.seq_offset, 2, threads, 1, None)
+        vout = np.zeros((B, lws), dtype=np.uint32)
+        r = lib.emu_gibbs_stats(cid, fp(tables), up(hm), up(hmp), up(vout), B, Lf, 2, o.cd_k,
+                                ctypes.c_uint64(o.seed), o.gibbs_step, o.seq_offset, 2, threads,
+                                fp(partials), partials.size, fp(sums[model_off:]), skipb, skipl)
+        fused = r != -3
+        if fused:
+            assert r == row, r
+            v = np.zeros((B, 1, 4, Lv), dtype=np.float32)
+            lib.emu_decode(up(vout), fp(v), B, Lv, lws, 2)
+            h_after = unpack_hidden(hm, K)
+        else:
+            h_after, _, v, vout, lws = run_gibbs(cid, o, tables, 2, o.cd_k, 2, threads)
+            r = lib.emu_stats_mfma(cid, fp(tables), up(vout), B, Lv, lws, 0, 0, 2,
+                                   fp(partials), partials.size, fp(sums[model_off:]), skipb, skipl)
+            assert r == row, r
         assert sums[n_d] == n and sums[n_m] == B
         # raw sums against the oracle's
         P_m, P_mp, v_m = o.gibbs_steps(o.cd_k)
         assert np.array_equal(v, v_m)
+        assert np.array_equal(h_after, o.fantasy_h)
         o.gibbs_step -= o.cd_k
         s = o.local_sums(D, P_m, P_mp, v_m)
         KAM = K * 4 * M
@@ -306,9 +325,11 @@ def test_train_step():
         np.testing.assert_allclose(sums[3 * KAM + 2 * K:3 * KAM + 3 * K], s['sb'], rtol=2e-5)
         np.testing.assert_allclose(sums[3 * KAM + 3 * K:3 * KAM + 3 * K + 4], s['v_d'])
         np.testing.assert_allclose(sums[model_off:model_off + KAM], s['vh_m'].ravel(), rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(sums[model_off + 2 * KAM:model_off + 2 * KAM + K], s['h_m'], rtol=2e-5)
         np.testing.assert_allclose(sums[n_m - 4:n_m], s['v_m'])
         if ds:
             np.testing.assert_allclose(sums[KAM:2 * KAM], s['vh_dp'].ravel(), rtol=2e-5, atol=1e-6)
+            np.testing.assert_allclose(sums[model_off + KAM:model_off + 2 * KAM], s['vh_mp'].ravel(), rtol=2e-5, atol=1e-6)
             np.testing.assert_allclose(sums[model_off + 2 * KAM + K:model_off + 2 * KAM + 2 * K], s['h_mp'], rtol=2e-5)
         lib.emu_update(fp(sums), fp(W), fp(b), fp(c), fp(vW), fp(vb), fp(vc), K, M, int(ds), L, Lf,
                        ctypes.c_float(o.learning_rate), ctypes.c_float(o.momentum), ctypes.c_float(o.rho),
@@ -318,7 +339,70 @@ def test_train_step():
         np.testing.assert_allclose(b, o.b.ravel(), rtol=1e-4, atol=1e-6)
         np.testing.assert_allclose(c, o.c.ravel(), rtol=1e-4, atol=1e-6)
         np.testing.assert_allclose(vW.reshape(o.W.shape), o.vW, rtol=1e-4, atol=1e-7)
-        print("train step ok", cid, (K, M, ds))
+        print("train step ok", cid, (K, M, ds), "fused" if fused else "split")
+
+
+def stats_sums(cid, tables, letters, n, L, want_sparsity, threads, gx, skip=(-1, 0)):
+    """raw sums of one half through stats_mfma_body (+ the host column reduce of the harness)"""
+    info = case_info(cid)
+    K, M = info["K"], info["M"]
+    row = 3 * K * 4 * M + 3 * K + 4
+    partials = np.zeros(max(gx, 1) * row, dtype=np.float32)
+    sums = np.zeros(row + 1, dtype=np.float32)
+    r = lib.emu_stats_mfma(cid, fp(tables), up(letters), n, L, lib.emu_letter_words(L), want_sparsity, threads, gx,
+                           fp(partials), partials.size, fp(sums), skip[0], skip[1])
+    assert r == row, r
+    return sums
+
+
+def test_stats_mfma():
+    """The MFMA statistics kernel against the oracle's raw sums: units that span chains, chains
+    shorter than a group, a ragged last group, an odd number of groups, several blocks, one to
+    four waves per role."""
+    cases = (ALL_CASES if FULL else [1, 3, 5]) + [8]
+    for cid in cases:
+        info = case_info(cid)
+        K, M, ds = info["K"], info["M"], info["ds"]
+        KAM = K * 4 * M
+        # (n, L, waves per role, blocks); NR roles -> 64 * NR * waves threads
+        shapes = ((5, M + 20, 2, 3), (3, M + 69, 4, 2), (3, M + 3, 1, 1))
+        if cid == 8:
+            shapes = ((2, M + 40, 0, 2),)              # default geometry
+        for (n, L, wpr, gx) in shapes:
+            o = make_oracle(K, M, ds, seed=3, batch=2, Lf=10, rho=0.05)
+            D = synthetic_onehot(n, L, seed=21 + n)
+            letters, _ = encode(D)
+            tables = build_tables(cid, o)
+            Lh = L - M + 1
+            # oracle raw sums of the data half
+            P = o._bottomUpProbability(o._bottomUpActivity(D))
+            Pp = o._bottomUpProbability(o._bottomUpActivity(D, True)) if ds else None
+            Dv = D[:, 0].astype(np.float64)                       # (n,4,L)
+            def vh(Pk):
+                out = np.zeros((K, 4, M))
+                for j in range(M):
+                    out[:, :, j] = np.einsum('nks,nas->ka', Pk[:, :, 0, :], Dv[:, :, j:j + Lh])
+                return out
+            for want in (1, 0):
+                NT, JT = -(-K // 16), -(-M // 16)
+                kinds = 1 + int(ds) + want
+                ntw = NT
+                while ntw > 1 and (4 * JT * kinds * ntw > 32 or NT % ntw):
+                    ntw -= 1
+                threads = 64 * (NT // ntw) * wpr
+                s = stats_sums(cid, tables, letters, n, L, want, threads, gx)
+                np.testing.assert_allclose(s[0:KAM], vh(P).ravel(), rtol=2e-5, atol=1e-6)
+                np.testing.assert_allclose(s[2 * KAM:2 * KAM + K], P.sum(axis=(0, 2, 3)), rtol=2e-5)
+                if ds:
+                    np.testing.assert_allclose(s[KAM:2 * KAM], vh(Pp).ravel(), rtol=2e-5, atol=1e-6)
+                    np.testing.assert_allclose(s[2 * KAM + K:2 * KAM + 2 * K], Pp.sum(axis=(0, 2, 3)), rtol=2e-5)
+                if want:
+                    Q = P * (1 - P)
+                    np.testing.assert_allclose(s[2 * KAM + 2 * K:3 * KAM + 2 * K], vh(Q).ravel(), rtol=2e-5, atol=1e-6)
+                    np.testing.assert_allclose(s[3 * KAM + 2 * K:3 * KAM + 3 * K], Q.sum(axis=(0, 2, 3)), rtol=2e-5)
+                np.testing.assert_array_equal(s[3 * KAM + 3 * K:3 * KAM + 3 * K + 4], Dv.sum(axis=(0, 2)))
+                assert s[3 * KAM + 3 * K + 4] == n
+        print("stats mfma ok", cid, (K, M, ds))
 
 
 def test_free_energy():
@@ -358,7 +442,7 @@ def test_hit_summary():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["encode_pack", "hgv", "vgh", "gibbs", "train_step", "free_energy", "hit_summary"]
+    which = sys.argv[1:] or ["encode_pack", "hgv", "vgh", "gibbs", "stats_mfma", "train_step", "free_energy", "hit_summary"]
     for w in which:
         globals()["test_" + w]()
     print("EMU ALL OK")

@@ -4,6 +4,7 @@
 // One OS thread per GPU thread, pthread barriers for __syncthreads() and for
 // wave-level shuffles.  Never shipped, never used by the product path.
 #pragma once
+#include <immintrin.h>   // F16C: f16 <-> f32 exactly as the GPU's conversions round (nearest even, subnormals kept)
 #include <math.h>
 #include <pthread.h>
 #include <stdint.h>
@@ -27,6 +28,7 @@ struct float4 {
 };
 static inline float4 make_float4(float a, float b, float c, float d) { return float4{a, b, c, d}; }
 struct alignas(8) uint2 { uint32_t x, y; };
+static inline uint2 make_uint2(uint32_t x, uint32_t y) { uint2 r; r.x = x; r.y = y; return r; }
 struct uint4 {
   unsigned x, y, z, w;
 };
@@ -38,6 +40,7 @@ struct BlockCtx {
   pthread_barrier_t bar;
   pthread_barrier_t* wave_bar;   // one per wave
   float* wave_scratch;           // 64 floats per wave
+  uint32_t* wave_frag;           // 64 lanes x 8 words per wave: the A and B fragments of an emulated MFMA
   unsigned char* smem;
 };
 extern thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
@@ -125,6 +128,45 @@ static inline void __builtin_amdgcn_wave_barrier() {
   pthread_barrier_wait(&emu::t_ctx->wave_bar[emu::t_threadIdx.x >> 6]);
 }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+
+namespace emu {
+static inline float h2f(uint16_t h) { return _cvtsh_ss(h); }
+static inline uint16_t f2h(float f) { return _cvtss_sh(f, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC); }
+// x = hi + lo, both f16 (crbm_kernels.h: split_f16)
+static inline void split_f16(const float (&x)[8], uint32_t (&hi)[4], uint32_t (&lo)[4]) {
+  for (int q = 0; q < 4; ++q) {
+    uint16_t h[2], l[2];
+    for (int t = 0; t < 2; ++t) {
+      h[t] = f2h(x[2 * q + t]);
+      l[t] = f2h(x[2 * q + t] - h2f(h[t]));
+    }
+    hi[q] = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
+    lo[q] = (uint32_t)l[0] | ((uint32_t)l[1] << 16);
+  }
+}
+// v_mfma_f32_16x16x32_f16: lane l holds A[l&15][8(l>>4)+e], B[8(l>>4)+e][l&15], D[4(l>>4)+r][l&15].
+// All 64 lanes of the wave call it.  Products of two f16 are exact in f32; the sum is taken in
+// double and rounded once (the hardware's internal order is not specified).
+static inline void mfma_16x16x32_f16(const uint32_t (&a)[4], const uint32_t (&b)[4], float (&d)[4]) {
+  const unsigned lane = t_threadIdx.x & 63u, wave = t_threadIdx.x >> 6;
+  uint32_t* s = t_ctx->wave_frag + (size_t)wave * 64 * 8;
+  for (int q = 0; q < 4; ++q) { s[lane * 8 + q] = a[q]; s[lane * 8 + 4 + q] = b[q]; }
+  pthread_barrier_wait(&t_ctx->wave_bar[wave]);
+  const unsigned col = lane & 15u, rg = lane >> 4;
+  for (int r = 0; r < 4; ++r) {
+    const unsigned row = 4 * rg + r;
+    double acc = d[r];
+    for (unsigned kk = 0; kk < 32; ++kk) {
+      const unsigned la = row + 16 * (kk >> 3), lb = col + 16 * (kk >> 3), e = kk & 7u;
+      const uint16_t ha = (uint16_t)(s[la * 8 + (e >> 1)] >> (16 * (e & 1u)));
+      const uint16_t hb = (uint16_t)(s[lb * 8 + 4 + (e >> 1)] >> (16 * (e & 1u)));
+      acc += (double)h2f(ha) * (double)h2f(hb);
+    }
+    d[r] = (float)acc;
+  }
+  pthread_barrier_wait(&t_ctx->wave_bar[wave]);
+}
+}  // namespace emu
 
 // Only used to decide whether a wave takes a slow path that is a no-op for lanes
 // that do not need it, so the lane-local answer is an exact emulation.

@@ -132,3 +132,82 @@ def test_shard_ranges_and_model_sharding():
         lo, hi = m._shard_rows(100, 120)
         covered += list(range(lo, hi))
     assert covered == list(range(100, 120))
+
+
+# ---- the product's own control plane (crbm_amd.dist.ControlPlane: no torch) -------------------
+def _cp_rank(rank, world, port, q):
+    from crbm_amd.dist import ControlPlane
+    cp = ControlPlane(rank, world, addr="127.0.0.1", port=port)
+    got = {"bcast": cp.broadcast({"x": 41 + rank} if rank == 0 else None),
+           "gather": cp.gather(rank * 10),
+           "max": cp.allreduce_max([rank + 0.5, -rank]),
+           "sum": cp.allreduce_sum([1.0, rank]).tolist()}
+    cp.barrier()
+    cp.close()
+    q.put((rank, got))
+
+
+def test_control_plane_collectives():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 3
+    procs = [ctx.Process(target=_cp_rank, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=60) for _ in range(world))
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    for r in range(world):
+        assert got[r] == {"bcast": {"x": 41}, "gather": [0, 10, 20], "max": [2.5, 0.0], "sum": [3.0, 3.0]}
+
+
+def _replica_rank(rank, port, q):
+    # every rank builds the model the way a user would: default (unseeded) filters, wall-clock seed
+    import numpy as np
+    from crbm_amd import CRBM
+    from crbm_amd.dist import ControlPlane, sync_replicas
+    np.random.seed(100 + rank)
+    m = CRBM(4, 6, batchsize=8, seed=1000 + rank)
+    before = m.motifs.get_value().copy()
+    cp = ControlPlane(rank, 2, addr="127.0.0.1", port=port)
+    sync_replicas(m, cp)
+    cp.close()
+    q.put((rank, before, m.motifs.get_value(), m.bias.get_value(), m.seed))
+
+
+def test_sync_replicas_makes_default_initialised_ranks_identical():
+    """CRBM() draws W from the process-global generator and seeds the sampler from
+    the clock; attach() must leave every rank with rank 0's parameters and seed."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_replica_rank, args=(r, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {r: rest for r, *rest in (q.get(timeout=60) for _ in range(2))}
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    assert not np.array_equal(got[0][0], got[1][0])           # they really started different
+    np.testing.assert_array_equal(got[0][1], got[0][0])       # rank 0 keeps its own
+    np.testing.assert_array_equal(got[1][1], got[0][0])       # rank 1 adopts them
+    np.testing.assert_array_equal(got[1][2], got[0][2])
+    assert got[0][3] == got[1][3] == 1000
+
+
+def test_shard_rows_cover_every_slice_once():
+    from crbm_amd.dist import shard_range, shard_rows
+    total, bs, world = 37, 8, 3
+    parts = [shard_rows(total, bs, r, world) for r in range(world)]
+    assert sorted(np.concatenate(parts).tolist()) == list(range(total))
+    # rank r's rows of slice [start, end) are the contiguous range the library computes (crbm_api.hip)
+    for r in range(world):
+        want = []
+        for start in range(0, total, bs):
+            n = min(total, start + bs) - start
+            lo, hi = shard_range(n, r, world)
+            want += list(range(start + lo, start + hi))
+        assert parts[r].tolist() == want
+    assert shard_rows(2, 8, 2, 3).size in (0, 1)              # a rank may own nothing of a short set

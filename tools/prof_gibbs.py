@@ -11,7 +11,7 @@ import bench  # noqa: E402
 if __name__ == "__main__":
     cfg = bench.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "cfg2"]
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 50
-    model = bench.build_model(cfg, 1, 0)
+    model = bench.build_model(cfg, 1, 0, 0)
     model._call("crbm_gibbs_steps", 10)
     ms = ctypes.c_float()
     model._call("crbm_time_gibbs", cfg["k"], n, ctypes.byref(ms))

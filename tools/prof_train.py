@@ -12,7 +12,7 @@ from crbm_amd._lib import fptr  # noqa: E402
 if __name__ == "__main__":
     cfg = bench.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "cfg2"]
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-    model = bench.build_model(cfg, 1, 0)
+    model = bench.build_model(cfg, 1, 0, 0)
     D = bench.synthetic_onehot(cfg["chains"], cfg["L"], seed=1234)
     model._call("crbm_dataset_upload", fptr(D), cfg["chains"], cfg["L"])
     ms = ctypes.c_float()
