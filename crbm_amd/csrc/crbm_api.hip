@@ -264,7 +264,7 @@ void use_variant(crbm_handle* h, int v) {
   h->gibbs_grid = h->gridv[v];
 }
 
-StatsGeom stats_geom(const StatsMfmaLayout& st, float* partials, long ngroups);
+StatsGeom stats_geom(const StatsMfmaLayout& st, float* partials, long ngroups, int lds_bytes);
 
 // with_stats: the fused variant -- the launch also leaves the model half of the gradient statistics
 // as one partial row per block in h->partials2 (reduction handed back through `model_reduce`)
@@ -292,11 +292,11 @@ int launch_gibbs(crbm_handle* h, int steps, hipStream_t s = nullptr, ReduceArgs*
   unsigned lds = (unsigned)h->gl.lds_bytes;
   hipFunction_t fn = h->variant ? h->jk.gibbs_sparse : h->jk.gibbs;
   if (with_stats) {
-    const StatsMfmaLayout st = stats_mfma_layout(h->ms, 0, h->Lf, h->gibbs_threads);
+    const StatsMfmaLayout st = stats_mfma_layout(h->ms, 0, h->Lf, h->gibbs_threads, 0, false);
     HIPCHK(h->partials2.ensure((size_t)h->gibbs_grid * st.row));
     a.stats_off = (h->gl.lds_bytes / 4 + 3) & ~3;
-    a.sg = stats_geom(st, h->partials2.p, (long)h->gl.S * st.GPC);
     lds = (unsigned)std::max((a.stats_off + st.region_floats) * 4, st.combine_bytes);
+    a.sg = stats_geom(st, h->partials2.p, (long)h->gl.S * st.GPC, (int)lds);
     fn = h->jk.gibbs_sparse_stats;
     ReduceArgs& r = *model_reduce;
     r.partials = h->partials2.p;
@@ -385,9 +385,10 @@ int launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool d
   return CRBM_OK;
 }
 
-StatsGeom stats_geom(const StatsMfmaLayout& st, float* partials, long ngroups) {
+StatsGeom stats_geom(const StatsMfmaLayout& st, float* partials, long ngroups, int lds_bytes) {
   StatsGeom g;
   g.GPC = st.GPC;
+  g.lds_floats = lds_bytes / 4;
   g.off_slices = st.off_slices; g.slice = st.slice;
   g.off_win = st.off_win; g.off_gw = st.off_gw; g.off_pt = st.off_pt;
   g.divGPC = make_fastdiv((uint32_t)st.GPC, (uint64_t)std::max<long>(ngroups, 1));
@@ -416,6 +417,8 @@ int launch_stats_mfma(crbm_handle* h, const uint32_t* d_letters, int n, int L, b
   const long ngroups = (long)n * st.GPC;
   const long nunits = (ngroups + 1) / 2;
   a.off_tab = st.region_floats;
+  a.debug = env_int("CRBM_STATS_DEBUG", 0);
+  ARGCHK(ngroups < (1L << 31), "batch too large for the statistics kernel");
   const int lds = std::max(st.region_floats * 4 + tabs, st.combine_bytes);
   ARGCHK(lds <= 160 * 1024, "model too large for the statistics kernel");
   const int wpr = (st.threads / 64) / st.NR;                  // waves per role = units a block works on at a time
@@ -423,7 +426,7 @@ int launch_stats_mfma(crbm_handle* h, const uint32_t* d_letters, int n, int L, b
   const int cap = h->stats_rows > 0 ? h->stats_rows : h->num_cu * per_cu;
   const int gx = (int)std::max<long>(1, std::min<long>((nunits + wpr - 1) / wpr, cap));
   HIPCHK(pbuf.ensure((size_t)gx * st.row));
-  a.sg = stats_geom(st, pbuf.p, ngroups);
+  a.sg = stats_geom(st, pbuf.p, ngroups, lds);
   HIPCHK(jit_launch(data_half ? h->jk.stats_mfma_data : h->jk.stats_mfma_model, a, (unsigned)gx, 1, (unsigned)st.threads,
                     (unsigned)lds, s));
   ReduceArgs r;
@@ -444,17 +447,19 @@ int launch_stats_mfma(crbm_handle* h, const uint32_t* d_letters, int n, int L, b
   return CRBM_OK;
 }
 
+// update + rebuild of the table images in one launch (update_tables_body)
 int launch_update(crbm_handle* h, int L_data) {
-  UpdateArgs u;
+  UpdateTablesArgs a;
+  UpdateArgs& u = a.u;
   u.sums = h->d_sums;
   u.W = h->dW; u.b = h->db; u.c = h->dc; u.vW = h->dvW; u.vb = h->dvb; u.vc = h->dvc;
   u.K = h->K; u.M = h->M; u.ds = h->ds;
   u.L_data = L_data; u.Lf = h->Lf;
   u.data_off = h->sl.data_off; u.n_d = h->sl.n_d; u.model_off = h->sl.model_off; u.n_m = h->sl.n_m;
   u.lr = h->cfg.learning_rate; u.momentum = h->cfg.momentum; u.rho = h->cfg.rho; u.lambda_rate = h->cfg.lambda_rate;
-  hipLaunchKernelGGL(apply_update_kernel, dim3(1), dim3(256), 0, h->stream, u);
-  HIPCHK(hipGetLastError());
-  h->tables_dirty = true;
+  a.tables = h->d_tables;
+  HIPCHK(jit_launch(h->jk.update_tables, a, 1, 1, 1024, (unsigned)((h->KAM + h->K + 4) * 4), h->stream));
+  h->tables_dirty = false;
   return CRBM_OK;
 }
 
@@ -738,7 +743,7 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
     hh->stats_mfma = !(sv && !strcmp(sv, "walk"));
     hh->fuse_stats = hh->stats_mfma && hh->ms.FUSE_STATS && hh->variant == 1 && !(sv && !strcmp(sv, "split"));
     if (hh->fuse_stats) {   // the fused launch appends the statistics slices to the chain image: it must fit the LDS
-      const StatsMfmaLayout st = stats_mfma_layout(hh->ms, 0, hh->Lf, hh->gibbs_threads);
+      const StatsMfmaLayout st = stats_mfma_layout(hh->ms, 0, hh->Lf, hh->gibbs_threads, 0, false);
       const int lds = std::max((((hh->gl.lds_bytes / 4 + 3) & ~3) + st.region_floats) * 4, st.combine_bytes);
       if (lds > 160 * 1024) hh->fuse_stats = false;
     }

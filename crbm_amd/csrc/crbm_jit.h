@@ -26,7 +26,7 @@ namespace crbm {
 
 struct JitKernels {
   hipModule_t module = nullptr;
-  hipFunction_t build_tables = nullptr, hgv = nullptr, gibbs = nullptr /* dense top-down; null if the model has none */,
+  hipFunction_t build_tables = nullptr, update_tables = nullptr, hgv = nullptr, gibbs = nullptr /* dense top-down; null if the model has none */,
                 gibbs_sparse = nullptr, gibbs_sparse_stats = nullptr /* null unless Cfg::FUSE_STATS */, stats = nullptr, stats_mfma_data = nullptr, stats_mfma_model = nullptr,
                 free_energy = nullptr, hit_summary = nullptr;
   bool from_cache = false;
@@ -80,6 +80,7 @@ inline std::string jit_stub(int K, int M, int DS, int G, int gibbs_wpe) {
            "#ifndef CRBM_GIBBS_STATS_ATTR\n#define CRBM_GIBBS_STATS_ATTR %s\n#endif\n"
            "using ModelCfg = crbm::Cfg<%d, %d, %d, %d>;\n"
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_build_tables(crbm::TablesArgs a) { crbm::build_tables_body<ModelCfg>(a); }\n"
+           "extern \"C\" __global__ void __launch_bounds__(1024) crbm_update_tables(crbm::UpdateTablesArgs a) { crbm::update_tables_body<ModelCfg>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_hgv(crbm::HgvArgs a) { crbm::hgv_body<ModelCfg>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) CRBM_GIBBS_ATTR crbm_gibbs_sparse(crbm::GibbsArgs a) { crbm::gibbs_body<ModelCfg, true>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) CRBM_GIBBS_STATS_ATTR crbm_gibbs_sparse_stats(crbm::GibbsArgs a) { if constexpr (ModelCfg::FUSE_STATS) crbm::gibbs_body<ModelCfg, true, true>(a); }\n"
@@ -177,7 +178,7 @@ inline int jit_load(int K, int M, int DS, int G, int gibbs_wpe, JitKernels* out,
     return -1;
   }
   struct { const char* name; hipFunction_t* f; } syms[] = {
-      {"crbm_build_tables", &out->build_tables}, {"crbm_hgv", &out->hgv}, {"crbm_gibbs", &out->gibbs},
+      {"crbm_build_tables", &out->build_tables}, {"crbm_update_tables", &out->update_tables}, {"crbm_hgv", &out->hgv}, {"crbm_gibbs", &out->gibbs},
       {"crbm_gibbs_sparse", &out->gibbs_sparse}, {"crbm_gibbs_sparse_stats", &out->gibbs_sparse_stats},
       {"crbm_stats", &out->stats}, {"crbm_stats_mfma_data", &out->stats_mfma_data},
       {"crbm_stats_mfma_model", &out->stats_mfma_model}, {"crbm_free_energy", &out->free_energy},

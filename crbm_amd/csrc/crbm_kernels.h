@@ -465,6 +465,7 @@ __device__ void hgv_body(const HgvArgs& a) {
 struct StatsGeom {
   int32_t GPC;                                   // groups per chain
   int32_t off_slices, slice, off_win, off_gw, off_pt;   // LDS layout (floats): first slice, slice size, offsets inside a slice
+  int32_t lds_floats;                            // dynamic LDS of the launch (the end-of-kernel combine uses all of it)
   FastDiv divGPC;
   int32_t row, off_vh0, off_vh1, off_h0, off_h1, off_sw, off_sb, off_v;
   float* partials;                               // [gridDim.x][row]
@@ -483,11 +484,16 @@ struct StatsRole {
   static constexpr int NQW = 4 * NTW;            // float4 quads of motifs a wave gathers
 };
 
-// nibble -> four f16: bit e set -> 2^-14 (0x0400), else 0 (16 entries of 8 bytes)
+// A-fragment look-up tables: bit e of the index set -> f16 2^-14 (0x0400), else 0.
+//   nibble form: 16 entries of 8 bytes (four f16), two reads per fragment -- 128 bytes, for the Gibbs
+//                kernel whose LDS is spoken for;
+//   byte form:   256 entries of 16 bytes (eight f16), one read per fragment -- 4 KB, stand-alone kernel.
+template <bool BYTE_LUT>
 __device__ __forceinline__ void stats_build_lut(uint32_t* lut) {
-  if (threadIdx.x < 32) {
-    const uint32_t n = threadIdx.x >> 1, q = threadIdx.x & 1u;
-    lut[threadIdx.x] = ((n >> (2 * q)) & 1u ? 0x0400u : 0u) | ((n >> (2 * q + 1)) & 1u ? 0x04000000u : 0u);
+  constexpr int WORDS = BYTE_LUT ? 1024 : 32, PER = BYTE_LUT ? 4 : 2;
+  for (int i = threadIdx.x; i < WORDS; i += blockDim.x) {
+    const uint32_t n = (uint32_t)i / PER, q = (uint32_t)i % PER;
+    lut[i] = ((n >> (2 * q)) & 1u ? 0x0400u : 0u) | ((n >> (2 * q + 1)) & 1u ? 0x04000000u : 0u);
   }
 }
 
@@ -549,8 +555,8 @@ __device__ __forceinline__ void conv_gather_quads(const float* T, uint64_t win, 
 // One 32-position group (slot 0 or 1 of the wave's unit): all accumulator tiles of the wave.
 //   Pt  : the wave's column image (row kind*KW + i, stride STATS_RS, position slot*32 + t)
 //   win : the group's four 64-bit letter windows
-template <class C, int KINDS, int NTW>
-__device__ __forceinline__ void stats_mfma_group(const float* Pt, const uint2* win, const uint2* lut, int nt0, int slot,
+template <class C, int KINDS, int NTW, bool BYTE_LUT>
+__device__ __forceinline__ void stats_mfma_group(const float* Pt, const uint2* win, const uint32_t* lut, int nt0, int slot,
                                                  floatx4 (&acc)[4 * C::JT * KINDS * NTW]) {
   constexpr int KW = 16 * NTW < C::K ? 16 * NTW : C::K, ZROW = KINDS * KW;
   const int lane = threadIdx.x & 63, i16 = lane & 15, g = lane >> 4;
@@ -573,9 +579,14 @@ __device__ __forceinline__ void stats_mfma_group(const float* Pt, const uint2* w
 #pragma unroll
     for (int jt = 0; jt < C::JT; ++jt) {
       const uint32_t byte = (uint32_t)(bits >> (8 * g + i16 + 16 * jt));
-      const uint2 f0 = lut[byte & 15u], f1 = lut[(byte >> 4) & 15u];
       HalfFrag af;
-      af.r[0] = f0.x; af.r[1] = f0.y; af.r[2] = f1.x; af.r[3] = f1.y;
+      if constexpr (BYTE_LUT) {
+        const uint4 f = reinterpret_cast<const uint4*>(lut)[byte & 255u];
+        af.r[0] = f.x; af.r[1] = f.y; af.r[2] = f.z; af.r[3] = f.w;
+      } else {
+        const uint2 f0 = reinterpret_cast<const uint2*>(lut)[byte & 15u], f1 = reinterpret_cast<const uint2*>(lut)[(byte >> 4) & 15u];
+        af.r[0] = f0.x; af.r[1] = f0.y; af.r[2] = f1.x; af.r[3] = f1.y;
+      }
 #pragma unroll
       for (int c = 0; c < KINDS * NTW; ++c) {
         floatx4& d = acc[(a * C::JT + jt) * KINDS * NTW + c];
@@ -586,56 +597,68 @@ __device__ __forceinline__ void stats_mfma_group(const float* Pt, const uint2* w
   }
 }
 
-// Combines the waves of a block (fixed order) and writes the block's partial row:
-// vh / vh' / sw blocks, the H and sparsity-bias sums (filter column 0 pairs every hidden
-// position with exactly one letter: sum_s P[k,s] = sum_a VH[k,a,0]) and the letter counts.
+// Combines the waves of a block and writes the block's partial row: vh / vh' / sw blocks, the H
+// and sparsity-bias sums (filter column 0 pairs every hidden position with exactly one letter:
+// sum_s P[k,s] = sum_a VH[k,a,0]) and the letter counts.  Kind by kind, every wave parks its
+// accumulator tiles of that kind in a buffer of its own (as many waves at a time as the LDS
+// holds: normally all), then every thread sums the copies of its output elements in wave order
+// -- a barrier pair per kind instead of one per wave, and the same result for every launch
+// geometry of a block.
 // Uses the LDS of the block from its base on (everything is dead by now); all threads call it.
 template <class C, bool SP>
-__device__ __forceinline__ void stats_mfma_finish(const StatsGeom& sg, float* lds, int nt0, int wave_in_role, int waves_per_role,
+__device__ __forceinline__ void stats_mfma_finish(const StatsGeom& sg, float* lds, int nt0,
                                                   const floatx4 (&acc)[StatsRole<C, SP>::NACC], float vcount) {
   using R = StatsRole<C, SP>;
-  constexpr int K = C::K, M = C::M, KAM = K * 4 * M, KINDS = R::KINDS, NTW = R::NTW;
+  constexpr int K = C::K, M = C::M, KAM = K * 4 * M, KINDS = R::KINDS, NTW = R::NTW, NR = R::NR, KW = R::KW;
+  constexpr int PW = KW * 4 * M;                  // floats a wave parks per kind: [letter][column][motif of the role]
   const int nthr = blockDim.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = nthr >> 6;
   const int i16 = lane & 15, g = lane >> 4;
-  float* buf = lds;                   // [KINDS][KAM]
-  float* xch = lds + KINDS * KAM;     // [nwaves][4]
+  float* total = lds;                   // [KAM], one kind at a time
+  float* xch = lds + KAM;               // [nwaves][4]
+  float* wbuf = xch + 64;
+  int cw = min(nwaves, (sg.lds_floats - KAM - 64) / PW);   // waves parked at a time: whole sets of roles
+  cw = max(NR, cw / NR * NR);
   float* out = sg.partials + (size_t)blockIdx.x * sg.row;
   __syncthreads();
-  for (int p = 0; p < waves_per_role; ++p) {
-    if (wave_in_role == p) {
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+  for (int kind = 0; kind < KINDS; ++kind) {
+    for (int w0 = 0; w0 < nwaves; w0 += cw) {
+      if (wave >= w0 && wave < w0 + cw) {
+        float* mine = wbuf + (size_t)(wave - w0) * PW;
 #pragma unroll
-        for (int jt = 0; jt < C::JT; ++jt)
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-          for (int kind = 0; kind < KINDS; ++kind)
+          for (int jt = 0; jt < C::JT; ++jt)
 #pragma unroll
             for (int t = 0; t < NTW; ++t) {
-              const int k = 16 * (nt0 + t) + i16;
+              const int kl = 16 * t + i16;
               const floatx4 d = acc[((a * C::JT + jt) * KINDS + kind) * NTW + t];
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 const int j = 16 * jt + 4 * g + r;
-                if (j < M && k < K) {
-                  const int idx = kind * KAM + (k * 4 + a) * M + j;
-                  buf[idx] = p == 0 ? d[r] : buf[idx] + d[r];
-                }
+                if (j < M && 16 * nt0 + kl < K) mine[(a * M + j) * KW + kl] = d[r];   // motif fastest: lanes of a tile row hit consecutive banks
               }
             }
+      }
+      __syncthreads();
+      for (int e = threadIdx.x; e < KAM; e += nthr) {                     // e = (letter*M + column)*K + motif
+        const int aj = e / K, k = e - aj * K;
+        const int role = (k >> 4) / NTW, kl = k - 16 * NTW * role;
+        const int o = k * 4 * M + aj;                                     // its place in the (K,4,M) output block
+        float t = w0 == 0 ? 0.f : total[o];
+        for (int w = w0 + role; w < min(nwaves, w0 + cw); w += NR)       // the waves of this motif's role, in wave order
+          t += wbuf[(size_t)(w - w0) * PW + aj * KW + kl];
+        total[o] = t;
+      }
+      __syncthreads();
     }
-    __syncthreads();
-  }
-  constexpr int KIND_Q = 1 + C::DS;
-  for (int i = threadIdx.x; i < KAM; i += nthr) {
-    out[sg.off_vh0 + i] = buf[i];
-    if (C::DS) out[sg.off_vh1 + i] = buf[KAM + i];
-    if (SP) out[sg.off_sw + i] = buf[KIND_Q * KAM + i];
-  }
-  for (int k = threadIdx.x; k < K; k += nthr) {
-    auto col0 = [&](const float* t) { return (t[(k * 4) * M] + t[(k * 4 + 1) * M]) + (t[(k * 4 + 2) * M] + t[(k * 4 + 3) * M]); };
-    out[sg.off_h0 + k] = col0(buf);
-    if (C::DS) out[sg.off_h1 + k] = col0(buf + KAM);
-    if (SP) out[sg.off_sb + k] = col0(buf + KIND_Q * KAM);
+    // kinds: 0 = P (vh, h), 1 = P' when doublestranded (vh', h'), last = Q when SP (sw, sb)
+    const int off_w = kind == 0 ? sg.off_vh0 : (C::DS && kind == 1) ? sg.off_vh1 : sg.off_sw;
+    const int off_k = kind == 0 ? sg.off_h0 : (C::DS && kind == 1) ? sg.off_h1 : sg.off_sb;
+    for (int i = threadIdx.x; i < KAM; i += nthr) out[off_w + i] = total[i];
+    for (int k = threadIdx.x; k < K; k += nthr)
+      out[off_k + k] = (total[(k * 4) * M] + total[(k * 4 + 1) * M]) + (total[(k * 4 + 2) * M] + total[(k * 4 + 3) * M]);
+    // (the next kind's first barrier orders these reads before `total` is rewritten)
   }
   // letter counts: lane l counted letter (l & 3); lanes of one class -> wave -> block, fixed order
   const float cls = class_sum(vcount);
@@ -653,6 +676,8 @@ struct StatsMfmaArgs {
   const uint32_t* letters;
   int32_t n, L, Lh, LW;
   int32_t off_tab;      // gather tables inside LDS (floats), after the slices
+  int32_t debug;        // profiling only (results are wrong when set): 1 skips the MFMA steps, 2 the h|v arithmetic, 4 the
+                        // staging, 8 the combine + output, 16 the table copy, 32 the whole loop
   StatsGeom sg;
 };
 
@@ -675,10 +700,12 @@ __device__ void stats_mfma_body(const StatsMfmaArgs& a) {
   float* Pt = slice + sg.off_pt;
   float* Tf = smem + a.off_tab;
   float* Tr = Tf + C::TAB;
-  copy_tables<C::TAB>(Tf, a.tables + C::OFF_TF);
-  if (C::DS) copy_tables<C::TAB>(Tr, a.tables + C::OFF_TR);
-  stats_build_lut(lut);
-  for (int i = lane; i < R::ROWS * STATS_RS; i += 64) Pt[i] = 0.f;   // the zero row (and the pad columns) stay zero
+  if (!(a.debug & 16)) {
+    copy_tables<C::TAB>(Tf, a.tables + C::OFF_TF);
+    if (C::DS) copy_tables<C::TAB>(Tr, a.tables + C::OFF_TR);
+    stats_build_lut<true>(lut);
+    for (int i = lane; i < R::ROWS * STATS_RS; i += 64) Pt[i] = 0.f;   // the zero row (and the pad columns) stay zero
+  }
   __syncthreads();
 
   const int role = wave % NR, wave_in_role = wave / NR, waves_per_role = nwaves / NR;
@@ -689,28 +716,29 @@ __device__ void stats_mfma_body(const StatsMfmaArgs& a) {
   float vcount = 0.f;                                  // letter (lane & 3), lanes 0-7 of role-0 waves
 
   const int GPC = sg.GPC;
-  const long ngroups = (long)a.n * GPC;
-  const long nunits = (ngroups + 1) / 2;
-  const long ustride = (long)gridDim.x * waves_per_role;
+  const int ngroups = a.n * GPC;                       // the host keeps n * GPC below 2^31
+  const int nunits = (ngroups + 1) / 2;
+  const int ustride = (int)gridDim.x * waves_per_role;
   // letter words of a unit: lane t < 32 fetches word (t >> 2) & 3 of group slot (t >> 4) (four lanes,
   // one per letter, fetch the same word: one transaction) and later turns it into its window piece
   unsigned short* win16 = reinterpret_cast<unsigned short*>(win);
-  auto fetch_word = [&](long u) -> uint32_t {
+  auto fetch_word = [&](int u) -> uint32_t {
     if (lane >= 32 || u >= nunits) return 0u;
-    const long G = 2 * u + (lane >> 4);
+    const int G = 2 * u + (lane >> 4);
     if (G >= ngroups) return 0u;
     const uint32_t chain = fastdiv((uint32_t)G, sg.divGPC);
-    const int w = 2 * (int)(G - (long)chain * GPC) + ((lane >> 2) & 3);
+    const int w = 2 * (G - (int)chain * GPC) + ((lane >> 2) & 3);
     return w < a.LW ? a.letters[(size_t)chain * a.LW + w] : 0u;
   };
-  long u = (long)blockIdx.x * waves_per_role + wave_in_role;
+  int u = (int)blockIdx.x * waves_per_role + wave_in_role;
+  if (a.debug & 32) u = nunits;
   uint32_t pre = fetch_word(u);
   for (; u < nunits; u += ustride) {
-    const long G0 = 2 * u;
-    if (lane < 32) {
-      const long G = G0 + (lane >> 4);
+    const int G0 = 2 * u;
+    if (lane < 32 && !(a.debug & 4)) {
+      const int G = G0 + (lane >> 4);
       int gi = 0;
-      if (G < ngroups) gi = (int)(G - (long)fastdiv((uint32_t)G, sg.divGPC) * GPC);
+      if (G < ngroups) gi = G - (int)fastdiv((uint32_t)G, sg.divGPC) * GPC;
       if ((lane & 3) == 0) gw[lane >> 2] = pre;        // the packed words themselves feed the h|v gather below
       const float cnt = stats_window_piece(win16, lane, pre, G < ngroups, gi, GPC, a.L);
       if (role == 0) vcount += cnt;
@@ -720,11 +748,11 @@ __device__ void stats_mfma_body(const StatsMfmaArgs& a) {
     // ---- P (and P', Q) of this lane's hidden position for the wave's motifs, parked transposed ----
     {
       const int slot = lane >> 5, e = lane & 31;
-      const long G = G0 + slot;
-      bool valid = G < ngroups;
+      const int G = G0 + slot;
+      bool valid = G < ngroups && !(a.debug & 2);
       if (valid) {
         const uint32_t chain = fastdiv((uint32_t)G, sg.divGPC);
-        valid = 32 * (int)(G - (long)chain * GPC) + e < a.Lh;
+        valid = 32 * (G - (int)chain * GPC) + e < a.Lh;
       }
       float* col = Pt + lane;
       if (valid) {
@@ -754,11 +782,12 @@ __device__ void stats_mfma_body(const StatsMfmaArgs& a) {
     // ---- the MFMA steps of the unit ----
 #pragma unroll
     for (int slot = 0; slot < 2; ++slot)
-      if (G0 + slot < ngroups)
-        stats_mfma_group<C, KINDS, NTW>(Pt, win + 4 * slot, reinterpret_cast<const uint2*>(lut), nt0, slot, acc);
+      if (G0 + slot < ngroups && !(a.debug & 1))
+        stats_mfma_group<C, KINDS, NTW, true>(Pt, win + 4 * slot, lut, nt0, slot, acc);
     __builtin_amdgcn_wave_barrier();                   // the slice is rewritten by the next unit
   }
-  stats_mfma_finish<C, SP>(sg, smem, nt0, wave_in_role, waves_per_role, acc, vcount);
+  if (a.debug & 8) return;
+  stats_mfma_finish<C, SP>(sg, smem, nt0, acc, vcount);
 }
 
 // ---------------------------------------------------------------------------
@@ -871,7 +900,7 @@ __device__ void gibbs_body(const GibbsArgs& a) {
   if constexpr (STATS) {
 #pragma unroll
     for (int t = 0; t < SR::NACC; ++t) sacc[t] = floatx4{0.f, 0.f, 0.f, 0.f};
-    stats_build_lut(reinterpret_cast<uint32_t*>(sreg));
+    stats_build_lut<false>(reinterpret_cast<uint32_t*>(sreg));
     for (int i = lane; i < SR::ROWS * STATS_RS; i += 64) sPt[i] = 0.f;   // the zero row stays zero
   }
   // the pads of the mask rows (M-1 positions in front, the rest behind) stay zero for the whole kernel
@@ -1100,7 +1129,7 @@ __device__ void gibbs_body(const GibbsArgs& a) {
 #pragma unroll
           for (int slot = 0; slot < 2; ++slot)
             if (G0 + slot < ngl)
-              stats_mfma_group<C, SR::KINDS, SR::NTW>(sPt, swin + 4 * slot, reinterpret_cast<const uint2*>(sreg), 0, slot, sacc);
+              stats_mfma_group<C, SR::KINDS, SR::NTW, false>(sPt, swin + 4 * slot, reinterpret_cast<const uint32_t*>(sreg), 0, slot, sacc);
           __builtin_amdgcn_wave_barrier();       // the slice is rewritten by the next unit
         }
       }
@@ -1161,7 +1190,7 @@ __device__ void gibbs_body(const GibbsArgs& a) {
     const float tot = wave_sum((float)nset);
     if ((threadIdx.x & 63) == 0) a.ones[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = (uint32_t)tot;
   }
-  if constexpr (STATS) stats_mfma_finish<C, false>(a.sg, smem, 0, wave, nwaves, sacc, vcount);
+  if constexpr (STATS) stats_mfma_finish<C, false>(a.sg, smem, 0, sacc, vcount);
 }
 
 // ---------------------------------------------------------------------------
@@ -1683,6 +1712,96 @@ __device__ void hit_summary_body(const HitArgs& a) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// Normalise the (all-reduced) raw sums and apply the SGD+momentum update
+// (convRBM.py:358-371, :415-436, :440-451).
+// ---------------------------------------------------------------------------
+struct UpdateArgs {
+  const float* sums;
+  float* W; float* b; float* c;
+  float* vW; float* vb; float* vc;
+  int32_t K, M, ds;
+  int32_t L_data, Lf;
+  int32_t data_off, n_d, model_off, n_m;   // offsets into sums
+  float lr, momentum, rho, lambda_rate;
+};
+
+// `nw`: when not null, the new W, b, c are also left there ([KAM][K][4], LDS of the caller)
+__device__ __forceinline__ void apply_update_body(const UpdateArgs& a, float* nw) {
+  const int K = a.K, M = a.M, KAM = K * 4 * M;
+  const float n_d = a.sums[a.n_d], n_m = a.sums[a.n_m];
+  const float cnt_d = n_d * (float)(a.L_data - M + 1);
+  const float cnt_m = n_m * (float)a.Lf;
+  const float* d = a.sums + a.data_off;    // [vh][vh'][h][h'][sw][sb][v]
+  const float* m = a.sums + a.model_off;   // [vh][vh'][h][h'][v]
+  const float* d_vh = d, *d_vhp = d + KAM, *d_h = d + 2 * KAM, *d_hp = d_h + K;
+  const float* d_sw = d + 2 * KAM + 2 * K, *d_sb = d_sw + KAM, *d_v = d_sb + K;
+  const float* m_vh = m, *m_vhp = m + KAM, *m_h = m + 2 * KAM, *m_hp = m_h + K, *m_v = m_hp + K;
+  const float q = a.rho;
+  for (int idx = threadIdx.x; idx < KAM; idx += blockDim.x) {
+    const int k = idx / (4 * M), al = (idx / M) & 3, j = idx % M;
+    const int ridx = (k * 4 + (3 - al)) * M + (M - 1 - j);
+    float gd = d_vh[idx] / cnt_d, gm = m_vh[idx] / cnt_m;
+    if (a.ds) {
+      gd = 0.5f * (gd + d_vhp[ridx] / cnt_d);
+      gm = 0.5f * (gm + m_vhp[ridx] / cnt_m);
+    }
+    const float p = d_h[k] / cnt_d;
+    const float g = (q / p - (1.f - q) / (1.f - p)) / (float)K;
+    const float reg = -g * d_sw[idx] / cnt_d;
+    const float v = a.momentum * a.vW[idx] + a.lr * (gd - gm - a.lambda_rate * reg);
+    a.vW[idx] = v;
+    const float w = a.W[idx] + v;
+    a.W[idx] = w;
+    if (nw) nw[idx] = w;
+  }
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    float gd = d_h[k] / cnt_d, gm = m_h[k] / cnt_m;
+    if (a.ds) {
+      gd = 0.5f * (gd + d_hp[k] / cnt_d);
+      gm = 0.5f * (gm + m_hp[k] / cnt_m);
+    }
+    const float p = d_h[k] / cnt_d;
+    const float g = (q / p - (1.f - q) / (1.f - p)) / (float)K;
+    const float reg = -g * d_sb[k] / cnt_d;
+    const float v = a.momentum * a.vb[k] + a.lr * (gd - gm - a.lambda_rate * reg);
+    a.vb[k] = v;
+    const float bn = a.b[k] + v;
+    a.b[k] = bn;
+    if (nw) nw[KAM + k] = bn;
+  }
+  if (threadIdx.x < 4) {
+    const int al = threadIdx.x;
+    const float nd = n_d * (float)a.L_data, nm = n_m * (float)(a.Lf + M - 1);
+    const float gd = d_v[al] / nd + d_v[3 - al] / nd;     // a += a[::-1]  (:345)
+    const float gm = m_v[al] / nm + m_v[3 - al] / nm;
+    const float v = a.momentum * a.vc[al] + a.lr * (gd - gm);
+    a.vc[al] = v;
+    const float cn = a.c[al] + v;
+    a.c[al] = cn;
+    if (nw) nw[KAM + K + al] = cn;
+  }
+}
+
+// The end of a training step in one launch (one block): the update, then the LDS table images of
+// the new parameters for the next step's kernels.  The new W, b, c travel from the update to the
+// table build through LDS (the block's own global stores are not re-read).
+struct UpdateTablesArgs {
+  UpdateArgs u;
+  float* tables;     // Cfg::TABLES_ALL floats
+};
+
+template <class C>
+__device__ void update_tables_body(const UpdateTablesArgs& a) {
+  HIP_DYNAMIC_SHARED(float, smem);
+  constexpr int KAM = C::K * 4 * C::M;
+  apply_update_body(a.u, smem);
+  __syncthreads();
+  TablesArgs t;
+  t.W = smem; t.b = smem + KAM; t.c = smem + KAM + C::K; t.out = a.tables;
+  build_tables_body<C>(t);
+}
+
 #ifdef CRBM_DEFINE_MISC_KERNELS
 // ===========================================================================
 // Model-independent kernels, compiled ahead of time into libcrbm_hip.so.
@@ -1968,69 +2087,7 @@ __global__ void __launch_bounds__(1024) reduce_partials_pair_kernel(ReducePair p
   reduce_partials_body(p.half[blockIdx.y]);
 }
 
-// ---------------------------------------------------------------------------
-// Normalise the (all-reduced) raw sums and apply the SGD+momentum update
-// (convRBM.py:358-371, :415-436, :440-451).
-// ---------------------------------------------------------------------------
-struct UpdateArgs {
-  const float* sums;
-  float* W; float* b; float* c;
-  float* vW; float* vb; float* vc;
-  int32_t K, M, ds;
-  int32_t L_data, Lf;
-  int32_t data_off, n_d, model_off, n_m;   // offsets into sums
-  float lr, momentum, rho, lambda_rate;
-};
-
-__global__ void apply_update_kernel(UpdateArgs a) {
-  const int K = a.K, M = a.M, KAM = K * 4 * M;
-  const float n_d = a.sums[a.n_d], n_m = a.sums[a.n_m];
-  const float cnt_d = n_d * (float)(a.L_data - M + 1);
-  const float cnt_m = n_m * (float)a.Lf;
-  const float* d = a.sums + a.data_off;    // [vh][vh'][h][h'][sw][sb][v]
-  const float* m = a.sums + a.model_off;   // [vh][vh'][h][h'][v]
-  const float* d_vh = d, *d_vhp = d + KAM, *d_h = d + 2 * KAM, *d_hp = d_h + K;
-  const float* d_sw = d + 2 * KAM + 2 * K, *d_sb = d_sw + KAM, *d_v = d_sb + K;
-  const float* m_vh = m, *m_vhp = m + KAM, *m_h = m + 2 * KAM, *m_hp = m_h + K, *m_v = m_hp + K;
-  const float q = a.rho;
-  for (int idx = threadIdx.x; idx < KAM; idx += blockDim.x) {
-    const int k = idx / (4 * M), al = (idx / M) & 3, j = idx % M;
-    const int ridx = (k * 4 + (3 - al)) * M + (M - 1 - j);
-    float gd = d_vh[idx] / cnt_d, gm = m_vh[idx] / cnt_m;
-    if (a.ds) {
-      gd = 0.5f * (gd + d_vhp[ridx] / cnt_d);
-      gm = 0.5f * (gm + m_vhp[ridx] / cnt_m);
-    }
-    const float p = d_h[k] / cnt_d;
-    const float g = (q / p - (1.f - q) / (1.f - p)) / (float)K;
-    const float reg = -g * d_sw[idx] / cnt_d;
-    const float v = a.momentum * a.vW[idx] + a.lr * (gd - gm - a.lambda_rate * reg);
-    a.vW[idx] = v;
-    a.W[idx] += v;
-  }
-  for (int k = threadIdx.x; k < K; k += blockDim.x) {
-    float gd = d_h[k] / cnt_d, gm = m_h[k] / cnt_m;
-    if (a.ds) {
-      gd = 0.5f * (gd + d_hp[k] / cnt_d);
-      gm = 0.5f * (gm + m_hp[k] / cnt_m);
-    }
-    const float p = d_h[k] / cnt_d;
-    const float g = (q / p - (1.f - q) / (1.f - p)) / (float)K;
-    const float reg = -g * d_sb[k] / cnt_d;
-    const float v = a.momentum * a.vb[k] + a.lr * (gd - gm - a.lambda_rate * reg);
-    a.vb[k] = v;
-    a.b[k] += v;
-  }
-  if (threadIdx.x < 4) {
-    const int al = threadIdx.x;
-    const float nd = n_d * (float)a.L_data, nm = n_m * (float)(a.Lf + M - 1);
-    const float gd = d_v[al] / nd + d_v[3 - al] / nd;     // a += a[::-1]  (:345)
-    const float gm = m_v[al] / nm + m_v[3 - al] / nm;
-    const float v = a.momentum * a.vc[al] + a.lr * (gd - gm);
-    a.vc[al] = v;
-    a.c[al] += v;
-  }
-}
+__global__ void apply_update_kernel(UpdateArgs a) { apply_update_body(a, nullptr); }
 #endif  // CRBM_DEFINE_MISC_KERNELS
 
 }  // namespace crbm

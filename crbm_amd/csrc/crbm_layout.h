@@ -263,13 +263,15 @@ inline StatsLayout stats_layout(const ModelShape& ms, int want_sparsity, int Lh,
 // data half).  A wave owns the 16-motif tiles [nt0, nt0 + NTW) of every kind (its role,
 // NR = NT / NTW roles), so that its accumulator set stays <= 32 tiles (128 registers);
 // a unit is processed by one wave of every role.
-//   LDS of a block:  [lut 16 x 8 B][slice of wave 0][slice of wave 1] ...   (+ gather tables)
+//   LDS of a block:  [lut][slice of wave 0][slice of wave 1] ...   (+ gather tables)
 //   slice:           win [2][4] 64-bit letter windows: bit t of win[g][a] = [letter(32*gi + t) == a]
 //                    gw  [2][4] packed letter words of the two groups (stats_mfma_body only)
 //                    Pt  [kinds*KW + 1 rows][68] floats: row kind*KW + i = motif 16*nt0 + i of the
 //                        kind, 64 positions + 4 pad (row stride 17 x 16 B: conflict-free b128 reads);
 //                        the last row is all zero (motifs beyond K)
-//   lut:             nibble -> four f16 (bit e set -> 2^-14, else 0); two reads make an A fragment
+//   lut:             byte -> eight f16 (bit e set -> 2^-14, else 0): one 16-byte read makes an A fragment
+//                    (stand-alone kernel, 4 KB); the Gibbs kernel, short of LDS, uses the nibble form
+//                    (16 entries of four f16, two reads per fragment, 128 bytes)
 constexpr int STATS_RS = 68;                 // Pt row stride in floats
 constexpr int stats_ntw(int NT, int JT, int kinds) {        // motif tiles per wave
   int ntw = NT;
@@ -290,7 +292,7 @@ struct StatsMfmaLayout {
 // threads = 0: as many waves per role as the LDS (160 KiB minus `other_lds_bytes`: gather tables, or the
 // chain image of the Gibbs kernel) holds, at most 8 waves in all
 inline StatsMfmaLayout stats_mfma_layout(const ModelShape& ms, int want_sparsity, int Lh, int threads = 0,
-                                         int other_lds_bytes = 0) {
+                                         int other_lds_bytes = 0, bool byte_lut = true) {
   StatsMfmaLayout s;
   const int K = ms.K, M = ms.M, KAM = K * 4 * M;
   s.kinds = 1 + ms.DS + (want_sparsity ? 1 : 0);
@@ -303,13 +305,14 @@ inline StatsMfmaLayout stats_mfma_layout(const ModelShape& ms, int want_sparsity
   s.off_gw = 16;                        // 8 words
   s.off_pt = 24;
   s.slice = (s.off_pt + s.rows * STATS_RS + 3) & ~3;
-  s.off_slices = 32;
+  s.off_slices = byte_lut ? 1024 : 32;      // 256 x 16 B (stand-alone kernel) or 16 x 8 B (fused tail of the Gibbs kernel)
   s.threads = threads > 0 ? threads : stats_mfma_threads(s.NR);
   if (threads <= 0)
     while (s.threads > 64 * s.NR && (s.off_slices + (s.threads / 64) * s.slice) * 4 + other_lds_bytes > 160 * 1024)
       s.threads -= 64 * s.NR;
   s.region_floats = s.off_slices + (s.threads / 64) * s.slice;
-  s.combine_bytes = s.kinds * KAM * 4 + 64 * 4;
+  // per kind: total [KAM] + exchange + one set of roles parked ([KW][4][M] per wave); more waves at a time if there is room
+  s.combine_bytes = (KAM + 64 + s.NR * s.KW * 4 * M) * 4;
   s.off_vh[0] = 0;
   s.off_vh[1] = KAM;
   s.off_h[0] = 2 * KAM;

@@ -220,9 +220,10 @@ int emu_stats(int id, const float* tables, const uint32_t* letters, int n, int L
 }
 
 // fills the StatsGeom of a layout
-static StatsGeom geom_of(const StatsMfmaLayout& st, float* partials, long ngroups) {
+static StatsGeom geom_of(const StatsMfmaLayout& st, float* partials, long ngroups, size_t lds_bytes) {
   StatsGeom g;
   g.GPC = st.GPC;
+  g.lds_floats = (int)(lds_bytes / 4);
   g.off_slices = st.off_slices; g.slice = st.slice;
   g.off_win = st.off_win; g.off_gw = st.off_gw; g.off_pt = st.off_pt;
   g.divGPC = make_fastdiv((uint32_t)st.GPC, (uint64_t)ngroups);
@@ -272,9 +273,10 @@ int emu_stats_mfma(int id, const float* tables, const uint32_t* letters, int n, 
     if (gx > (nunits + wpr - 1) / wpr) gx = (int)((nunits + wpr - 1) / wpr);
     if ((long)gx * st.row > partials_cap) return -2;
     for (size_t i = 0; i < (size_t)gx * st.row; ++i) partials[i] = 1e30f;   // never cleared on the GPU either
-    a.sg = geom_of(st, partials, ngroups);
     a.off_tab = st.region_floats;
+    a.debug = 0;
     const size_t lds = std::max((size_t)st.region_floats * 4 + (size_t)(1 + C::DS) * C::TAB * 4, (size_t)st.combine_bytes);
+    a.sg = geom_of(st, partials, ngroups, lds);
     if (want_sparsity) emu::launch([&] { stats_mfma_body<C, true>(a); }, dim3(gx), dim3(st.threads), lds);
     else emu::launch([&] { stats_mfma_body<C, false>(a); }, dim3(gx), dim3(st.threads), lds);
     host_reduce(partials, gx, st.row, C::K, C::K * 4 * C::M, C::DS, want_sparsity, skip_begin, skip_len, (float)n, sums);
@@ -298,12 +300,12 @@ static int run_gibbs_stats(GibbsArgs a, int Lf, int S, int grid, int threads, fl
     a.divVB = make_fastdiv((uint32_t)gl.nvb); a.divHB = make_fastdiv((uint32_t)gl.nhb);
     a.divRow = make_fastdiv((uint32_t)(gl.Lrow * ms.NW)); a.divLfw = make_fastdiv((uint32_t)(Lf * ms.NW));
     if (!C::DS) a.hmp = nullptr;
-    const StatsMfmaLayout st = stats_mfma_layout(ms, 0, Lf, threads);
+    const StatsMfmaLayout st = stats_mfma_layout(ms, 0, Lf, threads, 0, false);
     if ((long)grid * st.row > partials_cap) return -2;
     for (size_t i = 0; i < (size_t)grid * st.row; ++i) partials[i] = 1e30f;
     a.stats_off = (gl.lds_bytes / 4 + 3) & ~3;
-    a.sg = geom_of(st, partials, (long)S * st.GPC);
     const size_t lds = std::max((size_t)(a.stats_off + st.region_floats) * 4, (size_t)st.combine_bytes);
+    a.sg = geom_of(st, partials, (long)S * st.GPC, lds);
     emu::launch([&] { gibbs_body<C, true, true>(a); }, dim3(grid), dim3(threads), lds);
     host_reduce(partials, grid, st.row, C::K, C::K * 4 * C::M, C::DS, 0, skip_begin, skip_len, (float)a.nchains, sums);
     return st.row;
@@ -339,6 +341,20 @@ int emu_update(const float* sums, float* W, float* b, float* c, float* vW, float
   UpdateArgs u{sums, W, b, c, vW, vb, vc, K, M, ds, L_data, Lf, sl.data_off, sl.n_d, sl.model_off, sl.n_m,
                lr, momentum, rho, lambda_rate};
   emu::launch([&] { apply_update_kernel(u); }, dim3(1), dim3(64), 0);
+  return 0;
+}
+
+// the fused end of a training step: update + table images of the new parameters (one block)
+int emu_update_tables(int id, const float* sums, float* W, float* b, float* c, float* vW, float* vb, float* vc,
+                      int L_data, int Lf, float lr, float momentum, float rho, float lambda_rate, float* tables, int threads) {
+  CFG_DISPATCH(id, {
+    const SumsLayout sl = sums_layout(C::K, C::M);
+    UpdateTablesArgs a;
+    a.u = UpdateArgs{sums, W, b, c, vW, vb, vc, C::K, C::M, C::DS, L_data, Lf, sl.data_off, sl.n_d, sl.model_off, sl.n_m,
+                     lr, momentum, rho, lambda_rate};
+    a.tables = tables;
+    emu::launch([&] { update_tables_body<C>(a); }, dim3(1), dim3(threads), (size_t)(C::K * 4 * C::M + C::K + 4) * 4);
+  });
   return 0;
 }
 

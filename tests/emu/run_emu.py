@@ -331,9 +331,14 @@ def test_train_step():
             np.testing.assert_allclose(sums[KAM:2 * KAM], s['vh_dp'].ravel(), rtol=2e-5, atol=1e-6)
             np.testing.assert_allclose(sums[model_off + KAM:model_off + 2 * KAM], s['vh_mp'].ravel(), rtol=2e-5, atol=1e-6)
             np.testing.assert_allclose(sums[model_off + 2 * KAM + K:model_off + 2 * KAM + 2 * K], s['h_mp'], rtol=2e-5)
-        lib.emu_update(fp(sums), fp(W), fp(b), fp(c), fp(vW), fp(vb), fp(vc), K, M, int(ds), L, Lf,
-                       ctypes.c_float(o.learning_rate), ctypes.c_float(o.momentum), ctypes.c_float(o.rho),
-                       ctypes.c_float(o.lambda_rate))
+        new_tables = np.zeros(info["TABLES"], dtype=np.float32)
+        lib.emu_update_tables(cid, fp(sums), fp(W), fp(b), fp(c), fp(vW), fp(vb), fp(vc), L, Lf,
+                              ctypes.c_float(o.learning_rate), ctypes.c_float(o.momentum), ctypes.c_float(o.rho),
+                              ctypes.c_float(o.lambda_rate), fp(new_tables), 128)
+        # the table images the fused launch leaves are those of the NEW parameters
+        ref_tables = np.zeros(info["TABLES"], dtype=np.float32)
+        assert lib.emu_tables(cid, fp(W), fp(b), fp(c), fp(ref_tables)) == 0
+        np.testing.assert_array_equal(new_tables, ref_tables)
         o.finalize_from_sums(s, L, Lf)
         np.testing.assert_allclose(W.reshape(o.W.shape), o.W, rtol=1e-4, atol=1e-6)
         np.testing.assert_allclose(b, o.b.ravel(), rtol=1e-4, atol=1e-6)

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from oracle.crbm_oracle import (OracleCRBM, synthetic_onehot, hidden_uniforms, visible_uniforms,
-                                KIND_API_H, KIND_API_V)
+                                KIND_API_H, KIND_API_V, KIND_CHAIN_H, KIND_CHAIN_V)
 
 pytestmark = pytest.mark.gpu
 
@@ -39,6 +39,53 @@ def assert_samples(got, prob, u):
     bad = got != want
     assert np.all(np.abs(prob - u)[bad] < 1e-6), "sample differs away from a p == u tie"
     assert bad.mean() < 1e-4
+
+
+TIE = 1e-6
+
+
+def assert_chain_steps(model, o, steps):
+    """`steps` Gibbs steps, one at a time from IDENTICAL states (the HIP chain is reset to the
+    oracle's before every step): every visible letter and every hidden unit that differs from the
+    oracle's must sit on a p == u tie (|p - u| < 1e-6, the only place where float32 and float64
+    arithmetic may legitimately decide differently).  Returns the number of ties met."""
+    ds = o.doublestranded
+    B, K, _, Lf = o.fantasy_h.shape
+    Lv = Lf + o.motif_length - 1
+    idx = np.arange(B) + o.seq_offset
+    ties = 0
+    for _ in range(steps):
+        h0, hp0 = o.fantasy_h.astype(np.float32), (o.fantasy_h_prime.astype(np.float32) if ds else None)
+        model.set_fantasy(h0, hp0)
+        t = o.gibbs_step
+        uv = visible_uniforms(o.seed, t, idx, Lv, KIND_CHAIN_V)
+        Pv, v = o._computeVgivenH(o.fantasy_h, o.fantasy_h_prime, uv)
+        uh = hidden_uniforms(o.seed, t, idx, K, Lf, 0, KIND_CHAIN_H)
+        P, h = o._computeHgivenV(v, False, uh)
+        if ds:
+            uhp = hidden_uniforms(o.seed, t, idx, K, Lf, 1, KIND_CHAIN_H)
+            Pp, hp = o._computeHgivenV(v, True, uhp)
+        model.gibbsSteps(1)
+        gv = model.get_fantasy_visible()
+        gh, ghp = model.get_fantasy()
+        np.testing.assert_array_equal(gv.sum(axis=2), 1.0)                       # one 1 per position
+        badv = (gv != v).any(axis=2)[:, 0]                                       # (B, Lv)
+        if badv.any():
+            cum = np.cumsum(Pv[:, 0], axis=1)[:, :3]                             # the three inner thresholds
+            gap = np.min(np.abs(cum - uv[:, None, :]), axis=1)
+            assert np.all(gap[badv] < TIE), "visible sample differs away from a tie"
+            ties += int(badv.sum())
+        clean = ~badv.any(axis=1)                                                # chains whose v agrees: h must too
+        for got, want, prob, u in ((gh, h, P, uh),) + (((ghp, hp, Pp, uhp),) if ds else ()):
+            bad = (got != want) & clean[:, None, None, None]
+            if bad.any():
+                assert np.all(np.abs(prob - u)[bad] < TIE), "hidden sample differs away from a tie"
+                ties += int(bad.sum())
+        o.fantasy_h, o.fantasy_h_prime = h, (hp if ds else None)
+        o.last_v_model = v
+        o.gibbs_step += 1
+    assert ties <= 1e-4 * steps * B * K * Lf * (2 if ds else 1) + 2
+    return ties
 
 
 # ---- reference tests/testcrbm.py:148-200 ------------------------------------
@@ -167,17 +214,20 @@ def test_gibbs_chain_matches_oracle(K, M, ds, Lf):
     o.fantasy_h, o.fantasy_h_prime = h0.astype(np.float64), (hp0.astype(np.float64) if ds else None)
     a, b = model.get_fantasy()
     np.testing.assert_array_equal(a, h0)
+    assert_chain_steps(model, o, 3)                   # sample for sample, ties only
+    assert o.fantasy_h.sum() > 0
+    # and the k-step launch composes: 1 + 2 steps in two launches == the oracle's 3 steps
+    model.set_fantasy(h0, hp0)
+    model.set_rng(gibbs_step=0)
+    o.fantasy_h, o.fantasy_h_prime = h0.astype(np.float64), (hp0.astype(np.float64) if ds else None)
+    o.gibbs_step = 0
     model.gibbsSteps(1)
     model.gibbsSteps(2)
     o.gibbs_steps(3)
     h, hp = model.get_fantasy()
-    assert o.fantasy_h.sum() > 0
-    assert (h != o.fantasy_h).mean() < 1e-4
+    assert (h != o.fantasy_h).mean() < 1e-4           # a tie in step 1 or 2 may legitimately fan out
     if ds:
         assert (hp != o.fantasy_h_prime).mean() < 1e-4
-    v = model.get_fantasy_visible()
-    np.testing.assert_array_equal(v.sum(axis=2), 1.0)
-    assert (v != o.last_v_model).mean() < 1e-4
 
 
 @pytest.mark.parametrize("variant", ["dense", "sparse"])
@@ -250,10 +300,15 @@ def test_train_step_trace(K, M, ds):
         np.testing.assert_allclose(model.bias.get_value(), o.b, rtol=RTOL, atol=2e-6)
         np.testing.assert_allclose(model.c.get_value(), o.c, rtol=RTOL, atol=2e-6)
         h, hp = model.get_fantasy()
-        assert (h != o.fantasy_h).mean() < 1e-3
+        assert (h != o.fantasy_h).mean() < 1e-4
+        # keep the two chains identical for the next step (a tie must not leak into the statistics)
+        o.fantasy_h = h.astype(np.float64)
+        if ds:
+            o.fantasy_h_prime = hp.astype(np.float64)
     vW, vb, vc = model.get_velocities()
-    np.testing.assert_allclose(vW, o.vW, rtol=1e-3, atol=2e-6)
-    np.testing.assert_allclose(vc, o.vc, rtol=1e-3, atol=2e-6)
+    np.testing.assert_allclose(vW, o.vW, rtol=RTOL, atol=2e-6)
+    np.testing.assert_allclose(vb, o.vb, rtol=RTOL, atol=2e-6)
+    np.testing.assert_allclose(vc, o.vc, rtol=RTOL, atol=2e-6)
 
 
 def test_host_reduced_data_parallel_equals_single():
@@ -400,11 +455,15 @@ def test_full_size_chain_properties():
     c = _cfg2_model(B, seed=7)                                           # another seed: different chain
     c.gibbsSteps(3)
     assert (c.get_fantasy()[0] != ha).mean() > 1e-3
-    # first 32 chains against the oracle
+    # the first 32 chains are bit-identical to a 32-chain run (chains are independent, counters are
+    # keyed by the global chain index) and that run follows the oracle sample for sample (ties only)
+    small = _cfg2_model(32)
+    small.gibbsSteps(3)
+    np.testing.assert_array_equal(small.get_fantasy()[0], ha[:32])
     o = OracleCRBM(10, 15, doublestranded=False, batchsize=32, cd_k=1, fantasy_hidden_len=186, seed=2026,
                    W=np.random.default_rng(42).standard_normal((10, 1, 4, 15)).astype(np.float32))
-    o.gibbs_steps(3)
-    assert (ha[:32] != o.fantasy_h).mean() < 1e-4
+    twin = _cfg2_model(32)
+    assert_chain_steps(twin, o, 3)
 
 
 def test_full_size_geometry_independence(monkeypatch):
@@ -422,26 +481,127 @@ def test_full_size_geometry_independence(monkeypatch):
     monkeypatch.delenv("CRBM_GIBBS_S"); monkeypatch.delenv("CRBM_GIBBS_THREADS")
 
 
-@pytest.mark.parametrize("K,M,ds,L,chains", [(50, 25, False, 1000, 2048), (20, 15, True, 500, 4096)])
-def test_large_config_train_and_chain(K, M, ds, L, chains):
-    """Configs #4 / #5 model sizes at (reduced-batch) full sequence length:
-    a training step keeps everything finite, c stays letter-symmetric, the
-    chain composes, the first chains match the oracle."""
+def _unpack_sums(buf, K, M):
+    """the packed raw-sum buffer of include/crbm_amd.h -> dict of arrays"""
+    KAM = K * 4 * M
+    row = 3 * KAM + 3 * K + 4
+    d, m = buf[:row + 1], buf[row + 1:]
+    out = {"vh_d": d[0:KAM], "vh_dp": d[KAM:2 * KAM], "h_d": d[2 * KAM:2 * KAM + K], "h_dp": d[2 * KAM + K:2 * KAM + 2 * K],
+           "sw": d[2 * KAM + 2 * K:3 * KAM + 2 * K], "sb": d[3 * KAM + 2 * K:3 * KAM + 3 * K],
+           "v_d": d[3 * KAM + 3 * K:3 * KAM + 3 * K + 4], "n_d": d[row],
+           "vh_m": m[0:KAM], "vh_mp": m[KAM:2 * KAM], "h_m": m[2 * KAM:2 * KAM + K], "h_mp": m[2 * KAM + K:2 * KAM + 2 * K],
+           "v_m": m[2 * KAM + 2 * K:2 * KAM + 2 * K + 4], "n_m": m[2 * KAM + 2 * K + 4]}
+    return out
+
+
+@pytest.mark.parametrize("K,M,ds,L,cd_k", [(50, 25, False, 1000, 5), (20, 15, True, 500, 1)])
+def test_baseline_config_full_batch(K, M, ds, L, cd_k):
+    """BASELINE configs #4 (50 x 25, 8192 x 4x1000, PCD-5) and #5 (20 x 15 doublestranded, 8192 x 4x500
+    per GPU) at their FULL batch: the real cd_k chain of all 8192 chains, whose first chains are
+    (a) bit-identical to an 8-chain run of the same handle type and (b) through that run checked
+    against the oracle sample for sample (ties only); plus the packed raw sums of a 64-row
+    sub-batch (both halves of the statistics, through crbm_train_local) against the oracle's."""
+    import ctypes
     from crbm_amd import CRBM
-    Lf = L - M + 1
+    from crbm_amd._lib import fptr
+    Lf, B = L - M + 1, 8192
     W = np.random.default_rng(42).standard_normal((K, 1, 4, M)).astype(np.float32)
-    m = CRBM(K, M, doublestranded=ds, batchsize=chains, cd_k=2, fantasy_hidden_len=Lf, seed=3)
-    m.motifs.set_value(W)
-    D = synthetic_onehot(256, L, seed=5)
-    m._trainingFct(D)
-    Wn, cn = m.motifs.get_value(), m.c.get_value()
-    assert np.isfinite(Wn).all() and not np.array_equal(Wn, W)
-    np.testing.assert_allclose(cn[0], cn[0, ::-1], atol=1e-6)
-    h1, _ = m.get_fantasy()
-    assert h1.shape == (chains, K, 1, Lf) and set(np.unique(h1)) <= {0.0, 1.0}
-    o = OracleCRBM(K, M, doublestranded=ds, batchsize=4, cd_k=2, fantasy_hidden_len=Lf, seed=3, W=W)
-    o.gibbs_steps(2)                       # the chain of step 1 does not depend on the data
-    assert (h1[:4] != o.fantasy_h).mean() < 1e-4
+
+    def make(chains):
+        m = CRBM(K, M, doublestranded=ds, batchsize=chains, cd_k=cd_k, fantasy_hidden_len=Lf, seed=3)
+        m.motifs.set_value(W)
+        return m
+    big = make(B)
+    big.gibbsSteps(cd_k)
+    hb, hbp = big.get_fantasy()
+    assert hb.shape == (B, K, 1, Lf) and 0.0005 < hb.mean() < 0.2
+    vb_ = big.get_fantasy_visible()
+    np.testing.assert_array_equal(vb_.sum(axis=2), 1.0)
+    small = make(8)
+    small.gibbsSteps(cd_k)
+    hs, hsp = small.get_fantasy()
+    np.testing.assert_array_equal(hb[:8], hs)
+    if ds:
+        np.testing.assert_array_equal(hbp[:8], hsp)
+    np.testing.assert_array_equal(vb_[:8], small.get_fantasy_visible())
+    del hb, hbp, vb_, big
+    # the 8-chain run against the oracle, step by step
+    o = OracleCRBM(K, M, doublestranded=ds, batchsize=8, cd_k=cd_k, fantasy_hidden_len=Lf, seed=3, W=W)
+    twin = make(8)
+    assert_chain_steps(twin, o, cd_k)
+    # raw sums of a training step on a 64-row sub-batch with 8 chains (data half + k Gibbs steps + model half)
+    o2 = OracleCRBM(K, M, doublestranded=ds, batchsize=8, cd_k=cd_k, fantasy_hidden_len=Lf, seed=3, W=W)
+    m2 = make(8)
+    D = synthetic_onehot(64, L, seed=5)
+    h2_ = m2._h()
+    cnt = m2._lib.crbm_sums_count(h2_)
+    buf = np.zeros(cnt, dtype=np.float32)
+    m2._call("crbm_train_local", fptr(D), 64, L, fptr(buf))
+    P_m, P_mp, v_m = o2.gibbs_steps(cd_k)
+    h2, h2p = m2.get_fantasy()
+    if np.array_equal(h2, o2.fantasy_h) and (not ds or np.array_equal(h2p, o2.fantasy_h_prime)):
+        ref = o2.local_sums(D, P_m, P_mp, v_m)
+        got = _unpack_sums(buf, K, M)
+        for key in ("vh_d", "h_d", "sw", "sb", "v_d", "vh_m", "h_m", "v_m") + (("vh_dp", "h_dp", "vh_mp", "h_mp") if ds else ()):
+            np.testing.assert_allclose(got[key], np.ravel(ref[key]), rtol=RTOL, atol=1e-5, err_msg=key)
+        assert got["n_d"] == 64 and got["n_m"] == 8
+    else:                                   # a tie flipped a unit: the step-by-step test above vouches for the chain
+        assert (h2 != o2.fantasy_h).mean() < 1e-4
+
+
+def test_resume_equals_uninterrupted_oracle(tmp_path):
+    """SURVEY 8(f)-3 against the oracle, not against ourselves: the oracle runs two training steps
+    in one go; the HIP model runs step -> saveState -> loadState -> step.  (The reference's own
+    saveModel/loadModel would restart momentum and chains from zero, convRBM.py:226-235.)"""
+    from crbm_amd import CRBM
+    K, M, ds = 6, 9, True
+    a, o = make_pair(K, M, ds=ds, batchsize=16, Lf=40, cd_k=2, bshift=4.0, rho=0.03)
+    D1, D2 = synthetic_onehot(24, 70, seed=3), synthetic_onehot(24, 70, seed=4)
+    a._trainingFct(D1)
+    o.train_step(D1)
+    h, hp = a.get_fantasy()
+    assert (h != o.fantasy_h).mean() < 1e-4
+    o.fantasy_h, o.fantasy_h_prime = h.astype(np.float64), hp.astype(np.float64)     # ties must not leak
+    fn = str(tmp_path / "state.pkl")
+    a.saveState(fn)
+    del a
+    b = CRBM.loadState(fn)
+    b._trainingFct(D2)
+    o.train_step(D2)                                   # never interrupted: velocities and chains carried over
+    np.testing.assert_allclose(b.motifs.get_value(), o.W, rtol=RTOL, atol=2e-6)
+    np.testing.assert_allclose(b.bias.get_value(), o.b, rtol=RTOL, atol=2e-6)
+    np.testing.assert_allclose(b.c.get_value(), o.c, rtol=RTOL, atol=2e-6)
+    vW, vb, vc = b.get_velocities()
+    np.testing.assert_allclose(vW, o.vW, rtol=RTOL, atol=2e-6)
+    np.testing.assert_allclose(vb, o.vb, rtol=RTOL, atol=2e-6)
+    assert (b.get_fantasy()[0] != o.fantasy_h).mean() < 1e-4
+    # the reference-format file of the same model still loads, with momentum and chains reset
+    fm = str(tmp_path / "model.pkl")
+    b.saveModel(fm)
+    c = CRBM.loadModel(fm)
+    np.testing.assert_array_equal(c.motifs.get_value(), b.motifs.get_value())
+
+
+def test_long_sequences_use_exact_division():
+    """rows longer than 65536 positions (one sequence per tile) must not wrap the
+    reciprocal-multiply division: activations, probabilities, samples, the dense v|h pass and the
+    free energy of a 70 001-bp sequence against the oracle."""
+    K, M, ds, L, n = 3, 7, True, 70001, 2
+    model, o = make_pair(K, M, ds=ds, batchsize=2, Lf=10, bshift=5.0)
+    D = synthetic_onehot(n, L, seed=9)
+    np.testing.assert_allclose(model._bottomUpActivity(D), o._bottomUpActivity(D), rtol=1e-5, atol=2e-5)
+    P, S = model._computeHgivenV(D, flip_motif=True, rng_step=3)
+    Lh = L - M + 1
+    u = hidden_uniforms(model.seed, 3, np.arange(n), K, Lh, 1, KIND_API_H)
+    ref = o._bottomUpProbability(o._bottomUpActivity(D, True))
+    np.testing.assert_allclose(P, ref, rtol=RTOL, atol=1e-7)
+    assert_samples(S, ref, u)
+    np.testing.assert_allclose(model.motifHitProbs(D), o.motifHitProbs(D), rtol=RTOL, atol=1e-7)
+    np.testing.assert_allclose(model.freeEnergy(D), o.freeEnergy(D), rtol=RTOL)
+    rng = np.random.default_rng(1)
+    h = rng.binomial(1, 0.02, size=(n, K, 1, Lh)).astype(np.float32)
+    hp = rng.binomial(1, 0.02, size=(n, K, 1, Lh)).astype(np.float32)
+    np.testing.assert_allclose(model._topDownActivity(h, hp), o._topDownActivity(h, hp), rtol=1e-5, atol=2e-5)
 
 
 def test_full_size_statistics_are_additive():
