@@ -109,6 +109,8 @@ struct crbm_handle {
   bool tables_dirty = true;
   // parameters and optimiser state
   float *dW = nullptr, *db = nullptr, *dc = nullptr, *dvW = nullptr, *dvb = nullptr, *dvc = nullptr;
+  // the update writes into a second set of buffers; the two sets swap after every step (launch_update)
+  float *dW2 = nullptr, *db2 = nullptr, *dc2 = nullptr, *dvW2 = nullptr, *dvb2 = nullptr, *dvc2 = nullptr;
   // persistent chains: K-bit masks per hidden position, letters of the last visible sample
   uint32_t *d_hm = nullptr, *d_hmp = nullptr, *d_vf = nullptr;
   uint32_t* d_flags = nullptr;
@@ -138,8 +140,7 @@ struct crbm_handle {
   int nset_slots = 0;
   uint32_t launches_since_read = 0;
   double activity = -1.0;              // fraction of hidden units on after the last launch that was read back
-  int stats_rows = 0, stats_lds_budget = 0;
-  bool stats_mfma = true;              // CRBM_STATS=walk selects the letter-bucketed LDS walk (A/B runs)
+  int stats_rows = 0;
   bool fuse_stats = false;             // model half of the statistics inside the Gibbs kernel (Cfg::FUSE_STATS; CRBM_STATS=split: off)
   SumsLayout sl;
   // data parallel
@@ -328,63 +329,6 @@ int refresh_activity(crbm_handle* h) {
   return CRBM_OK;
 }
 
-// raw statistic sums of (letters, n, L) -> sums half (data or model)
-// `defer`: hand the reduction of the partial rows back to the caller (to pair it with the other half)
-int launch_stats_mfma(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool data_half, hipStream_t s,
-                      ReduceArgs* defer);
-
-int launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool data_half, hipStream_t s = nullptr,
-                 ReduceArgs* defer = nullptr) {
-  if (h->stats_mfma) return launch_stats_mfma(h, d_letters, n, L, data_half, s, defer);
-  if (!s) s = h->stream;
-  DevBuf<float>& pbuf = data_half ? h->partials : h->partials2;
-  int rc = ensure_tables(h);
-  if (rc) return rc;
-  const int want_sp = data_half ? 1 : 0;
-  const int Lh = L - h->M + 1;
-  const StatsLayout st = stats_layout(h->ms, want_sp, Lh, n, h->stats_lds_budget, env_int("CRBM_STATS_S", 0));
-  StatsArgs a;
-  a.tables = h->d_tables;
-  a.letters = d_letters;
-  a.n = n; a.L = L; a.Lh = Lh; a.LW = letter_words(L);
-  a.S = st.S; a.LS = st.LS; a.nseg = st.nseg; a.Rrow = st.Rrow; a.LWt = st.LWt;
-  a.PB = st.PB; a.parts = st.parts; a.npasses = st.npasses;
-  a.want_sparsity = want_sp;
-  a.divLS = make_fastdiv((uint32_t)st.LS);
-  a.divLvis = make_fastdiv((uint32_t)(st.LS + h->M - 1));   // only used when nseg == 1 (S > 1)
-  a.divL = make_fastdiv((uint32_t)L);
-  a.row = st.row;
-  a.off_vh0 = st.off_vh[0]; a.off_vh1 = st.off_vh[1]; a.off_h0 = st.off_h[0]; a.off_h1 = st.off_h[1];
-  a.off_sw = st.off_sw; a.off_sb = st.off_sb; a.off_v = st.off_v;
-  const int ntiles = ((n + st.S - 1) / st.S) * st.nseg;
-  // persistent rows: one resident wave of blocks (as many per CU as their LDS allows)
-  const int per_cu = std::max(1, std::min(8, (160 * 1024) / std::max(1, st.lds_bytes)));
-  const int cap = h->stats_rows > 0 ? h->stats_rows : h->num_cu * per_cu;
-  const int gx = std::max(1, std::min(ntiles, cap));
-  const int rows = gx;   // one partial row per block
-  HIPCHK(pbuf.ensure((size_t)rows * st.row));
-  a.partials = pbuf.p;
-  a.debug = env_int("CRBM_STATS_DEBUG", 0);
-  HIPCHK(jit_launch(h->jk.stats, a, (unsigned)gx, (unsigned)st.grid_y, (unsigned)st.threads,
-                    (unsigned)st.lds_bytes, s));
-  ReduceArgs r;
-  r.partials = pbuf.p;
-  r.nrows = rows; r.row = st.row;
-  r.K = h->K; r.KAM = h->KAM; r.ds = h->ds; r.want_sparsity = want_sp;
-  if (data_half) {
-    r.sums = h->d_sums + h->sl.data_off;
-    r.skip_begin = st.row; r.skip_len = 0;
-  } else {
-    r.sums = h->d_sums + h->sl.model_off;
-    r.skip_begin = h->sl.model_skip_begin; r.skip_len = h->sl.model_skip_len;
-  }
-  r.n_value = (float)n;
-  if (defer) { *defer = r; return CRBM_OK; }
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((st.row + 31) / 32), dim3(1024), 0, s, r);
-  HIPCHK(hipGetLastError());
-  return CRBM_OK;
-}
-
 StatsGeom stats_geom(const StatsMfmaLayout& st, float* partials, long ngroups, int lds_bytes) {
   StatsGeom g;
   g.GPC = st.GPC;
@@ -398,10 +342,11 @@ StatsGeom stats_geom(const StatsMfmaLayout& st, float* partials, long ngroups, i
   return g;
 }
 
-// MFMA statistics kernel (stats_mfma_body): raw sums of (letters, n, L) -> partial rows; the column
-// reduction is handed back to the caller (ReduceArgs) or launched here.
-int launch_stats_mfma(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool data_half, hipStream_t s,
-                      ReduceArgs* defer) {
+// MFMA statistics kernel (stats_mfma_body): raw statistic sums of (letters, n, L) -> partial rows of the
+// data or the model half; the column reduction is handed back to the caller (`defer`, to pair it with the
+// other half) or launched here.
+int launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool data_half, hipStream_t s = nullptr,
+                 ReduceArgs* defer = nullptr) {
   if (!s) s = h->stream;
   DevBuf<float>& pbuf = data_half ? h->partials : h->partials2;
   int rc = ensure_tables(h);
@@ -409,7 +354,9 @@ int launch_stats_mfma(crbm_handle* h, const uint32_t* d_letters, int n, int L, b
   const int want_sp = data_half ? 1 : 0;
   const int Lh = L - h->M + 1;
   const int tabs = (1 + h->ds) * tab_bytes(h);
-  const StatsMfmaLayout st = stats_mfma_layout(h->ms, want_sp, Lh, env_int("CRBM_STATS_THREADS", 0), tabs);
+  // CRBM_STATS_MAX_TILES is an experiment knob: it must come with CRBM_JIT_DEFINES=-DCRBM_STATS_MAX_TILES=<same>
+  const StatsMfmaLayout st = stats_mfma_layout(h->ms, want_sp, Lh, env_int("CRBM_STATS_THREADS", 0), tabs, true,
+                                               env_int("CRBM_STATS_MAX_TILES", CRBM_STATS_MAX_TILES));
   StatsMfmaArgs a;
   a.tables = h->d_tables;
   a.letters = d_letters;
@@ -453,12 +400,16 @@ int launch_update(crbm_handle* h, int L_data) {
   UpdateArgs& u = a.u;
   u.sums = h->d_sums;
   u.W = h->dW; u.b = h->db; u.c = h->dc; u.vW = h->dvW; u.vb = h->dvb; u.vc = h->dvc;
+  u.oW = h->dW2; u.ob = h->db2; u.oc = h->dc2; u.ovW = h->dvW2; u.ovb = h->dvb2; u.ovc = h->dvc2;
   u.K = h->K; u.M = h->M; u.ds = h->ds;
   u.L_data = L_data; u.Lf = h->Lf;
   u.data_off = h->sl.data_off; u.n_d = h->sl.n_d; u.model_off = h->sl.model_off; u.n_m = h->sl.n_m;
   u.lr = h->cfg.learning_rate; u.momentum = h->cfg.momentum; u.rho = h->cfg.rho; u.lambda_rate = h->cfg.lambda_rate;
   a.tables = h->d_tables;
-  HIPCHK(jit_launch(h->jk.update_tables, a, 1, 1, 1024, (unsigned)((h->KAM + h->K + 4) * 4), h->stream));
+  const unsigned grid = (unsigned)std::max(1, std::min((h->ms.TABLES_ALL + 1023) / 1024, 32));
+  HIPCHK(jit_launch(h->jk.update_tables, a, grid, 1, 256, (unsigned)((h->KAM + h->K + 4) * 4), h->stream));
+  std::swap(h->dW, h->dW2); std::swap(h->db, h->db2); std::swap(h->dc, h->dc2);
+  std::swap(h->dvW, h->dvW2); std::swap(h->dvb, h->dvb2); std::swap(h->dvc, h->dvc2);
   h->tables_dirty = false;
   return CRBM_OK;
 }
@@ -680,8 +631,6 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
   TRY(hipGetDeviceProperties(&prop, hh->device));
   hh->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   // launch geometry, then the model-specific kernels (hiprtc; cached on disk)
-  if (hh->ms.STATS_WAVES == 8) hh->ms.STATS_WAVES = env_int("CRBM_STATS_WAVES_BIG", 8);   // experiment knob; must match -DCRBM_STATS_WAVES_BIG
-  else hh->ms.STATS_WAVES = env_int("CRBM_STATS_WAVES_SMALL", 4);                        // experiment knob; must match -DCRBM_STATS_WAVES_SMALL
   hh->has_dense = hh->ms.DENSE != 0;
   for (int v = hh->has_dense ? 0 : 1; v < 2; ++v) {
     const GibbsGeom geom = choose_gibbs_geometry(hh->ms, hh->Lf, hh->B, hh->num_cu, v == 1);
@@ -723,6 +672,9 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
   TRY(hipMemset(hh->dW, 0, kam * 4)); TRY(hipMemset(hh->dvW, 0, kam * 4));
   TRY(hipMemset(hh->db, 0, k * 4));   TRY(hipMemset(hh->dvb, 0, k * 4));
   TRY(hipMemset(hh->dc, 0, 16));      TRY(hipMemset(hh->dvc, 0, 16));
+  TRY(hipMalloc((void**)&hh->dW2, kam * 4)); TRY(hipMalloc((void**)&hh->dvW2, kam * 4));
+  TRY(hipMalloc((void**)&hh->db2, k * 4));   TRY(hipMalloc((void**)&hh->dvb2, k * 4));
+  TRY(hipMalloc((void**)&hh->dc2, 16));      TRY(hipMalloc((void**)&hh->dvc2, 16));
   TRY(hipMalloc((void**)&hh->d_tables, (size_t)hh->ms.TABLES_ALL * 4));
   const size_t mwords = (size_t)hh->B * hh->Lf * hh->NW;
   TRY(hipMalloc((void**)&hh->d_hm, mwords * 4)); TRY(hipMemset(hh->d_hm, 0, mwords * 4));
@@ -740,8 +692,7 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
   hh->tables_dirty = true;
   {
     const char* sv = getenv("CRBM_STATS");
-    hh->stats_mfma = !(sv && !strcmp(sv, "walk"));
-    hh->fuse_stats = hh->stats_mfma && hh->ms.FUSE_STATS && hh->variant == 1 && !(sv && !strcmp(sv, "split"));
+    hh->fuse_stats = hh->ms.FUSE_STATS && hh->variant == 1 && !(sv && !strcmp(sv, "split"));
     if (hh->fuse_stats) {   // the fused launch appends the statistics slices to the chain image: it must fit the LDS
       const StatsMfmaLayout st = stats_mfma_layout(hh->ms, 0, hh->Lf, hh->gibbs_threads, 0, false);
       const int lds = std::max((((hh->gl.lds_bytes / 4 + 3) & ~3) + st.region_floats) * 4, st.combine_bytes);
@@ -749,7 +700,6 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
     }
   }
   hh->stats_rows = env_int("CRBM_STATS_ROWS", 0);   // 0: one resident wave of blocks
-  hh->stats_lds_budget = env_int("CRBM_STATS_LDS", 0);   // 0: chosen per model (stats_layout)
   *out = hh;
   return CRBM_OK;
 }
@@ -760,7 +710,7 @@ int crbm_destroy(crbm_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->stream2) (void)hipStreamSynchronize(h->stream2);
   if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
-  void* ptrs[] = {h->dW, h->db, h->dc, h->dvW, h->dvb, h->dvc, h->d_hm, h->d_hmp, h->d_vf, h->d_flags, h->d_ones, h->d_nset, h->d_sums, h->d_tables};
+  void* ptrs[] = {h->dW2, h->db2, h->dc2, h->dvW2, h->dvb2, h->dvc2, h->dW, h->db, h->dc, h->dvW, h->dvb, h->dvc, h->d_hm, h->d_hmp, h->d_vf, h->d_flags, h->d_ones, h->d_nset, h->d_sums, h->d_tables};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   h->stage.release(); h->stage2.release(); h->out_a.release(); h->out_b.release(); h->out_c.release();
@@ -1633,13 +1583,18 @@ int crbm_train_apply(crbm_handle* h, const float* sums_in, int32_t L_data) {
 
 int crbm_get_launch_info(const crbm_handle* h, crbm_launch_info* out) {
   if (!h || !out) return CRBM_ERR_INVALID;
-  const StatsLayout st = stats_layout(h->ms, 1, h->Lf, h->B, h->stats_lds_budget);
+  // the data-half statistics kernel at the chains' shape (stats_mfma_body)
+  const int tabs = (1 + h->ds) * h->ms.TAB * 4;
+  const StatsMfmaLayout st = stats_mfma_layout(h->ms, 1, h->Lf, 0, tabs);
+  const int lds = std::max(st.region_floats * 4 + tabs, st.combine_bytes);
   out->nq = h->ms.NQ; out->group = h->G;
   out->gibbs_grid = h->gibbs_grid; out->gibbs_block = h->gibbs_threads;
   out->gibbs_seqs_per_tile = h->gl.S; out->gibbs_lds_bytes = h->gl.lds_bytes;
-  out->stats_grid_x = h->stats_rows > 0 ? h->stats_rows : h->num_cu * std::max(1, std::min(8, (160 * 1024) / std::max(1, st.lds_bytes)));
-  out->stats_grid_y = st.grid_y;
-  out->stats_block = st.threads; out->stats_lds_bytes = st.lds_bytes;
+  out->stats_grid_x = h->stats_rows > 0 ? h->stats_rows
+                                        : h->num_cu * std::max(1, std::min(2048 / st.threads, (160 * 1024) / std::max(1, lds)));
+  out->stats_grid_y = 1;
+  out->stats_block = st.threads; out->stats_lds_bytes = lds;
+  out->stats_fused = h->fuse_stats ? 1 : 0;
   out->gibbs_sparse = h->variant;
   out->activity_ppm = h->activity < 0.0 ? -1 : (int32_t)(h->activity * 1e6 + 0.5);
   return CRBM_OK;
@@ -1657,7 +1612,7 @@ int crbm_copy_bandwidth(crbm_handle* h, int64_t bytes, int32_t reps, float* gb_p
   hipError_t e = hipMalloc((void**)&dst, n4 * 16);
   if (e != hipSuccess) { (void)hipFree(src); return fail(h, CRBM_ERR_HIP, "hipMalloc (copy buffer)"); }
   (void)hipMemsetAsync(src, 1, n4 * 16, h->stream);
-  const int grid = h->num_cu * 16;
+  const unsigned grid = (unsigned)((n4 + 1023) / 1024);
   for (int i = 0; i < 1 + reps; ++i) {
     if (i == 1) (void)hipEventRecord(h->ev0, h->stream);
     hipLaunchKernelGGL(copy_float4_kernel, dim3(grid), dim3(256), 0, h->stream, src, dst, n4);

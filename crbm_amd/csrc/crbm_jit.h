@@ -27,7 +27,7 @@ namespace crbm {
 struct JitKernels {
   hipModule_t module = nullptr;
   hipFunction_t build_tables = nullptr, update_tables = nullptr, hgv = nullptr, gibbs = nullptr /* dense top-down; null if the model has none */,
-                gibbs_sparse = nullptr, gibbs_sparse_stats = nullptr /* null unless Cfg::FUSE_STATS */, stats = nullptr, stats_mfma_data = nullptr, stats_mfma_model = nullptr,
+                gibbs_sparse = nullptr, gibbs_sparse_stats = nullptr /* null unless Cfg::FUSE_STATS */, stats_mfma_data = nullptr, stats_mfma_model = nullptr,
                 free_energy = nullptr, hit_summary = nullptr;
   bool from_cache = false;
   std::string cache_file;
@@ -80,12 +80,11 @@ inline std::string jit_stub(int K, int M, int DS, int G, int gibbs_wpe) {
            "#ifndef CRBM_GIBBS_STATS_ATTR\n#define CRBM_GIBBS_STATS_ATTR %s\n#endif\n"
            "using ModelCfg = crbm::Cfg<%d, %d, %d, %d>;\n"
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_build_tables(crbm::TablesArgs a) { crbm::build_tables_body<ModelCfg>(a); }\n"
-           "extern \"C\" __global__ void __launch_bounds__(1024) crbm_update_tables(crbm::UpdateTablesArgs a) { crbm::update_tables_body<ModelCfg>(a); }\n"
+           "extern \"C\" __global__ void __launch_bounds__(256) crbm_update_tables(crbm::UpdateTablesArgs a) { crbm::update_tables_body<ModelCfg>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_hgv(crbm::HgvArgs a) { crbm::hgv_body<ModelCfg>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) CRBM_GIBBS_ATTR crbm_gibbs_sparse(crbm::GibbsArgs a) { crbm::gibbs_body<ModelCfg, true>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) CRBM_GIBBS_STATS_ATTR crbm_gibbs_sparse_stats(crbm::GibbsArgs a) { if constexpr (ModelCfg::FUSE_STATS) crbm::gibbs_body<ModelCfg, true, true>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_gibbs(crbm::GibbsArgs a) { if constexpr (ModelCfg::DENSE) crbm::gibbs_body<ModelCfg, ModelCfg::DENSE ? false : true>(a); }\n"
-           "extern \"C\" __global__ void __launch_bounds__(64 * ModelCfg::STATS_WAVES) crbm_stats(crbm::StatsArgs a) { crbm::stats_body<ModelCfg>(a); }\n"
            "using RoleData = crbm::StatsRole<ModelCfg, true>;\nusing RoleModel = crbm::StatsRole<ModelCfg, false>;\n"
            "extern \"C\" __global__ void __launch_bounds__(RoleData::THREADS) crbm_stats_mfma_data(crbm::StatsMfmaArgs a) { crbm::stats_mfma_body<ModelCfg, true>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(RoleModel::THREADS) crbm_stats_mfma_model(crbm::StatsMfmaArgs a) { crbm::stats_mfma_body<ModelCfg, false>(a); }\n"
@@ -107,7 +106,7 @@ inline int jit_compile(int K, int M, int DS, int G, int gibbs_wpe, std::vector<c
   const std::string stub = jit_stub(K, M, DS, G, gibbs_wpe);
   std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
                                    "-I" + dir, "-I/opt/rocm/include"};
-  if (const char* e = getenv("CRBM_JIT_DEFINES")) {   // tuning knobs, e.g. "-DCRBM_STATS_UNR=8"
+  if (const char* e = getenv("CRBM_JIT_DEFINES")) {   // tuning knobs, e.g. "-DCRBM_STATS_MAX_TILES=16"
     std::istringstream ss(e);
     std::string tok;
     while (ss >> tok) opts.push_back(tok);
@@ -180,7 +179,7 @@ inline int jit_load(int K, int M, int DS, int G, int gibbs_wpe, JitKernels* out,
   struct { const char* name; hipFunction_t* f; } syms[] = {
       {"crbm_build_tables", &out->build_tables}, {"crbm_update_tables", &out->update_tables}, {"crbm_hgv", &out->hgv}, {"crbm_gibbs", &out->gibbs},
       {"crbm_gibbs_sparse", &out->gibbs_sparse}, {"crbm_gibbs_sparse_stats", &out->gibbs_sparse_stats},
-      {"crbm_stats", &out->stats}, {"crbm_stats_mfma_data", &out->stats_mfma_data},
+      {"crbm_stats_mfma_data", &out->stats_mfma_data},
       {"crbm_stats_mfma_model", &out->stats_mfma_model}, {"crbm_free_energy", &out->free_energy},
       {"crbm_hit_summary", &out->hit_summary}};
   for (auto& s : syms) {

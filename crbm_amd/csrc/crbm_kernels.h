@@ -142,6 +142,11 @@ __device__ __forceinline__ uint32_t fastdiv(uint32_t i, const FastDiv& f) {
   if (f.fix && q * f.d > i) --q;   // long rows only (crbm_layout.h): the estimate is q or q + 1
   return q;
 }
+// The Gibbs kernel divides indices of one LDS-resident tile: dividend and divisor are both at most
+// the tile's word count (<= 40 960: 160 KB), so n*d < 2^32 and the single mul_hi is always exact.
+__device__ __forceinline__ uint32_t fastdiv_tile(uint32_t i, const FastDiv& f) {
+  return f.d <= 1 ? i : __umulhi(i, f.inv);
+}
 
 // The MFMA statistics carry probabilities scaled by 2^14 (and a one-hot operand of 2^-14):
 // the f16 halves of P then stay normal numbers down to P ~ 4e-9 instead of 6e-5.
@@ -455,10 +460,10 @@ __device__ void hgv_body(const HgvArgs& a) {
 //                from an LDS image the h|v pass writes transposed ([column][position]).
 // The accumulators (one 16x16 f32 tile per letter x column tile x motif tile) stay in
 // registers for the whole kernel; waves of a block are combined through LDS at the
-// end and the block writes one partial row.  Against the letter-bucketed walk this
-// replaces (stats_body: one LDS read and one VALU add per (k, j, position)), the
-// parked rows are read once instead of M times and the adds run on the matrix pipe
-// beside the VALU work of the next chunk's h|v pass.
+// end and the block writes one partial row.  Against the letter-bucketed LDS walk of
+// round 1 (one LDS read and one VALU add per (k, j, position); 42.5 us per half at
+// config #2) the parked probabilities are read once instead of M
+// times and the adds run on the matrix pipe beside the VALU work of other waves.
 // north_star's "no MFMA" is about the convolution and its transpose (4-wide output,
 // one-hot operand: gathers); this contraction is the one dense product on the path.
 // ===========================================================================
@@ -891,13 +896,16 @@ __device__ void gibbs_body(const GibbsArgs& a) {
   int nset = 0;
   // statistics state (STATS): the wave's LDS slice, accumulator tiles, letter counts
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-  float* sreg = smem + a.stats_off;
-  float* sslice = sreg + a.sg.off_slices + (size_t)wave * a.sg.slice;
-  uint2* swin = reinterpret_cast<uint2*>(sslice + a.sg.off_win);
-  float* sPt = sslice + a.sg.off_pt;
+  float* sreg = nullptr;
+  uint2* swin = nullptr;
+  float* sPt = nullptr;
   floatx4 sacc[STATS ? SR::NACC : 1];
   float vcount = 0.f;
   if constexpr (STATS) {
+    sreg = smem + a.stats_off;
+    float* sslice = sreg + a.sg.off_slices + (size_t)wave * a.sg.slice;
+    swin = reinterpret_cast<uint2*>(sslice + a.sg.off_win);
+    sPt = sslice + a.sg.off_pt;
 #pragma unroll
     for (int t = 0; t < SR::NACC; ++t) sacc[t] = floatx4{0.f, 0.f, 0.f, 0.f};
     stats_build_lut<false>(reinterpret_cast<uint32_t*>(sreg));
@@ -924,7 +932,7 @@ __device__ void gibbs_body(const GibbsArgs& a) {
     if (!(a.debug & 2)) {
       const uint32_t nwords = (uint32_t)ns * per;
       auto lds_index = [&](uint32_t i) {           // word i of the tile -> padded row position
-        const uint32_t nl = fastdiv(i, a.divLfw);
+        const uint32_t nl = fastdiv_tile(i, a.divLfw);
         return nl * (uint32_t)rowW + (uint32_t)((M - 1) * NW) + (i - nl * per);
       };
       const size_t g0 = (size_t)n0 * per;
@@ -986,7 +994,7 @@ __device__ void gibbs_body(const GibbsArgs& a) {
       __syncthreads();
       // ---- v | h : y[a,p] = c[a] + sum_{k,j} W[k,a,j] h[k,p-j] (+ rc strand) ----
       for (uint32_t it = threadIdx.x; it < (uint32_t)(ns * a.nvb); it += blockDim.x) {
-        const uint32_t nl = fastdiv(it, a.divVB);
+        const uint32_t nl = fastdiv_tile(it, a.divVB);
         const int pb = (int)(it - nl * (uint32_t)a.nvb);
         const int p0 = 4 * pb;
         float y[4][4];
@@ -1083,7 +1091,7 @@ __device__ void gibbs_body(const GibbsArgs& a) {
             int gi = 0;
             uint32_t word = 0u;
             if (G < ngl) {
-              const uint32_t nl = fastdiv((uint32_t)G, a.sg.divGPC);
+              const uint32_t nl = fastdiv_tile((uint32_t)G, a.sg.divGPC);
               gi = G - (int)nl * GPC;
               if (2 * gi + w < a.LWs) word = let[(size_t)nl * a.LWs + 2 * gi + w];
             }
@@ -1096,7 +1104,7 @@ __device__ void gibbs_body(const GibbsArgs& a) {
             uint32_t nl = 0u;
             int s = 0;
             if (valid) {
-              nl = fastdiv((uint32_t)G, a.sg.divGPC);
+              nl = fastdiv_tile((uint32_t)G, a.sg.divGPC);
               s = 32 * (G - (int)nl * GPC) + (lane & 31);
               valid = s < a.Lf;
             }
@@ -1139,7 +1147,7 @@ __device__ void gibbs_body(const GibbsArgs& a) {
       // already give the instruction-level parallelism, and single positions spread evenly
       // over the waves of the block
       for (uint32_t it = threadIdx.x; it < (uint32_t)(ns * a.nhb); it += blockDim.x) {
-        const uint32_t nl = fastdiv(it, a.divHB);
+        const uint32_t nl = fastdiv_tile(it, a.divHB);
         const int s = (int)(it - nl * (uint32_t)a.nhb);
         const uint32_t gn = a.rng.seq_offset + (uint32_t)(n0 + nl);
         const uint64_t win = letter_window<M>(let + (size_t)nl * a.LWs, s);
@@ -1165,7 +1173,7 @@ __device__ void gibbs_body(const GibbsArgs& a) {
       const uint32_t nwords = (uint32_t)ns * per;
       const size_t g0 = (size_t)n0 * per;
       auto lds_index = [&](uint32_t i) {
-        const uint32_t nl = fastdiv(i, a.divLfw);
+        const uint32_t nl = fastdiv_tile(i, a.divLfw);
         return nl * (uint32_t)rowW + (uint32_t)((M - 1) * NW) + (i - nl * per);
       };
       if (((g0 | nwords) & 3u) == 0u) {
@@ -1191,364 +1199,6 @@ __device__ void gibbs_body(const GibbsArgs& a) {
     if ((threadIdx.x & 63) == 0) a.ones[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = (uint32_t)tot;
   }
   if constexpr (STATS) stats_mfma_finish<C, false>(a.sg, smem, 0, sacc, vcount);
-}
-
-// ---------------------------------------------------------------------------
-// Gradient statistics (convRBM.py:327-371 and the closed form of :440-451):
-// raw sums over (n,s) of
-//   P[k,s] * onehot[a,s+j]          -> vh   (per strand)
-//   P(1-P)[k,s] * onehot[a,s+j]     -> sw   (forward strand, if want_sparsity)
-//   P[k,s], P(1-P)[k,s]             -> h, sb
-//   onehot[a,p]                     -> v    (letter counts)
-// Because the visible layer is one-hot, VH[k,a,j] = sum over the visible
-// positions p whose letter is a of P[k, p-j]: exactly one add per (k,j,p)
-// instead of four masked FMAs.  A tile (whole chains, or one segment of a long
-// chain) is processed in two phases:
-//  A  every thread computes P (and P') of one hidden position and parks the
-//     row in LDS (zero rows pad both ends of every chain segment);
-//  B  each wave owns one pass (vh, vh' or sw) for its share of the tile's
-//     visible positions.  It buckets them by letter (ballot + popcount:
-//     deterministic order); then the 16 lanes of lane-group g walk the
-//     positions of letter g together, lane j adding parked row p-j into its
-//     K registers: the lane that owns (a, j) accumulates VH[:, a, j] directly,
-//     the 16 rows read by a group are consecutive (no LDS bank conflicts) and
-//     no cross-lane reduction is ever needed.
-// At the end the waves of a block are combined through LDS in a fixed order and
-// the block writes one partial row.  Small models (Cfg::STATS_MERGE) fold the
-// sparsity statistic into the forward pass: it also accumulates sum P^2 and
-// sw = sum P - sum P^2.
-// ---------------------------------------------------------------------------
-struct StatsArgs {
-  const float* tables;
-  const uint32_t* letters;
-  int32_t n, L, Lh, LW;
-  int32_t S;            // chains per tile (1 when a chain is split into segments)
-  int32_t LS;           // hidden positions per segment (= Lh when nseg == 1)
-  int32_t nseg;         // segments per chain
-  int32_t Rrow;         // parked rows per chain segment = LS + 2(M-1)
-  int32_t LWt;          // letter words staged per chain: covers LS + M - 1 positions from any 16-aligned start, + 2
-  int32_t PB, parts;    // passes per block, position parts per pass (PB*parts == waves per block)
-  int32_t npasses;      // 1 + DS + want_sparsity
-  int32_t want_sparsity;
-  FastDiv divLS, divLvis, divL;   // / LS, / (LS+M-1), / L
-  int32_t row, off_vh0, off_vh1, off_h0, off_h1, off_sw, off_sb, off_v;
-  float* partials;      // [gridDim.x][row]; columns nobody writes are never read (reduce_partials_kernel)
-  int32_t debug;        // profiling only: bit 0 skips phase B, bit 1 skips the phase-A arithmetic
-};
-
-template <class C>
-__device__ void stats_body(const StatsArgs& a) {
-  constexpr int KP = C::KP, K = C::K, M = C::M;
-  constexpr int JCH = (M + 15) / 16;                     // filter columns per lane: j = 16*c + (lane & 15)
-  constexpr int CH = C::STATS_CH;                        // positions bucketed at a time per wave
-  constexpr int UNR = C::STATS_UNR;                      // list entries consumed per iteration
-  HIP_DYNAMIC_SHARED(float, smem);
-  const int nthr = blockDim.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = nthr >> 6;
-  float* Tf = smem;
-  float* Tr = Tf + C::TAB;
-  // parked rows [S*Rrow][KP] followed by M all-zero rows (target of the list padding)
-  const int nrows = a.S * a.Rrow + M;
-  float* Pb0 = Tr + (C::DS ? C::TAB : 0);
-  float* Pb1 = Pb0 + (size_t)nrows * KP;                        // (ds)
-  unsigned short* lists = reinterpret_cast<unsigned short*>(Pb1 + (C::DS ? (size_t)nrows * KP : 0));
-  unsigned short* mylist = lists + (size_t)wave * 4 * CH;       // [4][CH] per wave: parked-row index of each position
-  float* xch = reinterpret_cast<float*>(lists + (size_t)nwaves * 4 * CH);   // [nwaves][3*KP+4]
-  uint32_t* lw = reinterpret_cast<uint32_t*>(xch + (size_t)nwaves * (3 * KP + 4));   // [S][LWt] letters of the tile
-
-  if (!(a.debug & 16)) {
-    copy_tables<C::TAB>(Tf, a.tables + C::OFF_TF);
-    if (C::DS) copy_tables<C::TAB>(Tr, a.tables + C::OFF_TR);
-  }
-  // pad rows stay zero for the whole kernel
-  if (!(a.debug & 32))
-  for (int i = threadIdx.x; i < nrows * KP; i += nthr) {
-    Pb0[i] = 0.f;
-    if (C::DS) Pb1[i] = 0.f;
-  }
-  const unsigned short dummy_row = (unsigned short)(a.S * a.Rrow + M - 1);   // rows dummy_row - j are all zero
-
-  // this wave's pass and its share of the visible positions
-  const int pass = blockIdx.y * a.PB + (wave % a.PB);
-  const int part = wave / a.PB;
-  const bool active = pass < a.npasses;
-  // passes: 0 = vh (forward strand; with sum P^2 when merged), 1 = vh' (ds only),
-  // last = sw (forward, P(1-P)) when not merged
-  constexpr bool MERGE = C::STATS_MERGE;
-  const int t_kind = (!MERGE && active && a.want_sparsity && pass == C::DS + 1) ? 1 : 0;
-  const int t_strand = (active && !t_kind && pass == 1) ? 1 : 0;
-  const bool with_sq = MERGE && active && a.want_sparsity && pass == 0;
-  float acc[JCH][KP];
-  float sq[MERGE ? JCH : 1][MERGE ? KP : 1];
-#pragma unroll
-  for (int c = 0; c < JCH; ++c)
-#pragma unroll
-    for (int q = 0; q < KP; ++q) {
-      acc[c][q] = 0.f;
-      if (MERGE) sq[c][q] = 0.f;
-    }
-
-  const bool owner = blockIdx.y == 0;   // h / sb / letter counts are accumulated once
-  // (the H and sparsity-bias sums are not accumulated per thread: every hidden position
-  // pairs with exactly one letter at j = 0, so sum_s P[k,s] = sum_a VH[k,a,0] -- the block
-  // derives them from its combined vh / sw sums at the end)
-  float vc0 = 0.f, vc1 = 0.f, vc2 = 0.f, vc3 = 0.f;
-
-  // letter class of this lane and its filter column.  The 16 lanes of a class are one of the
-  // four lane groups the LDS serves a ds_read_b128 in ({0-3,12-15,20-27}, {4-11,16-19,28-31}
-  // and the same + 32): the 16 consecutive parked rows they read then fall on 16 different
-  // 16-byte bank slots (row stride 12 dwords: slot = 3*row mod 16 is a bijection) and the read
-  // is conflict-free.  With contiguous 16-lane classes every hardware group mixed two classes
-  // at unrelated offsets and almost always took two cycles.
-  int grp, lj;
-  {
-    const int l5 = lane & 31;
-    const bool second = (l5 >= 4 && l5 < 12) || (l5 >= 16 && l5 < 20) || l5 >= 28;
-    grp = 2 * (lane >> 5) + (second ? 1 : 0);
-    lj = l5 < 4 ? l5 : l5 < 12 ? l5 - 4 : l5 < 20 ? l5 - 8 : l5 < 28 ? l5 - 12 : l5 - 16;
-  }
-  const int ngroups = (a.n + a.S - 1) / a.S;
-  const int ntiles = ngroups * a.nseg;
-  // software prefetch of a tile's letter words (global memory latency is otherwise
-  // exposed once per tile: a block has nothing else to do until they arrive)
-  constexpr int PRE = 4;
-  uint32_t pre[PRE];
-  auto fetch_letters = [&](int tile) {
-#pragma unroll
-    for (int u = 0; u < PRE; ++u) pre[u] = 0u;
-    if (tile < ntiles) {
-      const int cg = tile / a.nseg, seg = tile - cg * a.nseg;
-      const int n0 = cg * a.S;
-      const int ns = min(a.S, a.n - n0);
-      const int w0 = (seg * a.LS) >> 4;
-#pragma unroll
-      for (int u = 0; u < PRE; ++u) {
-        const int i = threadIdx.x + u * nthr;
-        if (i < ns * a.LWt) {
-          const int nl = i / a.LWt, w = i - nl * a.LWt;
-          if (w0 + w < a.LW) pre[u] = a.letters[(size_t)(n0 + nl) * a.LW + w0 + w];
-        }
-      }
-    }
-  };
-  fetch_letters(blockIdx.x);
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int cg = tile / a.nseg, seg = tile - cg * a.nseg;
-    const int n0 = cg * a.S;
-    const int ns = min(a.S, a.n - n0);
-    const int s0 = seg * a.LS;
-    const int len = min(a.LS, a.Lh - s0);          // hidden positions of this segment
-    const int lvis = len + M - 1;                  // visible positions that touch it
-    const int w0 = s0 >> 4;                        // first letter word of the segment's window
-    const int pofs = s0 - 16 * w0;                 // position of s0 inside the staged window
-    __syncthreads();                               // previous tile fully consumed / tables + zero rows ready
-    // letters of the tile -> LDS (every later letter access is an LDS read); the first
-    // PRE words per thread were fetched while the previous tile was being processed
-#pragma unroll
-    for (int u = 0; u < PRE; ++u) {
-      const int i = threadIdx.x + u * nthr;
-      if (i < ns * a.LWt) lw[i] = pre[u];
-    }
-    for (int i = threadIdx.x + PRE * nthr; i < ns * a.LWt; i += nthr) {
-      const int nl = i / a.LWt, w = i - nl * a.LWt;
-      lw[i] = (w0 + w < a.LW) ? a.letters[(size_t)(n0 + nl) * a.LW + w0 + w] : 0u;
-    }
-    __syncthreads();
-    fetch_letters(tile + gridDim.x);               // in flight during phases A and B
-    // ---- phase A: park P rows (zero beyond the segment / beyond the last chain) ----
-    for (uint32_t i = threadIdx.x; i < (uint32_t)(a.S * a.LS); i += nthr) {
-      const uint32_t nl = fastdiv(i, a.divLS);
-      const int sr = (int)(i - nl * (uint32_t)a.LS);
-      float* p0 = Pb0 + ((size_t)nl * a.Rrow + (M - 1) + sr) * KP;
-      float* p1 = Pb1 + ((size_t)nl * a.Rrow + (M - 1) + sr) * KP;
-      if ((int)nl < ns && sr < len && !(a.debug & 2)) {
-        const uint64_t win = letter_window<M>(lw + (size_t)nl * a.LWt, pofs + sr);
-        float z[KP];
-        conv_gather<C>(Tf, win, z);
-#pragma unroll
-        for (int q = 0; q < KP; ++q) z[q] = sigmoid_z(z[q]);
-#pragma unroll
-        for (int q = 0; q < KP / 4; ++q)
-          reinterpret_cast<float4*>(p0)[q] = make_float4(z[4 * q], z[4 * q + 1], z[4 * q + 2], z[4 * q + 3]);
-        if (C::DS) {
-          conv_gather<C>(Tr, win, z);
-#pragma unroll
-          for (int q = 0; q < KP; ++q) z[q] = sigmoid_z(z[q]);
-#pragma unroll
-          for (int q = 0; q < KP / 4; ++q)
-            reinterpret_cast<float4*>(p1)[q] = make_float4(z[4 * q], z[4 * q + 1], z[4 * q + 2], z[4 * q + 3]);
-        }
-      } else {
-#pragma unroll
-        for (int q = 0; q < KP / 4; ++q) {
-          reinterpret_cast<float4*>(p0)[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (C::DS) reinterpret_cast<float4*>(p1)[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-      }
-    }
-    // letter counts: every visible position exactly once (segment 0 of each chain), 16
-    // positions per word with four popcounts on the low / high bit planes
-    if (owner && seg == 0) {
-      const int nw16 = (a.L + 15) >> 4;                         // letter words that hold positions
-      for (int i = threadIdx.x; i < ns * nw16; i += nthr) {
-        const int nl = i / nw16, w = i - nl * nw16;
-        // whole rows are staged when a chain is one segment; otherwise read the row from global memory
-        const uint32_t word = a.nseg == 1 ? lw[(size_t)nl * a.LWt + w] : a.letters[(size_t)(n0 + nl) * a.LW + w];
-        const int valid = min(16, a.L - 16 * w);                // positions of this word inside the sequence
-        const uint32_t plane = valid >= 16 ? 0x55555555u : ((1u << (2 * valid)) - 1u) & 0x55555555u;
-        const uint32_t lo = word & plane, hi = (word >> 1) & plane;
-        vc0 += (float)__popc(plane & ~lo & ~hi); vc1 += (float)__popc(lo & ~hi);
-        vc2 += (float)__popc(hi & ~lo);          vc3 += (float)__popc(lo & hi);
-      }
-    }
-    __syncthreads();
-    // ---- phase B ----
-    if (active && !(a.debug & 1)) {
-      const float* Pb = t_strand ? Pb1 : Pb0;
-      const int V = ns * lvis;                                   // flattened visible positions of the tile
-      const int per = (V + a.parts - 1) / a.parts;
-      const int v_lo = part * per, v_hi = min(V, v_lo + per);
-      for (int c0 = v_lo; c0 < v_hi; c0 += CH) {
-        const int c1 = min(v_hi, c0 + CH);
-        // bucket positions c0..c1 by letter; rank = order of appearance; the entry
-        // is the parked-row index of the hidden position that pairs with j = 0
-        int cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0;
-        for (int base = c0; base < c1; base += 64) {
-          const int v = base + lane;
-          const bool valid = v < c1;
-          uint32_t l = 0u, rowidx = 0u;
-          if (valid) {
-            const uint32_t nl = fastdiv((uint32_t)v, a.divLvis);
-            const int pr = v - (int)nl * lvis;
-            const int p = pofs + pr;
-            l = (lw[(size_t)nl * a.LWt + (p >> 4)] >> (2 * (p & 15))) & 3u;
-            rowidx = nl * (uint32_t)a.Rrow + (uint32_t)(M - 1 + pr);
-          }
-          const unsigned long long b0 = __ballot(valid && l == 0u), b1 = __ballot(valid && l == 1u);
-          const unsigned long long b2 = __ballot(valid && l == 2u), b3 = __ballot(valid && l == 3u);
-          const unsigned long long below = (1ull << lane) - 1ull;
-          if (valid) {
-            const unsigned long long mine = l == 0u ? b0 : l == 1u ? b1 : l == 2u ? b2 : b3;
-            const int basecnt = l == 0u ? cnt0 : l == 1u ? cnt1 : l == 2u ? cnt2 : cnt3;
-            mylist[l * CH + basecnt + __popcll(mine & below)] = (unsigned short)rowidx;
-          }
-          cnt0 += __popcll(b0); cnt1 += __popcll(b1); cnt2 += __popcll(b2); cnt3 += __popcll(b3);
-        }
-        // pad every list to a common multiple of UNR with the all-zero row: the walk
-        // below then needs no per-entry guard and keeps UNR rows in flight per lane
-        const int maxcnt = max(max(cnt0, cnt1), max(cnt2, cnt3));
-        const int padded = (maxcnt + UNR - 1) / UNR * UNR;
-        {
-          const int mycnt = grp == 0 ? cnt0 : grp == 1 ? cnt1 : grp == 2 ? cnt2 : cnt3;
-          for (int e = mycnt + lj; e < padded; e += 16) mylist[grp * CH + e] = dummy_row;
-        }
-        // the lists are private to this wave: LDS operations of one wave complete in
-        // order, so no workgroup barrier is needed between filling and reading them
-        __builtin_amdgcn_wave_barrier();
-        auto consume = [&](auto KIND) {
-          constexpr bool SPARSITY = decltype(KIND)::value == 1;   // P(1-P) only
-          constexpr bool SQUARES = decltype(KIND)::value == 2;    // P and P^2
-          for (int e = 0; e < padded; e += UNR) {
-            int r[UNR];
-#pragma unroll
-            for (int u = 0; u < UNR; ++u) r[u] = (int)mylist[grp * CH + e + u];   // same entries for the 16 lanes of the group
-#pragma unroll
-            for (int c = 0; c < JCH; ++c) {
-              const int j = 16 * c + lj;
-              if (j < M) {
-                float4 t[UNR][KP / 4];
-#pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                  const float4* r4 = reinterpret_cast<const float4*>(Pb + (size_t)(r[u] - j) * KP);
-#pragma unroll
-                  for (int q = 0; q < KP / 4; ++q) t[u][q] = r4[q];
-                }
-#pragma unroll
-                for (int u = 0; u < UNR; ++u)
-#pragma unroll
-                  for (int q = 0; q < KP / 4; ++q) {
-                    float4 v = t[u][q];
-                    if (SPARSITY) {
-                      v.x = v.x * (1.f - v.x); v.y = v.y * (1.f - v.y); v.z = v.z * (1.f - v.z); v.w = v.w * (1.f - v.w);
-                    }
-                    acc[c][4 * q] += v.x; acc[c][4 * q + 1] += v.y; acc[c][4 * q + 2] += v.z; acc[c][4 * q + 3] += v.w;
-                    if (SQUARES) {
-                      constexpr int cc = MERGE ? 1 : 0;   // sq is a dummy [1][1] when not merged
-                      sq[c * cc][(4 * q) * cc] = fmaf(v.x, v.x, sq[c * cc][(4 * q) * cc]);
-                      sq[c * cc][(4 * q + 1) * cc] = fmaf(v.y, v.y, sq[c * cc][(4 * q + 1) * cc]);
-                      sq[c * cc][(4 * q + 2) * cc] = fmaf(v.z, v.z, sq[c * cc][(4 * q + 2) * cc]);
-                      sq[c * cc][(4 * q + 3) * cc] = fmaf(v.w, v.w, sq[c * cc][(4 * q + 3) * cc]);
-                    }
-                  }
-              }
-            }
-          }
-        };
-        if (t_kind) consume(IC<1>{});
-        else if (MERGE && with_sq) consume(IC<2>{});
-        else consume(IC<0>{});
-        __builtin_amdgcn_wave_barrier();   // lists are rewritten by the next chunk
-      }
-    }
-  }
-
-  // lane (grp, lj) holds the sums for letter a = grp and filter columns j = 16c + lj.
-  // Combine the waves of the block through LDS (tables and parked rows are dead
-  // now), part by part in a fixed order: buf[0] = vh, buf[1] = vh', buf[2] = sw or sum P^2.
-  constexpr int KAM = K * 4 * M;
-  float* out = a.partials + (size_t)blockIdx.x * a.row;
-  __syncthreads();
-  if (!(a.debug & 4)) {
-    float* buf = smem;
-    for (int p = 0; p < a.parts; ++p) {
-      if (active && part == p) {
-        float* dst = buf + (t_kind ? 2 : t_strand) * KAM;
-#pragma unroll
-        for (int c = 0; c < JCH; ++c) {
-          const int j = 16 * c + lj;
-          if (j < M) {
-#pragma unroll
-            for (int q = 0; q < K; ++q) {
-              const int idx = (q * 4 + grp) * M + j;
-              dst[idx] = p == 0 ? acc[c][q] : dst[idx] + acc[c][q];
-              if (MERGE) {
-                if (with_sq) buf[2 * KAM + idx] = p == 0 ? sq[c][q] : buf[2 * KAM + idx] + sq[c][q];
-              }
-            }
-          }
-        }
-      }
-      __syncthreads();
-    }
-    for (int i = threadIdx.x; i < KAM; i += nthr) {
-      out[a.off_vh0 + i] = buf[i];
-      if (C::DS) out[a.off_vh1 + i] = buf[KAM + i];
-      if (a.want_sparsity) out[a.off_sw + i] = MERGE ? buf[i] - buf[2 * KAM + i] : buf[2 * KAM + i];
-    }
-    // H and sparsity-bias sums of the block: the four letters of filter column 0
-    for (int k = threadIdx.x; k < K; k += nthr) {
-      auto col0 = [&](const float* t) { return (t[(k * 4) * M] + t[(k * 4 + 1) * M]) + (t[(k * 4 + 2) * M] + t[(k * 4 + 3) * M]); };
-      const float hsum = col0(buf);
-      out[a.off_h0 + k] = hsum;
-      if (C::DS) out[a.off_h1 + k] = col0(buf + KAM);
-      if (a.want_sparsity) out[a.off_sb + k] = MERGE ? hsum - col0(buf + 2 * KAM) : col0(buf + 2 * KAM);
-    }
-    __syncthreads();   // xch (below) lives in the same LDS
-  }
-  if (owner && !(a.debug & 8)) {
-    // letter counts: per-thread sums -> wave (DPP) -> block (one LDS exchange), fixed order
-    {
-      const float c0v = wave_sum(vc0), c1v = wave_sum(vc1), c2v = wave_sum(vc2), c3v = wave_sum(vc3);
-      if (lane == 0) {
-        xch[wave * 4] = c0v; xch[wave * 4 + 1] = c1v; xch[wave * 4 + 2] = c2v; xch[wave * 4 + 3] = c3v;
-      }
-    }
-    __syncthreads();
-    if (threadIdx.x < 4) {
-      float t = 0.f;
-      for (int w = 0; w < nwaves; ++w) t += xch[w * 4 + threadIdx.x];
-      out[a.off_v + threadIdx.x] = t;
-    }
-  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1718,16 +1368,17 @@ __device__ void hit_summary_body(const HitArgs& a) {
 // ---------------------------------------------------------------------------
 struct UpdateArgs {
   const float* sums;
-  float* W; float* b; float* c;
-  float* vW; float* vb; float* vc;
+  const float *W, *b, *c, *vW, *vb, *vc;      // parameters and velocities before the step
+  float *oW, *ob, *oc, *ovW, *ovb, *ovc;      // ... after it (the same buffers when a single block updates in place)
   int32_t K, M, ds;
   int32_t L_data, Lf;
   int32_t data_off, n_d, model_off, n_m;   // offsets into sums
   float lr, momentum, rho, lambda_rate;
 };
 
-// `nw`: when not null, the new W, b, c are also left there ([KAM][K][4], LDS of the caller)
-__device__ __forceinline__ void apply_update_body(const UpdateArgs& a, float* nw) {
+// `nw`: when not null, the new W, b, c are also left there ([KAM][K][4], LDS of the caller);
+// `store`: whether this block writes the new parameters and velocities to global memory
+__device__ __forceinline__ void apply_update_body(const UpdateArgs& a, float* nw, bool store) {
   const int K = a.K, M = a.M, KAM = K * 4 * M;
   const float n_d = a.sums[a.n_d], n_m = a.sums[a.n_m];
   const float cnt_d = n_d * (float)(a.L_data - M + 1);
@@ -1750,9 +1401,8 @@ __device__ __forceinline__ void apply_update_body(const UpdateArgs& a, float* nw
     const float g = (q / p - (1.f - q) / (1.f - p)) / (float)K;
     const float reg = -g * d_sw[idx] / cnt_d;
     const float v = a.momentum * a.vW[idx] + a.lr * (gd - gm - a.lambda_rate * reg);
-    a.vW[idx] = v;
     const float w = a.W[idx] + v;
-    a.W[idx] = w;
+    if (store) { a.ovW[idx] = v; a.oW[idx] = w; }
     if (nw) nw[idx] = w;
   }
   for (int k = threadIdx.x; k < K; k += blockDim.x) {
@@ -1765,9 +1415,8 @@ __device__ __forceinline__ void apply_update_body(const UpdateArgs& a, float* nw
     const float g = (q / p - (1.f - q) / (1.f - p)) / (float)K;
     const float reg = -g * d_sb[k] / cnt_d;
     const float v = a.momentum * a.vb[k] + a.lr * (gd - gm - a.lambda_rate * reg);
-    a.vb[k] = v;
     const float bn = a.b[k] + v;
-    a.b[k] = bn;
+    if (store) { a.ovb[k] = v; a.ob[k] = bn; }
     if (nw) nw[KAM + k] = bn;
   }
   if (threadIdx.x < 4) {
@@ -1776,16 +1425,18 @@ __device__ __forceinline__ void apply_update_body(const UpdateArgs& a, float* nw
     const float gd = d_v[al] / nd + d_v[3 - al] / nd;     // a += a[::-1]  (:345)
     const float gm = m_v[al] / nm + m_v[3 - al] / nm;
     const float v = a.momentum * a.vc[al] + a.lr * (gd - gm);
-    a.vc[al] = v;
     const float cn = a.c[al] + v;
-    a.c[al] = cn;
+    if (store) { a.ovc[al] = v; a.oc[al] = cn; }
     if (nw) nw[KAM + K + al] = cn;
   }
 }
 
-// The end of a training step in one launch (one block): the update, then the LDS table images of
-// the new parameters for the next step's kernels.  The new W, b, c travel from the update to the
-// table build through LDS (the block's own global stores are not re-read).
+// The end of a training step in one launch: the update, then the LDS table images of the new
+// parameters for the next step's kernels.  Every block of the grid forms the complete update for
+// itself (a few hundred numbers from the packed sums) into its LDS and builds its share of the
+// tables from there; block 0 also stores the new parameters and velocities -- into the OTHER set of
+// buffers (the host swaps the two sets after the launch), because the remaining blocks may still be
+// reading the old ones.
 struct UpdateTablesArgs {
   UpdateArgs u;
   float* tables;     // Cfg::TABLES_ALL floats
@@ -1795,7 +1446,7 @@ template <class C>
 __device__ void update_tables_body(const UpdateTablesArgs& a) {
   HIP_DYNAMIC_SHARED(float, smem);
   constexpr int KAM = C::K * 4 * C::M;
-  apply_update_body(a.u, smem);
+  apply_update_body(a.u, smem, blockIdx.x == 0);
   __syncthreads();
   TablesArgs t;
   t.W = smem; t.b = smem + KAM; t.c = smem + KAM + C::K; t.out = a.tables;
@@ -1807,15 +1458,16 @@ __device__ void update_tables_body(const UpdateTablesArgs& a) {
 // Model-independent kernels, compiled ahead of time into libcrbm_hip.so.
 // ===========================================================================
 
-// plain streaming copy, 16 bytes per lane (crbm_copy_bandwidth)
+// plain streaming copy, 16 bytes per lane (crbm_copy_bandwidth): a block moves one contiguous 16 KB
+// chunk, four loads in flight per lane
 __global__ void __launch_bounds__(256) copy_float4_kernel(const float4* src, float4* dst, size_t n4) {
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  for (; i + 3 * stride < n4; i += 4 * stride) {      // four loads in flight per lane
-    const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-    dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+  const size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x;
+  if (base + 768 < n4) {
+    const float4 a = src[base], b = src[base + 256], c = src[base + 512], d = src[base + 768];
+    dst[base] = a; dst[base + 256] = b; dst[base + 512] = c; dst[base + 768] = d;
+  } else {
+    for (size_t i = base; i < n4 && i < base + 1024; i += 256) dst[i] = src[i];
   }
-  for (; i < n4; i += stride) dst[i] = src[i];
 }
 
 // one-hot fp32 (n,1,4,L) -> packed letters [n][LW]; flags[0] |= 1 on a column
@@ -2087,7 +1739,7 @@ __global__ void __launch_bounds__(1024) reduce_partials_pair_kernel(ReducePair p
   reduce_partials_body(p.half[blockIdx.y]);
 }
 
-__global__ void apply_update_kernel(UpdateArgs a) { apply_update_body(a, nullptr); }
+__global__ void apply_update_kernel(UpdateArgs a) { apply_update_body(a, nullptr, true); }   // one block, in place
 #endif  // CRBM_DEFINE_MISC_KERNELS
 
 }  // namespace crbm

@@ -85,28 +85,6 @@ struct Cfg {
   static constexpr int SP_WSR = SP_WS + WS;
   static constexpr int SP_C = SP_WS + WS * (1 + DS);
   static constexpr int SP_TABLES = SP_C + 4;
-  static constexpr int STATS_CH = 256;                    // positions a statistics wave buckets at a time
-#ifndef CRBM_STATS_UNR
-#define CRBM_STATS_UNR 4
-#endif
-#ifndef CRBM_STATS_UNR_BIG
-#define CRBM_STATS_UNR_BIG 2
-#endif
-  static constexpr int STATS_UNR = (KP <= 16) ? CRBM_STATS_UNR : CRBM_STATS_UNR_BIG;   // parked rows in flight per lane
-  // small models: the forward vh pass also accumulates sum P^2 (sw = vh - that), so the
-  // sparsity statistic costs no second walk over the parked rows; large models keep a
-  // separate pass (the second accumulator set would not fit the register file)
-  static constexpr bool STATS_MERGE = KP * cdiv(M, 16) <= 32;
-  // waves per block of the statistics kernel: models whose tables leave room for only one
-  // block per CU run 8 waves in it (two per SIMD) instead of 4
-  static constexpr long STATS_FIXED4 = (long)(1 + DS) * (TAB + M * KP) * 4 + 4L * 4 * STATS_CH * 2 + 4L * (3 * KP + 4) * 4;
-#ifndef CRBM_STATS_WAVES_BIG
-#define CRBM_STATS_WAVES_BIG 8
-#endif
-#ifndef CRBM_STATS_WAVES_SMALL
-#define CRBM_STATS_WAVES_SMALL 4
-#endif
-  static constexpr int STATS_WAVES = (STATS_FIXED4 + 24 * 1024 > 78 * 1024) ? CRBM_STATS_WAVES_BIG : CRBM_STATS_WAVES_SMALL;
   // MFMA statistics (stats_mfma_body, fused tail of gibbs_body): one v_mfma_f32_16x16x32_f16
   // contracts 32 hidden positions; its 16 output rows are 16 filter columns of one letter, its
   // 16 output columns are 16 motifs of one column kind (P, P' of the rc strand, P(1-P))
@@ -127,7 +105,7 @@ struct ModelShape {
   int K, M, DS, G, NT, JT;
   int NQ, KP, NW, NG, ROWS, TAB, NCH, DENSE, TV, WS, NGRP;
   int OFF_TF, OFF_TR, OFF_TV, OFF_TVR, OFF_C, TABLES, OFF_WS, END2, SP_TABLES, TABLES_ALL;
-  int HIT_NI, STATS_MERGE, STATS_WAVES, FUSE_STATS;
+  int HIT_NI, FUSE_STATS;
 };
 inline ModelShape model_shape(int K, int M, int DS, int G) {
   ModelShape s;
@@ -147,11 +125,6 @@ inline ModelShape model_shape(int K, int M, int DS, int G) {
   s.SP_TABLES = s.TAB * (1 + DS) + s.WS * (1 + DS) + 4;
   s.OFF_TR = DS ? s.TAB : s.END2; s.TABLES_ALL = DS ? s.END2 : s.END2 + s.TAB;
   s.HIT_NI = (48 / s.KP) < 1 ? 1 : ((48 / s.KP) > 4 ? 4 : (48 / s.KP));
-  s.STATS_MERGE = s.KP * cdiv(M, 16) <= 32;
-  {
-    const long fixed4 = (long)(1 + DS) * (s.TAB + M * s.KP) * 4 + 4L * 4 * 256 * 2 + 4L * (3 * s.KP + 4) * 4;
-    s.STATS_WAVES = (fixed4 + 24 * 1024 > 78 * 1024) ? 8 : 4;
-  }
   return s;
 }
 
@@ -187,72 +160,6 @@ inline GibbsLayout gibbs_layout(const ModelShape& ms, int Lf, int S, bool sparse
   return g;
 }
 
-// ---- statistics kernel ----------------------------------------------------------
-// A pass = one accumulator class: vh, vh' (ds), sw (sparsity).  One wave owns one
-// pass for one share ("part") of the visible positions of every tile.
-struct StatsLayout {
-  int npasses, PB, parts, threads, grid_y;
-  int S, LS, nseg, Rrow, LWt;  // chains per tile, hidden positions per segment, segments per chain, parked rows, staged letter words
-  int row;                // floats per partial row: 3*KAM + 3K + 4
-  int off_vh[2], off_h[2], off_sw, off_sb, off_v;
-  int lds_bytes;
-};
-inline StatsLayout stats_layout(const ModelShape& ms, int want_sparsity, int Lh, int n, int lds_budget, int force_S = 0) {
-  StatsLayout s;
-  const int K = ms.K, M = ms.M, KAM = K * 4 * M;
-  s.npasses = 1 + ms.DS + (ms.STATS_MERGE ? 0 : want_sparsity);
-  const int waves = ms.STATS_WAVES;
-  s.threads = 64 * waves;
-  s.PB = s.npasses <= 1 ? 1 : (s.npasses == 2 ? 2 : 4);
-  s.parts = waves / s.PB;
-  s.grid_y = 1;
-  const int CH = 256;   // Cfg::STATS_CH
-  long fixed = (long)(1 + ms.DS) * (ms.TAB + M * ms.KP) * 4 + (long)waves * 4 * CH * 2 + (long)waves * (3 * ms.KP + 4) * 4;
-  fixed += 16L * 4 * ((Lh + M - 1 + 15 + 15) / 16 + 3);      // staged letters for up to 16 chains (upper bound)
-  const long per_row = (long)(1 + ms.DS) * ms.KP * 4;
-  if (lds_budget <= 0) {
-    // auto: as many blocks per CU (3, 2, 1) as still leave a tile >= 256 hidden positions
-    // (or a whole chain): short segments idle most of the block in phase A and pay the
-    // 2(M-1) halo rows over and over
-    const long want_rows = (Lh < 256 ? Lh : 256) + 2 * (M - 1);
-    lds_budget = 156 * 1024;
-    for (int b = 3; b >= 2; --b)
-      if ((156 * 1024 / b - fixed) / per_row >= want_rows) { lds_budget = 156 * 1024 / b; break; }
-  }
-  if (lds_budget < fixed + 24 * 1024) lds_budget = (int)(fixed + 24 * 1024);   // big tables: trade occupancy for segment length
-  if (lds_budget > 156 * 1024) lds_budget = 156 * 1024;
-  long rows = (lds_budget - fixed) / per_row;                 // parked rows that fit
-  if (rows < 2 * (M - 1) + 8) rows = 2 * (M - 1) + 8;
-  if (rows > 65000) rows = 65000;                             // 16-bit parked-row indices in the lists
-  if (rows >= Lh + 2 * (M - 1)) {                             // whole chains
-    s.LS = Lh; s.nseg = 1;
-    s.Rrow = Lh + 2 * (M - 1);
-    s.S = (int)(rows / s.Rrow);
-    if (force_S > 0 && force_S < s.S) s.S = force_S;
-    if (s.S > 16) s.S = 16;
-    if (s.S > n) s.S = n > 0 ? n : 1;
-    if (s.S < 1) s.S = 1;
-  } else {                                                    // one segment of one chain
-    s.S = 1;
-    s.LS = (int)rows - 2 * (M - 1);
-    s.nseg = (Lh + s.LS - 1) / s.LS;
-    s.LS = (Lh + s.nseg - 1) / s.nseg;                        // balance the segments
-    s.Rrow = s.LS + 2 * (M - 1);
-  }
-  s.LWt = (s.LS + M - 1 + 15 + 15) / 16 + 3;
-  s.off_vh[0] = 0;
-  s.off_vh[1] = KAM;
-  s.off_h[0] = 2 * KAM;
-  s.off_h[1] = 2 * KAM + K;
-  s.off_sw = 2 * KAM + 2 * K;
-  s.off_sb = 3 * KAM + 2 * K;
-  s.off_v = 3 * KAM + 3 * K;
-  s.row = 3 * KAM + 3 * K + 4;
-  s.lds_bytes = (int)(fixed + (long)s.S * s.Rrow * per_row);
-  if (s.lds_bytes < 3 * KAM * 4) s.lds_bytes = 3 * KAM * 4;   // the block's waves are combined through LDS at the end
-  return s;
-}
-
 // ---- MFMA statistics ----------------------------------------------------------------
 // Hidden positions are handled in groups of 32 (one MFMA step).  A chain of Lh hidden
 // positions is GPC = ceil(Lh / 32) groups, the tail of the last one padded with P = 0.
@@ -273,9 +180,12 @@ inline StatsLayout stats_layout(const ModelShape& ms, int want_sparsity, int Lh,
 //                    (stand-alone kernel, 4 KB); the Gibbs kernel, short of LDS, uses the nibble form
 //                    (16 entries of four f16, two reads per fragment, 128 bytes)
 constexpr int STATS_RS = 68;                 // Pt row stride in floats
-constexpr int stats_ntw(int NT, int JT, int kinds) {        // motif tiles per wave
+#ifndef CRBM_STATS_MAX_TILES
+#define CRBM_STATS_MAX_TILES 32     // accumulator tiles (4 registers each) a wave may hold
+#endif
+constexpr int stats_ntw(int NT, int JT, int kinds, int max_tiles = CRBM_STATS_MAX_TILES) {   // motif tiles per wave
   int ntw = NT;
-  while (ntw > 1 && (4 * JT * kinds * ntw > 32 || NT % ntw != 0)) --ntw;
+  while (ntw > 1 && (4 * JT * kinds * ntw > max_tiles || NT % ntw != 0)) --ntw;
   return ntw;
 }
 // block size: 8 waves, rounded down to whole sets of roles
@@ -287,16 +197,16 @@ struct StatsMfmaLayout {
   int off_slices;                       // first slice (after the LUT), floats
   int region_floats;                    // LUT + all slices
   int combine_bytes;                    // end-of-kernel combine buffer, from the LDS base (everything is dead by then)
-  int row, off_vh[2], off_h[2], off_sw, off_sb, off_v;   // partial-row layout (same as StatsLayout)
+  int row, off_vh[2], off_h[2], off_sw, off_sb, off_v;   // partial row: [vh KAM][vh' KAM][h K][h' K][sw KAM][sb K][v 4]
 };
 // threads = 0: as many waves per role as the LDS (160 KiB minus `other_lds_bytes`: gather tables, or the
 // chain image of the Gibbs kernel) holds, at most 8 waves in all
 inline StatsMfmaLayout stats_mfma_layout(const ModelShape& ms, int want_sparsity, int Lh, int threads = 0,
-                                         int other_lds_bytes = 0, bool byte_lut = true) {
+                                         int other_lds_bytes = 0, bool byte_lut = true, int max_tiles = CRBM_STATS_MAX_TILES) {
   StatsMfmaLayout s;
   const int K = ms.K, M = ms.M, KAM = K * 4 * M;
   s.kinds = 1 + ms.DS + (want_sparsity ? 1 : 0);
-  s.NTW = stats_ntw(ms.NT, ms.JT, s.kinds);
+  s.NTW = stats_ntw(ms.NT, ms.JT, s.kinds, max_tiles);
   s.NR = ms.NT / s.NTW;
   s.KW = 16 * s.NTW < K ? 16 * s.NTW : K;
   s.rows = s.kinds * s.KW + 1;

@@ -162,63 +162,6 @@ int emu_gibbs(int id, const float* tables, uint32_t* hm, uint32_t* hmp, uint32_t
   return lws;
 }
 
-// statistics of one half + deterministic reduction into `sums` (row floats + n)
-int emu_stats(int id, const float* tables, const uint32_t* letters, int n, int L, int LW, int want_sparsity,
-              int force_ls, int gx, float* partials, int partials_cap, float* sums, int skip_begin, int skip_len) {
-  StatsArgs a;
-  a.tables = tables; a.letters = letters; a.n = n; a.L = L; a.LW = LW;
-  a.divL = make_fastdiv((uint32_t)L);
-  a.want_sparsity = want_sparsity;
-  a.partials = partials;
-  a.debug = 0;
-  int row = -1;
-  CFG_DISPATCH(id, {
-    const ModelShape ms = shape_of<C>();
-    const int Lh = L - C::M + 1;
-    StatsLayout st = stats_layout(ms, want_sparsity, Lh, n, 0);
-    if (force_ls > 0) {   // cut every chain into segments of force_ls hidden positions
-      st.S = 1; st.LS = force_ls; st.nseg = (Lh + force_ls - 1) / force_ls;
-      st.Rrow = st.LS + 2 * (C::M - 1);
-      st.LWt = (st.LS + C::M - 1 + 30) / 16 + 3;
-    }
-    a.Lh = Lh;
-    a.S = st.S; a.LS = st.LS; a.nseg = st.nseg; a.Rrow = st.Rrow; a.LWt = st.LWt;
-    a.PB = st.PB; a.parts = st.parts; a.npasses = st.npasses;
-    a.divLS = make_fastdiv((uint32_t)st.LS); a.divLvis = make_fastdiv((uint32_t)(st.LS + C::M - 1));
-    a.row = st.row;
-    a.off_vh0 = st.off_vh[0]; a.off_vh1 = st.off_vh[1]; a.off_h0 = st.off_h[0]; a.off_h1 = st.off_h[1];
-    a.off_sw = st.off_sw; a.off_sb = st.off_sb; a.off_v = st.off_v;
-    const int ntiles = ((n + st.S - 1) / st.S) * st.nseg;
-    if (gx > ntiles) gx = ntiles;
-    const int rows = gx;
-    if ((long)rows * st.row > partials_cap) return -2;
-    for (size_t i = 0; i < (size_t)rows * st.row; ++i) partials[i] = 1e30f;   // never cleared on the GPU either
-    emu::launch([&] { stats_body<C>(a); }, dim3(gx, st.grid_y), dim3(st.threads), (size_t)st.lds_bytes);
-    // column sums on the host, same validity rules as reduce_partials_kernel (which
-    // is emulated by emu_reduce on a small case: one OS thread per GPU thread is
-    // too slow for ~2000 columns)
-    const int sb = skip_begin < 0 ? st.row : skip_begin, sl = skip_begin < 0 ? 0 : skip_len;
-    const int KAM = C::K * 4 * C::M, K = C::K;
-    for (int r = 0; r < st.row; ++r) {
-      if (r >= sb && r < sb + sl) continue;
-      bool valid;
-      if (r < KAM) valid = true;
-      else if (r < 2 * KAM) valid = C::DS != 0;
-      else if (r < 2 * KAM + K) valid = true;
-      else if (r < 2 * KAM + 2 * K) valid = C::DS != 0;
-      else if (r < 3 * KAM + 3 * K) valid = want_sparsity != 0;
-      else valid = true;
-      float t = 0.f;
-      if (valid)
-        for (int i = 0; i < rows; ++i) t += partials[(size_t)i * st.row + r];
-      sums[r < sb ? r : r - sl] = t;
-    }
-    sums[st.row - sl] = (float)n;
-    row = st.row;
-  });
-  return row;
-}
-
 // fills the StatsGeom of a layout
 static StatsGeom geom_of(const StatsMfmaLayout& st, float* partials, long ngroups, size_t lds_bytes) {
   StatsGeom g;
@@ -338,22 +281,25 @@ int emu_reduce(const float* partials, float* sums, int nrows, int row, int K, in
 int emu_update(const float* sums, float* W, float* b, float* c, float* vW, float* vb, float* vc, int K, int M,
                int ds, int L_data, int Lf, float lr, float momentum, float rho, float lambda_rate) {
   const SumsLayout sl = sums_layout(K, M);
-  UpdateArgs u{sums, W, b, c, vW, vb, vc, K, M, ds, L_data, Lf, sl.data_off, sl.n_d, sl.model_off, sl.n_m,
+  UpdateArgs u{sums, W, b, c, vW, vb, vc, W, b, c, vW, vb, vc, K, M, ds, L_data, Lf, sl.data_off, sl.n_d, sl.model_off, sl.n_m,
                lr, momentum, rho, lambda_rate};
   emu::launch([&] { apply_update_kernel(u); }, dim3(1), dim3(64), 0);
   return 0;
 }
 
-// the fused end of a training step: update + table images of the new parameters (one block)
-int emu_update_tables(int id, const float* sums, float* W, float* b, float* c, float* vW, float* vb, float* vc,
-                      int L_data, int Lf, float lr, float momentum, float rho, float lambda_rate, float* tables, int threads) {
+// the fused end of a training step: update + table images of the new parameters; `grid` blocks, the
+// new parameters and velocities go to the o* buffers (the old ones stay untouched)
+int emu_update_tables(int id, const float* sums, const float* W, const float* b, const float* c, const float* vW,
+                      const float* vb, const float* vc, float* oW, float* ob, float* oc, float* ovW, float* ovb, float* ovc,
+                      int L_data, int Lf, float lr, float momentum, float rho, float lambda_rate, float* tables, int grid,
+                      int threads) {
   CFG_DISPATCH(id, {
     const SumsLayout sl = sums_layout(C::K, C::M);
     UpdateTablesArgs a;
-    a.u = UpdateArgs{sums, W, b, c, vW, vb, vc, C::K, C::M, C::DS, L_data, Lf, sl.data_off, sl.n_d, sl.model_off, sl.n_m,
-                     lr, momentum, rho, lambda_rate};
+    a.u = UpdateArgs{sums, W, b, c, vW, vb, vc, oW, ob, oc, ovW, ovb, ovc, C::K, C::M, C::DS, L_data, Lf,
+                     sl.data_off, sl.n_d, sl.model_off, sl.n_m, lr, momentum, rho, lambda_rate};
     a.tables = tables;
-    emu::launch([&] { update_tables_body<C>(a); }, dim3(1), dim3(threads), (size_t)(C::K * 4 * C::M + C::K + 4) * 4);
+    emu::launch([&] { update_tables_body<C>(a); }, dim3(grid), dim3(threads), (size_t)(C::K * 4 * C::M + C::K + 4) * 4);
   });
   return 0;
 }

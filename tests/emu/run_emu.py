@@ -332,9 +332,14 @@ def test_train_step():
             np.testing.assert_allclose(sums[model_off + KAM:model_off + 2 * KAM], s['vh_mp'].ravel(), rtol=2e-5, atol=1e-6)
             np.testing.assert_allclose(sums[model_off + 2 * KAM + K:model_off + 2 * KAM + 2 * K], s['h_mp'], rtol=2e-5)
         new_tables = np.zeros(info["TABLES"], dtype=np.float32)
-        lib.emu_update_tables(cid, fp(sums), fp(W), fp(b), fp(c), fp(vW), fp(vb), fp(vc), L, Lf,
+        old = [x.copy() for x in (W, b, c, vW, vb, vc)]
+        nxt = [np.full_like(x, np.nan) for x in old]
+        lib.emu_update_tables(cid, fp(sums), *[fp(x) for x in old], *[fp(x) for x in nxt], L, Lf,
                               ctypes.c_float(o.learning_rate), ctypes.c_float(o.momentum), ctypes.c_float(o.rho),
-                              ctypes.c_float(o.lambda_rate), fp(new_tables), 128)
+                              ctypes.c_float(o.lambda_rate), fp(new_tables), 3, 128)
+        for x, keep in zip(old, (W, b, c, vW, vb, vc)):
+            assert np.array_equal(x, keep)               # the blocks still reading the old set see it untouched
+        W, b, c, vW, vb, vc = nxt
         # the table images the fused launch leaves are those of the NEW parameters
         ref_tables = np.zeros(info["TABLES"], dtype=np.float32)
         assert lib.emu_tables(cid, fp(W), fp(b), fp(c), fp(ref_tables)) == 0
@@ -345,6 +350,92 @@ def test_train_step():
         np.testing.assert_allclose(c, o.c.ravel(), rtol=1e-4, atol=1e-6)
         np.testing.assert_allclose(vW.reshape(o.W.shape), o.vW, rtol=1e-4, atol=1e-7)
         print("train step ok", cid, (K, M, ds), "fused" if fused else "split")
+
+
+def rank_step(cid, o, tables, D_rows, L, chain_lo, chain_hi, threads=128):
+    """The local phase of one rank of a data-parallel step through the product kernels: packed raw
+    sums (include/crbm_amd.h layout) of its data rows and of its chains, which it advances by cd_k
+    Gibbs steps.  Returns (sums, hm, hmp) with the new chain masks."""
+    info = case_info(cid)
+    K, M, ds, NW = info["K"], info["M"], info["ds"], info["NW"]
+    lay = (ctypes.c_int * 7)()
+    lib.emu_sums_layout(K, M, lay)
+    data_off, n_d, model_off, n_m, count, skipb, skipl = list(lay)
+    sums = np.zeros(count, dtype=np.float32)
+    row = 3 * K * 4 * M + 3 * K + 4
+    partials = np.zeros(16 * row, dtype=np.float32)
+    n = D_rows.shape[0]
+    if n:
+        letters, _ = encode(D_rows)
+        r = lib.emu_stats_mfma(cid, fp(tables), up(letters), n, L, lib.emu_letter_words(L), 1, 0, 2,
+                               fp(partials), partials.size, fp(sums[data_off:]), -1, 0)
+        assert r == row
+    sums[n_d] = n                                       # a rank may own no rows: zeros and n_d = 0
+    B = chain_hi - chain_lo
+    Lf = o.fantasy_h.shape[3]
+    hm, _ = pack_hidden(f32(o.fantasy_h[chain_lo:chain_hi]), NW)
+    hmp = pack_hidden(f32(o.fantasy_h_prime[chain_lo:chain_hi]), NW)[0] if ds else np.zeros_like(hm)
+    lws = lib.emu_gibbs(cid, fp(tables), up(hm), up(hmp), None, B, Lf, 2, o.cd_k,
+                        ctypes.c_uint64(o.seed), o.gibbs_step, chain_lo, 2, threads, 1, None)
+    vout = np.zeros((B, lws), dtype=np.uint32)
+    r = lib.emu_gibbs_stats(cid, fp(tables), up(hm), up(hmp), up(vout), B, Lf, 2, o.cd_k,
+                            ctypes.c_uint64(o.seed), o.gibbs_step, chain_lo, 2, threads,
+                            fp(partials), partials.size, fp(sums[model_off:]), skipb, skipl)
+    assert r == row, r
+    return sums, hm, hmp
+
+
+def test_two_ranks():
+    """SURVEY 8(e) in the GPU-less container with the PRODUCT kernels in the kernel seat: two ranks
+    shard the rows of each mini-batch (crbm_amd.dist.shard_range, the arithmetic of
+    crbm_train_epoch_resident) and the chains (Philox counters keyed by the global chain index), sum
+    their packed buffers (what ncclAllReduce does) and apply the same update; the result must equal
+    the one-rank step on the same rows: identical chains, parameters to reduction-order tolerance.
+    The second mini-batch has a single row, so rank 0 owns none of it."""
+    from crbm_amd.dist import shard_range
+    cid = 1                                             # (10, 15, doublestranded): has the fused Gibbs variant
+    info = case_info(cid)
+    K, M, ds, NW = info["K"], info["M"], info["ds"], info["NW"]
+    B, Lf, L = 4, 40, M + 20
+    D = synthetic_onehot(6, L, seed=33)
+    batches = [(0, 5), (5, 6)]
+
+    def run(world):
+        o = make_oracle(K, M, ds, seed=5, batch=B, Lf=Lf, cd_k=2, rho=0.05)
+        W, b, c = model_arrays(o)
+        vW, vb, vc = np.zeros_like(W), np.zeros_like(b), np.zeros_like(c)
+        fh, fhp = o.fantasy_h.copy(), o.fantasy_h_prime.copy()
+        for (s0, s1) in batches:
+            o.W, o.b, o.c = W.reshape(o.W.shape).astype(np.float64), b.reshape(o.b.shape).astype(np.float64), c.reshape(o.c.shape).astype(np.float64)
+            o.fantasy_h, o.fantasy_h_prime = fh, fhp
+            tables = build_tables(cid, o)
+            total = None
+            new_h, new_hp = [], []
+            for r in range(world):
+                lo, hi = shard_range(s1 - s0, r, world)
+                clo, chi = shard_range(B, r, world)
+                sums, hm, hmp = rank_step(cid, o, tables, D[s0 + lo:s0 + hi], L, clo, chi)
+                total = sums if total is None else (total + sums).astype(np.float32)
+                new_h.append(unpack_hidden(hm, K))
+                new_hp.append(unpack_hidden(hmp, K))
+            fh, fhp = np.concatenate(new_h).astype(np.float64), np.concatenate(new_hp).astype(np.float64)
+            o.gibbs_step += o.cd_k
+            old = [W, b, c, vW, vb, vc]
+            nxt = [np.zeros_like(x) for x in old]
+            new_tables = np.zeros(info["TABLES"], dtype=np.float32)
+            lib.emu_update_tables(cid, fp(total), *[fp(x) for x in old], *[fp(x) for x in nxt], L, Lf,
+                                  ctypes.c_float(o.learning_rate), ctypes.c_float(o.momentum), ctypes.c_float(o.rho),
+                                  ctypes.c_float(o.lambda_rate), fp(new_tables), 2, 128)
+            W, b, c, vW, vb, vc = nxt
+        return W, b, c, vW, fh, fhp
+
+    one, two = run(1), run(2)
+    np.testing.assert_array_equal(one[4], two[4])       # identical samples
+    np.testing.assert_array_equal(one[5], two[5])
+    for x, y in zip(one[:4], two[:4]):
+        np.testing.assert_allclose(x, y, rtol=1e-5, atol=1e-7)
+    assert not np.array_equal(one[0], model_arrays(make_oracle(K, M, ds, seed=5, batch=B, Lf=Lf, cd_k=2, rho=0.05))[0])
+    print("two ranks ok")
 
 
 def stats_sums(cid, tables, letters, n, L, want_sparsity, threads, gx, skip=(-1, 0)):
@@ -447,7 +538,8 @@ def test_hit_summary():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["encode_pack", "hgv", "vgh", "gibbs", "stats_mfma", "train_step", "free_energy", "hit_summary"]
+    which = sys.argv[1:] or ["encode_pack", "hgv", "vgh", "gibbs", "stats_mfma", "train_step", "two_ranks", "free_energy",
+                             "hit_summary"]
     for w in which:
         globals()["test_" + w]()
     print("EMU ALL OK")

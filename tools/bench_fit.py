@@ -15,7 +15,7 @@ import bench  # noqa: E402
 if __name__ == "__main__":
     cfg = bench.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "cfg2"]
     nb = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-    model = bench.build_model(cfg, 1, 0)
+    model = bench.build_model(cfg, 1, 0, 0)
     model.epochs = 3
     codes = np.random.default_rng(1).integers(0, 4, size=(cfg["chains"] * nb, cfg["L"]), dtype=np.uint8)
     test = codes[:cfg["chains"]]

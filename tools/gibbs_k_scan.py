@@ -10,7 +10,7 @@ import bench  # noqa: E402
 
 if __name__ == "__main__":
     cfg = bench.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "cfg2"]
-    model = bench.build_model(cfg, 1, 0)
+    model = bench.build_model(cfg, 1, 0, 0)
     model._call("crbm_gibbs_steps", 10)
     ms = ctypes.c_float()
     for k in [int(x) for x in os.environ.get('KS', '0,1,2,4').split(',')]:

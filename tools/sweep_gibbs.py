@@ -15,7 +15,7 @@ import bench  # noqa: E402
 def time_cfg(cfg, env, steps=300):
     for k, v in env.items():
         os.environ[k] = str(v)
-    model = bench.build_model(cfg, 1, 0)
+    model = bench.build_model(cfg, 1, 0, 0)
     try:
         model._h()
     except Exception as e:
