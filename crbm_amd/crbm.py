@@ -146,8 +146,6 @@ class CRBM(object):
             return self._handle
         if self.input_dims != 4:
             raise Exception("the HIP kernels require input_dims == 4")
-        if self.pooling != 1:
-            raise Exception("the HIP kernels require pooling == 1")
         lib = _lib.load()
         if self.batchsize % self.world_size != 0:
             raise Exception("batchsize must be divisible by the number of GPUs")

@@ -73,7 +73,7 @@ def precompile(configs, verbose=True):
     for c in configs:
         cfg = _lib.CrbmConfig(num_motifs=c["num_motifs"], motif_length=c["motif_length"], input_dims=4,
                               doublestranded=int(c.get("doublestranded", 0)), batchsize=c.get("batchsize", 20),
-                              cd_k=1, pooling=1, fantasy_hidden_len=c.get("fantasy_hidden_len", 200),
+                              cd_k=1, pooling=c.get("pooling", 1), fantasy_hidden_len=c.get("fantasy_hidden_len", 200),
                               learning_rate=0.1, momentum=0.9, rho=0.01, lambda_rate=0.1, seed=0, device=0, reserved=0)
         rc = lib.crbm_precompile(ctypes.byref(cfg))
         if rc != 0:

@@ -476,6 +476,8 @@ int check_data_shape(crbm_handle* h, int n, int L) {
   ARGCHK(n >= 1, "n must be positive");
   ARGCHK(L >= h->M, "sequence length must be >= motif_length");
   ARGCHK((long)L * 4 < (1 << 20), "sequence too long");
+  // the reference reshapes the hidden layer into (…, Lh / pooling, pooling) (convRBM.py:250-252); fit() truncates for it
+  ARGCHK((L - h->M + 1) % h->ms.POOL == 0, "hidden length L - motif_length + 1 must be a multiple of pooling");
   return CRBM_OK;
 }
 
@@ -511,7 +513,8 @@ int validate_config(const crbm_config* cfg) {
   ARGCHK(cfg->motif_length >= 1, "Motif length must be positive.");
   ARGCHK(cfg->motif_length <= 32, "motif_length > 32 is not supported by the HIP kernels");
   ARGCHK(cfg->input_dims == 4, "the HIP kernels require input_dims == 4 (DNA one-hot)");
-  ARGCHK(cfg->pooling == 1, "the HIP kernels require pooling == 1");
+  ARGCHK(cfg->pooling >= 1 && cfg->pooling <= 64, "pooling must be between 1 and 64");
+  ARGCHK(cfg->fantasy_hidden_len % cfg->pooling == 0, "pooling must divide the hidden length of the fantasy chains");
   ARGCHK(cfg->batchsize >= 1, "batchsize must be positive.");
   ARGCHK(cfg->cd_k >= 1, "cd_k must be positive.");
   ARGCHK(cfg->fantasy_hidden_len >= 1 && cfg->fantasy_hidden_len <= 65536, "fantasy_hidden_len out of range");
@@ -582,13 +585,13 @@ int crbm_precompile(const crbm_config* cfg) {
   const int ds = cfg->doublestranded ? 1 : 0;
   int G = env_int("CRBM_GROUP", 0);
   if (G < 1 || G > 4) G = choose_group(cfg->num_motifs, cfg->motif_length, ds, env_int("CRBM_TABLE_BUDGET", 24 * 1024));
-  const ModelShape ms = model_shape(cfg->num_motifs, cfg->motif_length, ds, G);
+  const ModelShape ms = model_shape(cfg->num_motifs, cfg->motif_length, ds, G, cfg->pooling);
   std::vector<char> code;
   bool cached = false;
   std::string file, err;
   const int Lf_pc = cfg->fantasy_hidden_len > 0 ? cfg->fantasy_hidden_len : 200;
   const int wpe = gibbs_wpe_hint(choose_gibbs_geometry(ms, Lf_pc, cfg->batchsize, env_int("CRBM_NUM_CU", 256), true));
-  if (jit_compile(ms.K, ms.M, ms.DS, ms.G, wpe, &code, &cached, &file, &err) != 0) {
+  if (jit_compile(ms.K, ms.M, ms.DS, ms.G, ms.POOL, wpe, &code, &cached, &file, &err) != 0) {
     g_create_error = err;
     return CRBM_ERR_HIP;
   }
@@ -617,7 +620,7 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
   // gather-table group size, derived shapes
   hh->G = env_int("CRBM_GROUP", 0);
   if (hh->G < 1 || hh->G > 4) hh->G = choose_group(hh->K, hh->M, hh->ds, env_int("CRBM_TABLE_BUDGET", 24 * 1024));
-  hh->ms = model_shape(hh->K, hh->M, hh->ds, hh->G);
+  hh->ms = model_shape(hh->K, hh->M, hh->ds, hh->G, cfg->pooling);
   hh->NW = hh->ms.NW;
   auto bail = [&](int code) { crbm_destroy(hh); return code; };
   hipError_t e;
@@ -653,7 +656,7 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
   }
   {
     std::string err;
-    if (jit_load(hh->K, hh->M, hh->ds, hh->G, hh->gibbs_wpe, &hh->jk, &err) != 0) {
+    if (jit_load(hh->K, hh->M, hh->ds, hh->G, hh->ms.POOL, hh->gibbs_wpe, &hh->jk, &err) != 0) {
       g_create_error = "kernel specialisation failed: " + err;
       return bail(CRBM_ERR_HIP);
     }

@@ -299,6 +299,113 @@ __device__ __forceinline__ void conv_gather(const float* T, uint64_t win, float 
   }
 }
 
+// ---------------------------------------------------------------------------
+// Pooling (convRBM.py:245-267; Cfg::POOL > 1): the hidden units of POOL consecutive
+// positions compete, P_i = exp(x_i) / (POOL + sum_j exp(x_j)), and at most one of them
+// fires: unit i is on iff cum_{i-1} <= u < cum_i for the one uniform of the group
+// (that of its first position).  A lane owns one position and evaluates its whole
+// group itself (POOL gathers, two passes: maximum, then sums) -- plain and without
+// cross-lane traffic; the reference calls pooling "not relevant for cRBM" and every
+// BASELINE configuration uses POOL = 1, whose code never sees any of this.
+//   zfun(pos, z): z[k] = -log2(e) * activation of the units at hidden position pos
+// Results for the lane's position s: p = P_s, cb = sum of P over the group's earlier
+// positions, S = sum of P over the group (all in the overflow-free form).
+// ---------------------------------------------------------------------------
+template <int POOL, int KP, class ZFun>
+__device__ __forceinline__ void pooled_probs(ZFun zfun, int s, float (&p)[KP], float (&cb)[KP], float (&S)[KP]) {
+  const int g0 = s - s % POOL, me = s - g0;
+  float zmin[KP], z[KP];
+#pragma unroll
+  for (int k = 0; k < KP; ++k) zmin[k] = 0.f;               // the "POOL" term is POOL * exp(0)
+#pragma unroll 1
+  for (int j = 0; j < POOL; ++j) {
+    zfun(g0 + j, z);
+#pragma unroll
+    for (int k = 0; k < KP; ++k) zmin[k] = fminf(zmin[k], z[k]);
+  }
+  float den[KP];
+#pragma unroll
+  for (int k = 0; k < KP; ++k) { den[k] = (float)POOL * __builtin_amdgcn_exp2f(zmin[k]); cb[k] = 0.f; p[k] = 0.f; }
+#pragma unroll 1
+  for (int j = 0; j < POOL; ++j) {
+    zfun(g0 + j, z);
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+      const float e = __builtin_amdgcn_exp2f(zmin[k] - z[k]);   // exp(x_j - max), <= 1
+      den[k] += e;
+      cb[k] += j < me ? e : 0.f;
+      p[k] = j == me ? e : p[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < KP; ++k) {
+    const float inv = 1.0f / den[k];
+    S[k] = (den[k] - (float)POOL * __builtin_amdgcn_exp2f(zmin[k])) * inv;
+    p[k] *= inv;
+    cb[k] *= inv;
+  }
+}
+
+// 24-bit uniforms of the K units at (sequence n, position s): both 12-bit fields of every sampler
+// group (the pooled sampler compares against cumulative sums, so the lazy fine call of
+// sample_hidden does not apply)
+template <class C>
+__device__ __forceinline__ void hidden_uniforms24(uint32_t n, uint32_t s, uint32_t kind, uint32_t strand, const RngView& rng,
+                                                  uint32_t step, float (&u)[C::KP]) {
+#pragma unroll
+  for (int g = 0; g < C::NGRP; ++g) {
+    const Philox4 rc = philox4x32_10(n, s, rng_word2(kind, strand, 0, (uint32_t)g), step, rng.seed_lo, rng.seed_hi);
+    const Philox4 rf = philox4x32_10(n, s, rng_word2(kind, strand, 1, (uint32_t)g), step, rng.seed_lo, rng.seed_hi);
+    auto unit = [&](auto I) {
+      constexpr int i = decltype(I)::value;
+      const int k = 10 * g + i;
+      if (k < C::K) u[k] = (float)(philox_field12<i>(rc) * 4096u + philox_field12<i>(rf)) * 5.9604644775390625e-8f;
+    };
+    unit(IC<0>{}); unit(IC<1>{}); unit(IC<2>{}); unit(IC<3>{}); unit(IC<4>{});
+    unit(IC<5>{}); unit(IC<6>{}); unit(IC<7>{}); unit(IC<8>{}); unit(IC<9>{});
+  }
+}
+
+// sum_k log(1 + sum_j exp(x_j)) of the group that starts at position g0, per unit into acc[] (free energy,
+// convRBM.py:664-665): ln2 * (-zmin) + ln(exp(-max) + sum_j exp(x_j - max))
+template <int POOL, int KP, class ZFun>
+__device__ __forceinline__ void pooled_softplus(ZFun zfun, int g0, float (&acc)[KP], int nvalid) {
+  float zmin[KP], z[KP], den[KP];
+#pragma unroll
+  for (int k = 0; k < KP; ++k) zmin[k] = 0.f;
+#pragma unroll 1
+  for (int j = 0; j < POOL; ++j) {
+    zfun(g0 + j, z);
+#pragma unroll
+    for (int k = 0; k < KP; ++k) zmin[k] = fminf(zmin[k], z[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < KP; ++k) den[k] = __builtin_amdgcn_exp2f(zmin[k]);
+#pragma unroll 1
+  for (int j = 0; j < POOL; ++j) {
+    zfun(g0 + j, z);
+#pragma unroll
+    for (int k = 0; k < KP; ++k) den[k] += __builtin_amdgcn_exp2f(zmin[k] - z[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < KP; ++k)
+    if (k < nvalid) acc[k] += 0.6931471805599453f * (__builtin_amdgcn_logf(den[k]) - zmin[k]);
+}
+
+// K-bit mask of the pooled sample at the lane's position: on iff cb <= u < cb + p (first index whose
+// cumulative probability exceeds the group's uniform, convRBM.py:259-267)
+template <class C>
+__device__ __forceinline__ void pooled_sample(const float (&p)[C::KP], const float (&cb)[C::KP], const float (&u)[C::KP],
+                                              uint32_t (&mask)[C::NW]) {
+#pragma unroll
+  for (int w = 0; w < C::NW; ++w) mask[w] = 0u;
+#pragma unroll
+  for (int k = 0; k < C::K; ++k) {
+    const uint32_t one = (cb[k] + p[k] > u[k] && cb[k] <= u[k]) ? 1u : 0u;
+    mask[k >> 5] |= one << (k & 31);
+  }
+}
+
 // global precomputed tables -> LDS (plain float4 copy)
 template <int NFLOATS>
 __device__ __forceinline__ void copy_tables(float* dst, const float* src) {
@@ -414,13 +521,25 @@ __device__ void hgv_body(const HgvArgs& a) {
       const uint32_t nl = fastdiv(i, a.divLh);
       const int s = (int)(i - nl * (uint32_t)a.Lh);
       const int nn = n0 + (int)nl;
-      const uint64_t win = letter_window<M>(a.letters + (size_t)nn * a.LW, s);
+      const uint32_t* lrow = a.letters + (size_t)nn * a.LW;
+      auto zfun = [&](int pos, float (&z)[KP]) {
+        const uint64_t w = letter_window<M>(lrow, pos);
+        conv_gather<C>(T0, w, z);
+        if (a.mode == 2) conv_gather<C, true>(T1, w, z);
+      };
       float x[KP];
-      conv_gather<C>(T0, win, x);
-      if (a.mode == 2) conv_gather<C, true>(T1, win, x);
+      zfun(s, x);
       uint32_t mask[C::NW];
       float p[KP];
-      if (want_sample) {
+      if constexpr (C::POOL > 1) {
+        float cb[KP], S[KP];
+        pooled_probs<C::POOL, KP>(zfun, s, p, cb, S);
+        if (want_sample) {
+          float u[KP];
+          hidden_uniforms24<C>(a.rng.seq_offset + (uint32_t)nn, (uint32_t)(s - s % C::POOL), a.kind, strand, a.rng, a.rng.step, u);
+          pooled_sample<C>(p, cb, u, mask);
+        }
+      } else if (want_sample) {
         sample_hidden<C, 1>(x, a.rng.seq_offset + (uint32_t)nn, (uint32_t)s, a.kind, strand, a.rng, a.rng.step,
                                mask, p);
       } else {
@@ -755,11 +874,38 @@ __device__ void stats_mfma_body(const StatsMfmaArgs& a) {
       const int slot = lane >> 5, e = lane & 31;
       const int G = G0 + slot;
       bool valid = G < ngroups && !(a.debug & 2);
+      uint32_t chain = 0u;
+      int s = 0;
       if (valid) {
-        const uint32_t chain = fastdiv((uint32_t)G, sg.divGPC);
-        valid = 32 * (G - (int)chain * GPC) + e < a.Lh;
+        chain = fastdiv((uint32_t)G, sg.divGPC);
+        s = 32 * (G - (int)chain * GPC) + e;
+        valid = s < a.Lh;
       }
       float* col = Pt + lane;
+      if constexpr (C::POOL > 1) {
+        // pooled units: the lane evaluates its whole pooling group (it may reach back over the staged
+        // window: letters come from the global row); Q = dP_group/dx_s = P_s (1 - sum of the group's P)
+        if (valid) {
+          const uint32_t* lrow = a.letters + (size_t)chain * a.LW;
+          constexpr int NV = 4 * R::NQW;
+          float p[NV], cb[NV], S[NV];
+#pragma unroll
+          for (int strand = 0; strand <= C::DS; ++strand) {
+            auto zfun = [&](int pos, float (&z)[NV]) { conv_gather_quads<C, R::NQW>(strand ? Tr : Tf, letter_window<M>(lrow, pos), 4 * nt0, z); };
+            pooled_probs<C::POOL, NV>(zfun, s, p, cb, S);
+#pragma unroll
+            for (int kl = 0; kl < KW; ++kl)
+              if (16 * nt0 + kl < K) {
+                const float ps = 16384.0f * p[kl];
+                col[(size_t)(strand * KW + kl) * STATS_RS] = ps;
+                if (SP && strand == 0) col[(size_t)((1 + C::DS) * KW + kl) * STATS_RS] = ps * (1.0f - S[kl]);
+              }
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < KINDS * KW; ++r) col[(size_t)r * STATS_RS] = 0.f;
+        }
+      } else
       if (valid) {
         const uint64_t wl = letter_window<M>(gw + 4 * slot, e);
         float z[4 * R::NQW];
@@ -1154,10 +1300,19 @@ __device__ void gibbs_body(const GibbsArgs& a) {
 #pragma unroll
         for (int strand = 0; strand <= C::DS; ++strand) {
           float x[KP], p[KP];
-          conv_gather<C>(strand ? Tr : Tf, win, x);
           uint32_t mask[NW];
+          if constexpr (C::POOL > 1) {
+            const uint32_t* lrow = let + (size_t)nl * a.LWs;
+            auto zfun = [&](int pos, float (&z)[KP]) { conv_gather<C>(strand ? Tr : Tf, letter_window<M>(lrow, pos), z); };
+            float cb[KP], S[KP], u[KP];
+            pooled_probs<C::POOL, KP>(zfun, s, p, cb, S);
+            hidden_uniforms24<C>(gn, (uint32_t)(s - s % C::POOL), KIND_CHAIN_H, (uint32_t)strand, a.rng, a.rng.step + (uint32_t)st, u);
+            pooled_sample<C>(p, cb, u, mask);
+          } else {
+          conv_gather<C>(strand ? Tr : Tf, win, x);
           sample_hidden<C, 0>(x, gn, (uint32_t)s, KIND_CHAIN_H, (uint32_t)strand, a.rng,
                                   a.rng.step + (uint32_t)st, mask, p);
+          }
           uint32_t* dst = (strand ? hmp : hm) + (size_t)nl * rowW + (size_t)(s + M - 1) * NW;
 #pragma unroll
           for (int w = 0; w < NW; ++w) {
@@ -1241,6 +1396,15 @@ __device__ void free_energy_body(const FeArgs& a) {
     float acc[KP];
 #pragma unroll
     for (int q = 0; q < KP; ++q) acc[q] = 0.f;
+    if constexpr (C::POOL > 1) {
+      // one term per pooling group, log(1 + sum_j exp(x_j)) (convRBM.py:664-665): a lane takes whole groups
+      for (int g0 = lane * C::POOL; g0 < a.Lh; g0 += 64 * C::POOL)
+#pragma unroll
+        for (int strand = 0; strand <= C::DS; ++strand) {
+          auto zfun = [&](int pos, float (&z)[KP]) { conv_gather<C>(strand ? Tr : Tf, letter_window<M>(row, pos), z); };
+          pooled_softplus<C::POOL, KP>(zfun, g0, acc, K);
+        }
+    } else
     for (int s = lane; s < a.Lh; s += 64) {
       const uint64_t win = letter_window<M>(row, s);
       float x[KP];
@@ -1319,13 +1483,23 @@ __device__ void hit_summary_body(const HitArgs& a) {
     for (int i = 0; i < NI; ++i) {
       const int s = s0 + lane + 64 * i;
       if (s < a.Lh) {
-        const uint64_t win = letter_window<M>(row, s);
-        float z[KP];
-        conv_gather<C>(Tf, win, z);
-        if (BOTH) conv_gather<C, true>(Tr, win, z);
+        auto zfun = [&](int pos, float (&zz)[KP]) {
+          const uint64_t w = letter_window<M>(row, pos);
+          conv_gather<C>(Tf, w, zz);
+          if (BOTH) conv_gather<C, true>(Tr, w, zz);
+        };
+        float z[KP], pp[KP];
+        if constexpr (C::POOL > 1) {
+          float cb[KP], S[KP];
+          pooled_probs<C::POOL, KP>(zfun, s, pp, cb, S);
+        } else {
+          zfun(s, z);
+#pragma unroll
+          for (int q = 0; q < K; ++q) pp[q] = sigmoid_z(z[q]);
+        }
 #pragma unroll
         for (int q = 0; q < K; ++q) {
-          const float p = sigmoid_z(z[q]);
+          const float p = pp[q];
           mx[q] = fmaxf(mx[q], p);
           sm[q] += p;
           pacc[i][q] += p;

@@ -45,9 +45,12 @@ constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
 // (hiprtc at crbm_create, like the reference compiles its Theano graph at
 // construction, convRBM.py:175); the host uses the same formulas through
 // ModelShape below.
-template <int K_, int M_, int DS_, int G_>
+// POOL: hidden units compete in groups of POOL consecutive positions (convRBM.py:245-267,
+// "pooling"; 1 = independent sigmoid units, the reference's default and what every
+// BASELINE configuration uses).
+template <int K_, int M_, int DS_, int G_, int POOL_ = 1>
 struct Cfg {
-  static constexpr int K = K_, M = M_, DS = DS_, G = G_;
+  static constexpr int K = K_, M = M_, DS = DS_, G = G_, POOL = POOL_;
   static constexpr int NQ = cdiv(K, 4), KP = 4 * NQ;      // motifs padded to float4
   static constexpr int NW = cdiv(K, 32);                  // 32-bit mask words per hidden position
   static constexpr int NG = cdiv(M, G), ROWS = cpow4(G);  // gather table: groups x letter tuples
@@ -93,7 +96,7 @@ struct Cfg {
   // the model half of the statistics rides in the Gibbs kernel's last h|v pass when all motifs of
   // a position fit one wave's accumulator set of at most 8 tiles (32 registers; measured: with 16 tiles,
   // config #5, the fused kernel drops to one wave per SIMD and loses to the separate launch)
-  static constexpr bool FUSE_STATS = 4 * JT * (1 + DS) * NT <= 8;
+  static constexpr bool FUSE_STATS = 4 * JT * (1 + DS) * NT <= 8 && POOL == 1;
   static constexpr int OFF_TR = DS ? TAB : END2;
   static constexpr int TABLES_ALL = DS ? END2 : END2 + TAB;
   // hit-summary kernel: a lane keeps the position sums of HIT_NI positions in registers
@@ -102,17 +105,17 @@ struct Cfg {
 
 // Host-side mirror of Cfg (runtime values, same arithmetic).
 struct ModelShape {
-  int K, M, DS, G, NT, JT;
+  int K, M, DS, G, NT, JT, POOL;
   int NQ, KP, NW, NG, ROWS, TAB, NCH, DENSE, TV, WS, NGRP;
   int OFF_TF, OFF_TR, OFF_TV, OFF_TVR, OFF_C, TABLES, OFF_WS, END2, SP_TABLES, TABLES_ALL;
   int HIT_NI, FUSE_STATS;
 };
-inline ModelShape model_shape(int K, int M, int DS, int G) {
+inline ModelShape model_shape(int K, int M, int DS, int G, int POOL = 1) {
   ModelShape s;
-  s.K = K; s.M = M; s.DS = DS; s.G = G;
+  s.K = K; s.M = M; s.DS = DS; s.G = G; s.POOL = POOL;
   s.NQ = cdiv(K, 4); s.KP = 4 * s.NQ; s.NW = cdiv(K, 32);
   s.NT = cdiv(K, 16); s.JT = cdiv(M, 16);
-  s.FUSE_STATS = 4 * s.JT * (1 + DS) * s.NT <= 8;
+  s.FUSE_STATS = 4 * s.JT * (1 + DS) * s.NT <= 8 && POOL == 1;
   s.NG = cdiv(M, G); s.ROWS = cpow4(G); s.TAB = s.NG * s.ROWS * s.KP;
   s.NCH = cdiv(K, 5);
   s.DENSE = (s.NW == 1) && (s.NCH * M * (1 + DS) <= 64);

@@ -53,7 +53,8 @@ typedef struct crbm_config {
   int32_t doublestranded;      /* 0/1                                 :114 */
   int32_t batchsize;           /* number of persistent fantasy chains :115 */
   int32_t cd_k;                /* Gibbs steps per update              :121 */
-  int32_t pooling;             /* must be 1                           :120 */
+  int32_t pooling;             /* hidden units compete in groups of this many
+                                  positions (1..64; 1 = independent)  :120 */
   int32_t fantasy_hidden_len;  /* hidden length of the fantasy chains;
                                   the reference hard-codes 200        :168 */
   float learning_rate;         /*                                     :116 */

@@ -372,17 +372,26 @@ class OracleCRBM:
         av = self._collectVStatistics(data)
         return avh, ah, av
 
+    def _pooled_slope(self, P):
+        """sum over the units i of a pooling group of dP_i/dx_s for every position s:
+        with P_i = exp(x_i) / (pool + sum_j exp(x_j)), dP_i/dx_s = delta_is P_i - P_i P_s,
+        hence P_s (1 - sum_i P_i); P (1 - P) for pooling == 1."""
+        pool = self.pooling
+        N, K, one, Lh = P.shape
+        grp = P.reshape(N, K, one, Lh // pool, pool)
+        return (grp * (1.0 - grp.sum(axis=4, keepdims=True))).reshape(N, K, one, Lh)
+
     def _gradientSparsityConstraintEntropy(self, data):
-        """convRBM.py:440-451 in closed form (pooling == 1): forward strand
-        only; returns (-dE/dW, -dE/db) for
-        E = mean_k[q ln p_k + (1-q) ln(1-p_k)], p_k = mean_{n,s} sigma(x)."""
-        assert self.pooling == 1, "closed form written for pooling == 1"
+        """convRBM.py:440-451 (T.grad of the entropy penalty) in closed form:
+        forward strand only; returns (-dE/dW, -dE/db) for
+        E = mean_k[q ln p_k + (1-q) ln(1-p_k)], p_k = mean_{n,s} P[n,k,s].
+        Checked against finite differences of ``sparsity_penalty`` (tests/test_oracle.py)."""
         P = self._computeHgivenV(data)[0]
         N, K, _, Lh = P.shape
         q = self.rho
         p = np.mean(P, axis=(0, 2, 3))
         g = (q / p - (1.0 - q) / (1.0 - p)) / K
-        dP = P * (1.0 - P)
+        dP = self._pooled_slope(P)
         win = np.lib.stride_tricks.sliding_window_view(
             np.asarray(data, dtype=np.float64)[:, 0], Lh, axis=2)   # (N,A,M,Lh)
         S_W = np.einsum('najs,nks->kaj', win, dP[:, :, 0, :], optimize=True) / (N * Lh)
@@ -457,7 +466,7 @@ class OracleCRBM:
         P_d = self._computeHgivenV(D)[0]
         out['vh_d'] = vh_raw(P_d, D)
         out['h_d'] = P_d.sum(axis=(0, 2, 3))
-        dP = P_d * (1 - P_d)
+        dP = self._pooled_slope(P_d)
         out['sw'] = vh_raw(dP, D)
         out['sb'] = dP.sum(axis=(0, 2, 3))
         out['v_d'] = D.sum(axis=(0, 1, 3))

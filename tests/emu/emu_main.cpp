@@ -69,18 +69,20 @@ RngView make_rng(uint64_t seed, uint32_t step, uint32_t off) {
     case 6: { using C = Cfg<7, 32, 1, 3>; __VA_ARGS__; break; }         \
     case 7: { using C = Cfg<10, 15, 0, 3>; __VA_ARGS__; break; }        \
     case 8: { using C = Cfg<64, 32, 1, 1>; __VA_ARGS__; break; }        \
+    case 9: { using C = Cfg<4, 5, 1, 2, 2>; __VA_ARGS__; break; }       \
+    case 10: { using C = Cfg<10, 15, 0, 3, 3>; __VA_ARGS__; break; }    \
     default: return -1;                                          \
   }
 
 template <class C>
-ModelShape shape_of() { return model_shape(C::K, C::M, C::DS, C::G); }
+ModelShape shape_of() { return model_shape(C::K, C::M, C::DS, C::G, C::POOL); }
 }  // namespace
 
 extern "C" {
 
-int emu_case_info(int id, int* out) {   // K, M, DS, G, TABLES, NW, DENSE
+int emu_case_info(int id, int* out) {   // K, M, DS, G, TABLES, NW, DENSE, POOL
   CFG_DISPATCH(id, (out[0] = C::K, out[1] = C::M, out[2] = C::DS, out[3] = C::G, out[4] = C::TABLES_ALL, out[5] = C::NW,
-                    out[6] = C::DENSE ? 1 : 0));
+                    out[6] = C::DENSE ? 1 : 0, out[7] = C::POOL));
   return 0;
 }
 

@@ -36,10 +36,10 @@ def model_arrays(o):
 
 
 def case_info(cid):
-    out = (ctypes.c_int * 7)()
+    out = (ctypes.c_int * 8)()
     assert lib.emu_case_info(cid, out) == 0
-    K, M, DS, G, TABLES, NW, DENSE = list(out)
-    return dict(K=K, M=M, ds=bool(DS), G=G, TABLES=TABLES, NW=NW, DENSE=DENSE)
+    K, M, DS, G, TABLES, NW, DENSE, POOL = list(out)
+    return dict(K=K, M=M, ds=bool(DS), G=G, TABLES=TABLES, NW=NW, DENSE=DENSE, POOL=POOL)
 
 
 def build_tables(cid, o):
@@ -98,7 +98,9 @@ def make_oracle(K, M, ds, seed=0, batch=4, Lf=20, cd_k=2, wscale=1.0, **kw):
 # 0 (10,5,ss,G2) 1 (10,15,ds,G3) 2 (2,5,ds,G4) 3 (3,4,ss,G1) 4 (20,15,ds,G2: sparse v|h)
 # 5 (50,25,ss,G2: two mask words) 6 (7,32,ds,G3: sparse, 96-bit letter window) 7 (10,15,ss,G3: config #2)
 # 8 (64,32,ds,G1: the largest model the kernels take; statistics only -- three column roles)
+# 9 (4,5,ds,G2,pooling 2) 10 (10,15,ss,G3,pooling 3): pooled hidden units (convRBM.py:245-267)
 ALL_CASES = list(range(8))
+POOLED_CASES = [9, 10]
 # One OS thread per GPU thread makes barrier-heavy kernels slow on 8 cores: the
 # default run keeps the CPU suite to a few minutes, CRBM_EMU_FULL=1 runs all.
 FULL = os.environ.get("CRBM_EMU_FULL", "0") == "1"
@@ -109,7 +111,7 @@ TRAIN_CASES = ALL_CASES[:6] if FULL else [1, 2, 5]
 
 def oracle_for(cid, **kw):
     info = case_info(cid)
-    return info, make_oracle(info["K"], info["M"], info["ds"], **kw)
+    return info, make_oracle(info["K"], info["M"], info["ds"], pooling=info["POOL"], **kw)
 
 
 def test_encode_pack():
@@ -501,6 +503,98 @@ def test_stats_mfma():
         print("stats mfma ok", cid, (K, M, ds))
 
 
+def check_pooled_samples(name, got, prob, u, pool):
+    """a pooled sample may differ from the oracle's only where the group's uniform sits on a cumulative-sum tie"""
+    N, K, one, Lh = prob.shape
+    p = prob.reshape(N, K, one, Lh // pool, pool)
+    ug = u.reshape(N, K, one, Lh // pool, pool)[..., :1]
+    cum = np.cumsum(p, axis=4)
+    want = ((cum > ug) & (np.concatenate([np.zeros_like(cum[..., :1]), cum[..., :-1]], axis=4) <= ug)).astype(np.float32)
+    g = got.reshape(N, K, one, Lh // pool, pool)
+    bad = (g != want).any(axis=4)
+    if bad.any():
+        gap = np.min(np.abs(cum - ug), axis=4)
+        assert np.all(gap[bad] < 1e-6), "%s: pooled sample differs away from a tie" % name
+    assert np.all(g.sum(axis=4) <= 1)
+    return int(bad.sum())
+
+
+def test_pooling():
+    """pooling > 1 (convRBM.py:245-267, :586-599, :664-665): probabilities exp(x)/(pool + sum exp), one
+    multinomial draw per pooling group, free energy log(1 + sum exp), hit summaries, a Gibbs chain and
+    the raw statistic sums with the pooled sparsity slope -- every kernel against the oracle."""
+    for cid in POOLED_CASES:
+        info, o = oracle_for(cid, seed=7, batch=4, Lf=24, cd_k=2, rho=0.05)
+        K, M, ds, NW, pool = info["K"], info["M"], info["ds"], info["NW"], info["POOL"]
+        tables = build_tables(cid, o)
+        n, Lh = 3, 30
+        L = Lh + M - 1
+        d = synthetic_onehot(n, L, seed=K + 2)
+        letters, _ = encode(d)
+        for mode in (0, 1, 2):
+            prob = np.zeros((n, K, 1, Lh), dtype=np.float32)
+            smp = np.zeros_like(prob)
+            ones = ctypes.c_ulonglong(0)
+            assert lib.emu_hgv(cid, fp(tables), up(letters), n, L, mode, None, fp(prob), fp(smp), ctypes.byref(ones),
+                               ctypes.c_uint64(77), 5, 3, KIND_API_H, 2, 2, 128) == 0
+            act = o._bottomUpActivity(d) + o._bottomUpActivity(d, True) if mode == 2 else o._bottomUpActivity(d, mode == 1)
+            ref = o._bottomUpProbability(act)
+            np.testing.assert_allclose(prob, ref, rtol=2e-5, atol=1e-7)
+            u = hidden_uniforms(77, 5, np.arange(n) + 3, K, Lh, 1 if mode == 1 else 0, KIND_API_H)
+            check_pooled_samples("hgv", smp, ref, u, pool)
+            assert ones.value == int(smp.sum())
+        fe = np.zeros(n, dtype=np.float32)
+        fem = np.zeros((n, K), dtype=np.float32)
+        lib.emu_free_energy(cid, fp(tables), up(letters), n, L, fp(fe), fp(fem), 2, 128)
+        np.testing.assert_allclose(fe, o.freeEnergy(d), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(fem, o.freeEnergy(d, True), rtol=1e-5, atol=1e-5)
+        P = o.motifHitProbs(d)
+        hmax = np.zeros((n, K), dtype=np.float32)
+        hsum = np.zeros((n, K), dtype=np.float32)
+        pos = np.zeros((K, Lh), dtype=np.float32)
+        lib.emu_hit_summary(cid, fp(tables), up(letters), n, L, fp(hmax), fp(hsum), fp(pos), 2, 128)
+        np.testing.assert_allclose(hmax, P.max(axis=(2, 3)), rtol=2e-5, atol=1e-7)
+        np.testing.assert_allclose(pos / n, P.mean(axis=(0, 2)), rtol=2e-5, atol=1e-7)
+        # the chain: from a pooled-valid start (at most one unit on per group)
+        rng = np.random.default_rng(3)
+        def pooled_start():
+            h = np.zeros(o.fantasy_h.shape)
+            grp = h.reshape(h.shape[0], K, 1, -1, pool)
+            pick = rng.integers(0, 3 * pool, size=grp.shape[:4])
+            for i in range(pool):
+                grp[..., i] = (pick == i)
+            return grp.reshape(h.shape)
+        o.fantasy_h = pooled_start()
+        if ds:
+            o.fantasy_h_prime = pooled_start()
+        o.seq_offset = 2
+        h, hp, v, vout, lws = run_gibbs(cid, o, tables, 2, 2, 2, 128)
+        P_m, P_mp, v_m = o.gibbs_steps(2)
+        assert np.array_equal(v, v_m) and np.array_equal(h, o.fantasy_h)
+        assert np.all(h.reshape(h.shape[0], K, 1, -1, pool).sum(axis=4) <= 1)
+        # raw sums of both halves (the model half through the stand-alone kernel: no fused variant with pooling)
+        lay = (ctypes.c_int * 7)()
+        lib.emu_sums_layout(K, M, lay)
+        data_off, n_d, model_off, n_m, count, skipb, skipl = list(lay)
+        sums = np.zeros(count, dtype=np.float32)
+        row = 3 * K * 4 * M + 3 * K + 4
+        partials = np.zeros(8 * row, dtype=np.float32)
+        assert lib.emu_stats_mfma(cid, fp(tables), up(letters), n, L, lib.emu_letter_words(L), 1, 128, 2,
+                                  fp(partials), partials.size, fp(sums[data_off:]), -1, 0) == row
+        Lv = o.fantasy_h.shape[3] + M - 1
+        assert lib.emu_stats_mfma(cid, fp(tables), up(vout), o.fantasy_h.shape[0], Lv, lws, 0, 128, 2,
+                                  fp(partials), partials.size, fp(sums[model_off:]), skipb, skipl) == row
+        s = o.local_sums(d, P_m, P_mp, v_m)
+        KAM = K * 4 * M
+        np.testing.assert_allclose(sums[0:KAM], s['vh_d'].ravel(), rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(sums[2 * KAM + 2 * K:3 * KAM + 2 * K], s['sw'].ravel(), rtol=5e-5, atol=1e-6)
+        np.testing.assert_allclose(sums[3 * KAM + 2 * K:3 * KAM + 3 * K], s['sb'], rtol=5e-5, atol=1e-6)
+        np.testing.assert_allclose(sums[model_off:model_off + KAM], s['vh_m'].ravel(), rtol=2e-5, atol=1e-6)
+        if ds:
+            np.testing.assert_allclose(sums[model_off + KAM:model_off + 2 * KAM], s['vh_mp'].ravel(), rtol=2e-5, atol=1e-6)
+        print("pooling ok", cid, (K, M, ds, pool))
+
+
 def test_free_energy():
     for cid in CASES:
         info, o = oracle_for(cid)
@@ -538,8 +632,8 @@ def test_hit_summary():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["encode_pack", "hgv", "vgh", "gibbs", "stats_mfma", "train_step", "two_ranks", "free_energy",
-                             "hit_summary"]
+    which = sys.argv[1:] or ["encode_pack", "hgv", "vgh", "gibbs", "stats_mfma", "train_step", "two_ranks", "pooling",
+                             "free_energy", "hit_summary"]
     for w in which:
         globals()["test_" + w]()
     print("EMU ALL OK")

@@ -697,6 +697,73 @@ def test_edge_shapes(K, M, ds, L, n):
     np.testing.assert_allclose(model.c.get_value(), o.c, rtol=RTOL, atol=5e-6)
 
 
+# ---- pooling > 1 (convRBM.py:245-267, :586-599, :664-665) ---------------------------------
+@pytest.mark.parametrize("K,M,ds,pool", [(6, 7, True, 2), (10, 15, False, 4), (5, 8, True, 3)])
+def test_pooling(K, M, ds, pool, capsys):
+    """Pooled hidden units: probabilities exp(x)/(pool + sum exp) over groups of `pool` positions, one
+    multinomial draw per group, free energy log(1 + sum exp), the PCD update with the pooled sparsity
+    slope, and fit()'s truncation -- each against the oracle (which is pinned for pooling by
+    tests/test_oracle.py: probability formula and finite differences of the penalty)."""
+    from crbm_amd import CRBM
+    Lf, B, n = 12 * pool, 8, 9
+    L = 10 * pool + M - 1
+    rng = np.random.default_rng(50 + K)
+    W = (rng.standard_normal((K, 1, 4, M)) * 0.8).astype(np.float32)
+    m = CRBM(K, M, doublestranded=ds, batchsize=B, cd_k=2, pooling=pool, fantasy_hidden_len=Lf, seed=11, rho=0.03)
+    o = OracleCRBM(K, M, doublestranded=ds, batchsize=B, cd_k=2, pooling=pool, fantasy_hidden_len=Lf, seed=11, rho=0.03, W=W)
+    b = (o.b + 4.0).astype(np.float32)
+    m.motifs.set_value(W)
+    m.bias.set_value(b)
+    o.b = b.astype(np.float64)
+    D = synthetic_onehot(n, L, seed=4)
+    # bottom-up: probability and sample (one draw per group)
+    P, S = m._computeHgivenV(D, rng_step=6)
+    Pref = o._bottomUpProbability(o._bottomUpActivity(D))
+    np.testing.assert_allclose(P, Pref, rtol=RTOL, atol=1e-7)
+    Lh = L - M + 1
+    u = hidden_uniforms(m.seed, 6, np.arange(n), K, Lh, 0, KIND_API_H)
+    Sref = o._bottomUpSample(Pref, u)
+    grp = S.reshape(n, K, 1, Lh // pool, pool)
+    assert np.all(grp.sum(axis=4) <= 1) and S.sum() > 0
+    bad = (S != Sref).reshape(n, K, 1, Lh // pool, pool).any(axis=4)
+    if bad.any():
+        cum = np.cumsum(Pref.reshape(n, K, 1, Lh // pool, pool), axis=4)
+        ug = u.reshape(n, K, 1, Lh // pool, pool)[..., :1]
+        assert np.all(np.min(np.abs(cum - ug), axis=4)[bad] < TIE)
+    # evaluation
+    np.testing.assert_allclose(m.motifHitProbs(D), o.motifHitProbs(D), rtol=RTOL, atol=1e-7)
+    np.testing.assert_allclose(m.freeEnergy(D), o.freeEnergy(D), rtol=RTOL)
+    np.testing.assert_allclose(m.freeEnergy(D, True), o.freeEnergy(D, True), rtol=RTOL, atol=1e-5)
+    with pytest.raises(Exception, match="pooling"):
+        m.freeEnergy(synthetic_onehot(2, L + 1, seed=1))          # hidden length not a multiple of pooling
+    # the chain and a training step
+    m.gibbsSteps(2)
+    o.gibbs_steps(2)
+    h, hp = m.get_fantasy()
+    assert (h != o.fantasy_h).mean() < 1e-4
+    assert np.all(h.reshape(B, K, 1, Lf // pool, pool).sum(axis=4) <= 1)
+    o.fantasy_h = h.astype(np.float64)
+    if ds:
+        assert (hp != o.fantasy_h_prime).mean() < 1e-4
+        o.fantasy_h_prime = hp.astype(np.float64)
+    m._trainingFct(D)
+    o.train_step(D)
+    np.testing.assert_allclose(m.motifs.get_value(), o.W, rtol=RTOL, atol=2e-6)
+    np.testing.assert_allclose(m.bias.get_value(), o.b, rtol=RTOL, atol=2e-6)
+    np.testing.assert_allclose(m.c.get_value(), o.c, rtol=RTOL, atol=2e-6)
+    # fit() truncates the sequences so that the hidden length divides (convRBM.py:586-599)
+    m.epochs = 1
+    m.fit(synthetic_onehot(20, L + 1, seed=8))
+    assert "Epoch 0: FE=" in capsys.readouterr().out
+
+
+def test_pooling_must_divide_the_chain_length():
+    from crbm_amd import CRBM
+    m = CRBM(4, 5, pooling=3)                     # the reference's chains are 200 long: 3 does not divide
+    with pytest.raises(Exception, match="pooling"):
+        m.gibbsSteps(1)
+
+
 # ---- SURVEY 8(f)-1/2: packed input and data-set scale sweeps ------------------------
 @pytest.mark.parametrize("ds", [False, True])
 def test_codes_input_equals_onehot(ds):

@@ -215,13 +215,16 @@ def test_statistics_bruteforce():
     np.testing.assert_allclose(av.sum(), 2.0)
 
 
-def test_sparsity_gradient_matches_finite_differences():
+@pytest.mark.parametrize("pooling", [1, 2, 3])
+def test_sparsity_gradient_matches_finite_differences(pooling):
+    """the closed form of T.grad(entropy penalty) (convRBM.py:440-451), for independent units and
+    for pooled groups (hidden length 18 = 21 - 4 + 1, divisible by 1, 2 and 3)"""
     rng = np.random.default_rng(12)
     K, M = 3, 4
-    model = OracleCRBM(K, M, doublestranded=True, rho=0.05,
+    model = OracleCRBM(K, M, doublestranded=True, rho=0.05, pooling=pooling,
                        W=rng.standard_normal((K, 1, 4, M)))
     model.b = model.b + rng.standard_normal((1, K)) * 0.1 + 3.0
-    data = synthetic_onehot(6, 20, seed=13)
+    data = synthetic_onehot(6, 21, seed=13)
     reg_W, reg_b = model._gradientSparsityConstraintEntropy(data)
     eps = 1e-6
     num_W = np.zeros_like(model.W)
