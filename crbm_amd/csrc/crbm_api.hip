@@ -142,6 +142,7 @@ struct crbm_handle {
   double activity = -1.0;              // fraction of hidden units on after the last launch that was read back
   int stats_rows = 0;
   bool fuse_stats = false;             // model half of the statistics inside the Gibbs kernel (Cfg::FUSE_STATS; CRBM_STATS=split: off)
+  bool one_launch = true;              // ... and the data half in the same launch (CRBM_STATS=two: separate launch)
   SumsLayout sl;
   // data parallel
   ncclComm_t comm = nullptr;
@@ -267,14 +268,12 @@ void use_variant(crbm_handle* h, int v) {
 
 StatsGeom stats_geom(const StatsMfmaLayout& st, float* partials, long ngroups, int lds_bytes);
 
-// with_stats: the fused variant -- the launch also leaves the model half of the gradient statistics
-// as one partial row per block in h->partials2 (reduction handed back through `model_reduce`)
-int launch_gibbs(crbm_handle* h, int steps, hipStream_t s = nullptr, ReduceArgs* model_reduce = nullptr) {
-  if (!s) s = h->stream;
-  int rc = ensure_tables(h);
-  if (rc) return rc;
+// Arguments of a Gibbs launch of `steps` steps.  model_reduce != null selects the STATS variant: the
+// launch also leaves the model half of the gradient statistics as one partial row per block in
+// h->partials2 and the column reduction is handed back through `model_reduce`.
+int prepare_gibbs(crbm_handle* h, int steps, ReduceArgs* model_reduce, GibbsArgs* out, unsigned* lds_out) {
   const bool with_stats = model_reduce != nullptr;
-  GibbsArgs a;
+  GibbsArgs& a = *out;
   a.tables = h->d_tables;
   a.hm = h->d_hm; a.hmp = h->ds ? h->d_hmp : nullptr; a.vout = h->d_vf;
   a.nchains = h->B; a.Lf = h->Lf; a.Lv = h->gl.Lv; a.S = h->gl.S;
@@ -288,17 +287,16 @@ int launch_gibbs(crbm_handle* h, int steps, hipStream_t s = nullptr, ReduceArgs*
   a.ones = h->d_nset;
   a.debug = env_int("CRBM_GIBBS_DEBUG", 0);
   h->nset_slots = h->gibbs_grid * (h->gibbs_threads / 64);
+  a.nblocks = h->gibbs_grid;
   a.stats_off = 0;
   a.sg = StatsGeom();
   unsigned lds = (unsigned)h->gl.lds_bytes;
-  hipFunction_t fn = h->variant ? h->jk.gibbs_sparse : h->jk.gibbs;
   if (with_stats) {
     const StatsMfmaLayout st = stats_mfma_layout(h->ms, 0, h->Lf, h->gibbs_threads, 0, false);
     HIPCHK(h->partials2.ensure((size_t)h->gibbs_grid * st.row));
     a.stats_off = (h->gl.lds_bytes / 4 + 3) & ~3;
     lds = (unsigned)std::max((a.stats_off + st.region_floats) * 4, st.combine_bytes);
     a.sg = stats_geom(st, h->partials2.p, (long)h->gl.S * st.GPC, (int)lds);
-    fn = h->jk.gibbs_sparse_stats;
     ReduceArgs& r = *model_reduce;
     r.partials = h->partials2.p;
     r.nrows = h->gibbs_grid; r.row = st.row;
@@ -307,6 +305,19 @@ int launch_gibbs(crbm_handle* h, int steps, hipStream_t s = nullptr, ReduceArgs*
     r.skip_begin = h->sl.model_skip_begin; r.skip_len = h->sl.model_skip_len;
     r.n_value = (float)h->B;
   }
+  *lds_out = lds;
+  return CRBM_OK;
+}
+
+int launch_gibbs(crbm_handle* h, int steps, hipStream_t s = nullptr, ReduceArgs* model_reduce = nullptr) {
+  if (!s) s = h->stream;
+  int rc = ensure_tables(h);
+  if (rc) return rc;
+  GibbsArgs a;
+  unsigned lds = 0;
+  rc = prepare_gibbs(h, steps, model_reduce, &a, &lds);
+  if (rc) return rc;
+  hipFunction_t fn = model_reduce ? h->jk.gibbs_sparse_stats : (h->variant ? h->jk.gibbs_sparse : h->jk.gibbs);
   HIPCHK(jit_launch(fn, a, (unsigned)h->gibbs_grid, 1, (unsigned)h->gibbs_threads, lds, s));
   h->gibbs_step += (uint32_t)steps;
   h->launches_since_read += 1;
@@ -342,22 +353,20 @@ StatsGeom stats_geom(const StatsMfmaLayout& st, float* partials, long ngroups, i
   return g;
 }
 
-// MFMA statistics kernel (stats_mfma_body): raw statistic sums of (letters, n, L) -> partial rows of the
-// data or the model half; the column reduction is handed back to the caller (`defer`, to pair it with the
-// other half) or launched here.
-int launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool data_half, hipStream_t s = nullptr,
-                 ReduceArgs* defer = nullptr) {
-  if (!s) s = h->stream;
+// Arguments of the MFMA statistics kernel (stats_mfma_body) for (letters, n, L): raw statistic sums ->
+// partial rows of the data or the model half.  `threads` 0: the kernel's own block size and the byte
+// LUT; otherwise the geometry of a host kernel it rides in (nibble LUT).
+int prepare_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool data_half, int threads,
+                  StatsMfmaArgs* out, int* lds_out, int* grid_out, int* block_out, ReduceArgs* reduce) {
   DevBuf<float>& pbuf = data_half ? h->partials : h->partials2;
-  int rc = ensure_tables(h);
-  if (rc) return rc;
   const int want_sp = data_half ? 1 : 0;
   const int Lh = L - h->M + 1;
   const int tabs = (1 + h->ds) * tab_bytes(h);
+  const bool own = threads <= 0;
   // CRBM_STATS_MAX_TILES is an experiment knob: it must come with CRBM_JIT_DEFINES=-DCRBM_STATS_MAX_TILES=<same>
-  const StatsMfmaLayout st = stats_mfma_layout(h->ms, want_sp, Lh, env_int("CRBM_STATS_THREADS", 0), tabs, true,
+  const StatsMfmaLayout st = stats_mfma_layout(h->ms, want_sp, Lh, own ? env_int("CRBM_STATS_THREADS", 0) : threads, tabs, own,
                                                env_int("CRBM_STATS_MAX_TILES", CRBM_STATS_MAX_TILES));
-  StatsMfmaArgs a;
+  StatsMfmaArgs& a = *out;
   a.tables = h->d_tables;
   a.letters = d_letters;
   a.n = n; a.L = L; a.Lh = Lh; a.LW = letter_words(L);
@@ -373,10 +382,10 @@ int launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool d
   const int cap = h->stats_rows > 0 ? h->stats_rows : h->num_cu * per_cu;
   const int gx = (int)std::max<long>(1, std::min<long>((nunits + wpr - 1) / wpr, cap));
   HIPCHK(pbuf.ensure((size_t)gx * st.row));
+  a.nblocks = gx;
   a.sg = stats_geom(st, pbuf.p, ngroups, lds);
-  HIPCHK(jit_launch(data_half ? h->jk.stats_mfma_data : h->jk.stats_mfma_model, a, (unsigned)gx, 1, (unsigned)st.threads,
-                    (unsigned)lds, s));
-  ReduceArgs r;
+  *lds_out = lds; *grid_out = gx; *block_out = st.threads;
+  ReduceArgs& r = *reduce;
   r.partials = pbuf.p;
   r.nrows = gx; r.row = st.row;
   r.K = h->K; r.KAM = h->KAM; r.ds = h->ds; r.want_sparsity = want_sp;
@@ -388,8 +397,25 @@ int launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool d
     r.skip_begin = h->sl.model_skip_begin; r.skip_len = h->sl.model_skip_len;
   }
   r.n_value = (float)n;
+  return CRBM_OK;
+}
+
+// stand-alone launch; the column reduction is handed back to the caller (`defer`, to pair it with the
+// other half) or launched here
+int launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool data_half, hipStream_t s = nullptr,
+                 ReduceArgs* defer = nullptr) {
+  if (!s) s = h->stream;
+  int rc = ensure_tables(h);
+  if (rc) return rc;
+  StatsMfmaArgs a;
+  ReduceArgs r;
+  int lds = 0, gx = 0, block = 0;
+  rc = prepare_stats(h, d_letters, n, L, data_half, 0, &a, &lds, &gx, &block, &r);
+  if (rc) return rc;
+  HIPCHK(jit_launch(data_half ? h->jk.stats_mfma_data : h->jk.stats_mfma_model, a, (unsigned)gx, 1, (unsigned)block,
+                    (unsigned)lds, s));
   if (defer) { *defer = r; return CRBM_OK; }
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((st.row + 31) / 32), dim3(1024), 0, s, r);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((r.row + 31) / 32), dim3(1024), 0, s, r);
   HIPCHK(hipGetLastError());
   return CRBM_OK;
 }
@@ -430,6 +456,26 @@ int train_local_dev(crbm_handle* h, const uint32_t* d_letters, int n, int L) {
   // single stream: the two column reductions share one launch
   ReducePair pair;
   const bool paired = !h->overlap && n > 0;
+  if (h->fuse_stats && paired && h->one_launch) {
+    // the whole local phase in one launch (train_local_body): chain + model half in the first
+    // gibbs_grid blocks, data half in the blocks behind them
+    TrainLocalArgs t;
+    unsigned glds = 0;
+    rc = prepare_gibbs(h, h->cfg.cd_k, &pair.half[1], &t.g, &glds);
+    if (rc) return rc;
+    int dlds = 0, dgrid = 0, dblock = 0;
+    rc = prepare_stats(h, d_letters, n, L, true, h->gibbs_threads, &t.d, &dlds, &dgrid, &dblock, &pair.half[0]);
+    if (rc) return rc;
+    const unsigned lds = std::max(glds, (unsigned)dlds);
+    t.g.sg.lds_floats = (int)(lds / 4);
+    t.d.sg.lds_floats = (int)(lds / 4);
+    HIPCHK(jit_launch(h->jk.train_local, t, (unsigned)(h->gibbs_grid + dgrid), 1, (unsigned)h->gibbs_threads, lds, h->stream));
+    h->gibbs_step += (uint32_t)h->cfg.cd_k;
+    h->launches_since_read += 1;
+    hipLaunchKernelGGL(reduce_partials_pair_kernel, dim3((pair.half[0].row + 31) / 32, 2), dim3(1024), 0, h->stream, pair);
+    HIPCHK(hipGetLastError());
+    return CRBM_OK;
+  }
   if (h->fuse_stats) {
     // the Gibbs launch itself leaves the model half of the statistics (last-step probabilities
     // and visible sample never leave the chip)
@@ -696,6 +742,7 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
   {
     const char* sv = getenv("CRBM_STATS");
     hh->fuse_stats = hh->ms.FUSE_STATS && hh->variant == 1 && !(sv && !strcmp(sv, "split"));
+    hh->one_launch = !(sv && !strcmp(sv, "two"));
     if (hh->fuse_stats) {   // the fused launch appends the statistics slices to the chain image: it must fit the LDS
       const StatsMfmaLayout st = stats_mfma_layout(hh->ms, 0, hh->Lf, hh->gibbs_threads, 0, false);
       const int lds = std::max((((hh->gl.lds_bytes / 4 + 3) & ~3) + st.region_floats) * 4, st.combine_bytes);

@@ -27,7 +27,7 @@ namespace crbm {
 struct JitKernels {
   hipModule_t module = nullptr;
   hipFunction_t build_tables = nullptr, update_tables = nullptr, hgv = nullptr, gibbs = nullptr /* dense top-down; null if the model has none */,
-                gibbs_sparse = nullptr, gibbs_sparse_stats = nullptr /* null unless Cfg::FUSE_STATS */, stats_mfma_data = nullptr, stats_mfma_model = nullptr,
+                gibbs_sparse = nullptr, gibbs_sparse_stats = nullptr /* empty unless Cfg::FUSE_STATS */, train_local = nullptr /* ditto */, stats_mfma_data = nullptr, stats_mfma_model = nullptr,
                 free_energy = nullptr, hit_summary = nullptr;
   bool from_cache = false;
   std::string cache_file;
@@ -73,7 +73,7 @@ inline std::string jit_stub(int K, int M, int DS, int G, int POOL, int gibbs_wpe
   // kernel's geometry (4 blocks of 4 waves per CU for small models): cap it at 128 registers there
   if (gibbs_wpe > 0) snprintf(sattr, sizeof(sattr), "__attribute__((amdgpu_waves_per_eu(1, %d)))", gibbs_wpe);
   else snprintf(sattr, sizeof(sattr), "__attribute__((amdgpu_waves_per_eu(4)))");
-  char buf[8192];
+  char buf[12288];
   snprintf(buf, sizeof(buf),
            "#include \"crbm_kernels.h\"\n"
            "#ifndef CRBM_GIBBS_ATTR\n#define CRBM_GIBBS_ATTR %s\n#endif\n"
@@ -84,6 +84,7 @@ inline std::string jit_stub(int K, int M, int DS, int G, int POOL, int gibbs_wpe
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_hgv(crbm::HgvArgs a) { crbm::hgv_body<ModelCfg>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) CRBM_GIBBS_ATTR crbm_gibbs_sparse(crbm::GibbsArgs a) { crbm::gibbs_body<ModelCfg, true>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) CRBM_GIBBS_STATS_ATTR crbm_gibbs_sparse_stats(crbm::GibbsArgs a) { if constexpr (ModelCfg::FUSE_STATS) crbm::gibbs_body<ModelCfg, true, true>(a); }\n"
+           "extern \"C\" __global__ void __launch_bounds__(256) CRBM_GIBBS_STATS_ATTR crbm_train_local(crbm::TrainLocalArgs a) { crbm::train_local_body<ModelCfg>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_gibbs(crbm::GibbsArgs a) { if constexpr (ModelCfg::DENSE) crbm::gibbs_body<ModelCfg, ModelCfg::DENSE ? false : true>(a); }\n"
            "using RoleData = crbm::StatsRole<ModelCfg, true>;\nusing RoleModel = crbm::StatsRole<ModelCfg, false>;\n"
            "extern \"C\" __global__ void __launch_bounds__(RoleData::THREADS) crbm_stats_mfma_data(crbm::StatsMfmaArgs a) { crbm::stats_mfma_body<ModelCfg, true>(a); }\n"
@@ -178,7 +179,7 @@ inline int jit_load(int K, int M, int DS, int G, int POOL, int gibbs_wpe, JitKer
   }
   struct { const char* name; hipFunction_t* f; } syms[] = {
       {"crbm_build_tables", &out->build_tables}, {"crbm_update_tables", &out->update_tables}, {"crbm_hgv", &out->hgv}, {"crbm_gibbs", &out->gibbs},
-      {"crbm_gibbs_sparse", &out->gibbs_sparse}, {"crbm_gibbs_sparse_stats", &out->gibbs_sparse_stats},
+      {"crbm_gibbs_sparse", &out->gibbs_sparse}, {"crbm_gibbs_sparse_stats", &out->gibbs_sparse_stats}, {"crbm_train_local", &out->train_local},
       {"crbm_stats_mfma_data", &out->stats_mfma_data},
       {"crbm_stats_mfma_model", &out->stats_mfma_model}, {"crbm_free_energy", &out->free_energy},
       {"crbm_hit_summary", &out->hit_summary}};

@@ -592,7 +592,7 @@ struct StatsGeom {
   int32_t lds_floats;                            // dynamic LDS of the launch (the end-of-kernel combine uses all of it)
   FastDiv divGPC;
   int32_t row, off_vh0, off_vh1, off_h0, off_h1, off_sw, off_sb, off_v;
-  float* partials;                               // [gridDim.x][row]
+  float* partials;                               // [blocks of the statistics grid][row]
 };
 
 // kinds, motif tiles per wave, roles; mirrors stats_mfma_layout()
@@ -730,7 +730,7 @@ __device__ __forceinline__ void stats_mfma_group(const float* Pt, const uint2* w
 // geometry of a block.
 // Uses the LDS of the block from its base on (everything is dead by now); all threads call it.
 template <class C, bool SP>
-__device__ __forceinline__ void stats_mfma_finish(const StatsGeom& sg, float* lds, int nt0,
+__device__ __forceinline__ void stats_mfma_finish(const StatsGeom& sg, float* lds, int nt0, int block_row,
                                                   const floatx4 (&acc)[StatsRole<C, SP>::NACC], float vcount) {
   using R = StatsRole<C, SP>;
   constexpr int K = C::K, M = C::M, KAM = K * 4 * M, KINDS = R::KINDS, NTW = R::NTW, NR = R::NR, KW = R::KW;
@@ -742,7 +742,7 @@ __device__ __forceinline__ void stats_mfma_finish(const StatsGeom& sg, float* ld
   float* wbuf = xch + 64;
   int cw = min(nwaves, (sg.lds_floats - KAM - 64) / PW);   // waves parked at a time: whole sets of roles
   cw = max(NR, cw / NR * NR);
-  float* out = sg.partials + (size_t)blockIdx.x * sg.row;
+  float* out = sg.partials + (size_t)block_row * sg.row;
   __syncthreads();
 #pragma unroll
   for (int kind = 0; kind < KINDS; ++kind) {
@@ -802,6 +802,7 @@ struct StatsMfmaArgs {
   int32_t off_tab;      // gather tables inside LDS (floats), after the slices
   int32_t debug;        // profiling only (results are wrong when set): 1 skips the MFMA steps, 2 the h|v arithmetic, 4 the
                         // staging, 8 the combine + output, 16 the table copy, 32 the whole loop
+  int32_t nblocks;      // blocks of the statistics grid (0: the whole launch)
   StatsGeom sg;
 };
 
@@ -810,8 +811,8 @@ struct StatsMfmaArgs {
 // in the Gibbs kernel.  A wave loops over units of two groups: lanes 0-7 stage the groups'
 // letter words (fetched one unit ahead) and build the letter windows, every lane computes P of
 // one hidden position for the wave's motifs and parks it transposed, then the MFMA steps run.
-template <class C, bool SP>
-__device__ void stats_mfma_body(const StatsMfmaArgs& a) {
+template <class C, bool SP, bool BYTE_LUT = true>
+__device__ void stats_mfma_body(const StatsMfmaArgs& a, int bid = -1) {   // bid: block of the statistics grid (default: blockIdx.x)
   using R = StatsRole<C, SP>;
   constexpr int K = C::K, M = C::M, KINDS = R::KINDS, NTW = R::NTW, NR = R::NR, KW = R::KW;
   HIP_DYNAMIC_SHARED(float, smem);
@@ -827,7 +828,7 @@ __device__ void stats_mfma_body(const StatsMfmaArgs& a) {
   if (!(a.debug & 16)) {
     copy_tables<C::TAB>(Tf, a.tables + C::OFF_TF);
     if (C::DS) copy_tables<C::TAB>(Tr, a.tables + C::OFF_TR);
-    stats_build_lut<true>(lut);
+    stats_build_lut<BYTE_LUT>(lut);
     for (int i = lane; i < R::ROWS * STATS_RS; i += 64) Pt[i] = 0.f;   // the zero row (and the pad columns) stay zero
   }
   __syncthreads();
@@ -842,7 +843,9 @@ __device__ void stats_mfma_body(const StatsMfmaArgs& a) {
   const int GPC = sg.GPC;
   const int ngroups = a.n * GPC;                       // the host keeps n * GPC below 2^31
   const int nunits = (ngroups + 1) / 2;
-  const int ustride = (int)gridDim.x * waves_per_role;
+  if (bid < 0) bid = (int)blockIdx.x;
+  const int nblk = a.nblocks > 0 ? a.nblocks : (int)gridDim.x;
+  const int ustride = nblk * waves_per_role;
   // letter words of a unit: lane t < 32 fetches word (t >> 2) & 3 of group slot (t >> 4) (four lanes,
   // one per letter, fetch the same word: one transaction) and later turns it into its window piece
   unsigned short* win16 = reinterpret_cast<unsigned short*>(win);
@@ -854,7 +857,7 @@ __device__ void stats_mfma_body(const StatsMfmaArgs& a) {
     const int w = 2 * (G - (int)chain * GPC) + ((lane >> 2) & 3);
     return w < a.LW ? a.letters[(size_t)chain * a.LW + w] : 0u;
   };
-  int u = (int)blockIdx.x * waves_per_role + wave_in_role;
+  int u = bid * waves_per_role + wave_in_role;
   if (a.debug & 32) u = nunits;
   uint32_t pre = fetch_word(u);
   for (; u < nunits; u += ustride) {
@@ -934,11 +937,11 @@ __device__ void stats_mfma_body(const StatsMfmaArgs& a) {
 #pragma unroll
     for (int slot = 0; slot < 2; ++slot)
       if (G0 + slot < ngroups && !(a.debug & 1))
-        stats_mfma_group<C, KINDS, NTW, true>(Pt, win + 4 * slot, lut, nt0, slot, acc);
+        stats_mfma_group<C, KINDS, NTW, BYTE_LUT>(Pt, win + 4 * slot, lut, nt0, slot, acc);
     __builtin_amdgcn_wave_barrier();                   // the slice is rewritten by the next unit
   }
   if (a.debug & 8) return;
-  stats_mfma_finish<C, SP>(sg, smem, nt0, acc, vcount);
+  stats_mfma_finish<C, SP>(sg, smem, nt0, bid, acc, vcount);
 }
 
 // ---------------------------------------------------------------------------
@@ -961,6 +964,7 @@ struct GibbsArgs {
   uint32_t* ones;      // [gridDim.x * waves per block] set bits of the final hidden state per wave (activity monitor), may be null
   int32_t debug;       // profiling only: 1 skips the table copy, 2 the state load, 4 the state store
   // STATS variant only: the model half of the gradient statistics rides in the last h|v pass
+  int32_t nblocks;     // blocks [0, nblocks) of the launch run the chain (0: the whole grid)
   int32_t stats_off;   // statistics region inside LDS (floats, 16-byte aligned), after the chain image
   StatsGeom sg;        // divGPC divides group indices of one tile
 };
@@ -1013,7 +1017,7 @@ __device__ __forceinline__ void topdown_bits(unsigned long long w, const char* t
 // registers anyway in the wave's LDS slice, and the wave contracts them with the visible
 // sample (still in LDS) on the matrix cores -- no second read of v, no recomputation of P.
 template <class C, bool SPARSE, bool STATS = false>
-__device__ void gibbs_body(const GibbsArgs& a) {
+__device__ void gibbs_body(const GibbsArgs& a, int bid = -1) {   // bid: block of the chain grid (default: blockIdx.x)
   constexpr int KP = C::KP, M = C::M, NW = C::NW, NCH = C::NCH;
   static_assert(SPARSE || C::DENSE, "no dense top-down tables for this model");
   using SR = StatsRole<C, false>;
@@ -1039,6 +1043,8 @@ __device__ void gibbs_body(const GibbsArgs& a) {
   const int rowW = a.Lrow * NW;
   const uint32_t per = (uint32_t)(a.Lf * NW);           // state words per chain
   const int ntiles = (a.nchains + a.S - 1) / a.S;
+  if (bid < 0) bid = (int)blockIdx.x;
+  const int nblk = a.nblocks > 0 ? a.nblocks : (int)gridDim.x;
   int nset = 0;
   // statistics state (STATS): the wave's LDS slice, accumulator tiles, letter counts
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
@@ -1067,7 +1073,7 @@ __device__ void gibbs_body(const GibbsArgs& a) {
       if (C::DS) hmp[d] = 0u;
     }
   }
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  for (int tile = bid; tile < ntiles; tile += nblk) {
     const int n0 = tile * a.S;
     const int ns = min(a.S, a.nchains - n0);
     __syncthreads();
@@ -1351,9 +1357,31 @@ __device__ void gibbs_body(const GibbsArgs& a) {
   }
   if (a.ones) {   // one plain store per wave, summed by the host (counts stay far below 2^24: exact in float)
     const float tot = wave_sum((float)nset);
-    if ((threadIdx.x & 63) == 0) a.ones[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = (uint32_t)tot;
+    if ((threadIdx.x & 63) == 0) a.ones[bid * (blockDim.x >> 6) + (threadIdx.x >> 6)] = (uint32_t)tot;
   }
-  if constexpr (STATS) stats_mfma_finish<C, false>(a.sg, smem, 0, sacc, vcount);
+  if constexpr (STATS) stats_mfma_finish<C, false>(a.sg, smem, 0, bid, sacc, vcount);
+}
+
+// The local phase of a training step in ONE launch (convRBM.py:373-413): g.nblocks blocks advance the
+// persistent chains and leave the model half of the statistics (gibbs_body, STATS variant), d.nblocks
+// blocks compute the data half (stats_mfma_body with the sparsity columns) -- the two halves are
+// independent given (W, b, c).  Same block size, similar LDS footprint; the two kinds alternate in
+// the grid, so every CU runs chain blocks (VALU and LDS gathers) beside statistics blocks (matrix
+// pipe) from the first cycle, and there is no second launch floor and no idle tail between them.
+struct TrainLocalArgs {
+  GibbsArgs g;
+  StatsMfmaArgs d;
+};
+
+template <class C>
+__device__ void train_local_body(const TrainLocalArgs& a) {
+  if constexpr (C::FUSE_STATS) {
+    const int nG = a.g.nblocks, nD = a.d.nblocks, m = min(nG, nD), b = (int)blockIdx.x;
+    const bool chain = b < 2 * m ? !(b & 1) : nG > nD;      // alternate while both kinds last, then the rest
+    const int idx = b < 2 * m ? b >> 1 : b - m;
+    if (chain) gibbs_body<C, true, true>(a.g, idx);
+    else stats_mfma_body<C, true, false>(a.d, idx);
+  }
 }
 
 // ---------------------------------------------------------------------------

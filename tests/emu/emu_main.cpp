@@ -144,7 +144,7 @@ int emu_gibbs(int id, const float* tables, uint32_t* hm, uint32_t* hmp, uint32_t
               int steps, uint64_t seed, uint32_t step, uint32_t off, int grid, int threads, int sparse,
               uint32_t* ones) {
   GibbsArgs a;
-  a.tables = tables; a.hm = hm; a.hmp = hmp; a.vout = vout; a.ones = ones; a.debug = 0;
+  a.tables = tables; a.hm = hm; a.hmp = hmp; a.vout = vout; a.ones = ones; a.debug = 0; a.nblocks = 0; a.stats_off = 0;
   a.nchains = nchains; a.Lf = Lf; a.S = S; a.steps = steps; a.rng = make_rng(seed, step, off);
   int lws = -1;
   CFG_DISPATCH(id, {
@@ -220,6 +220,7 @@ int emu_stats_mfma(int id, const float* tables, const uint32_t* letters, int n, 
     for (size_t i = 0; i < (size_t)gx * st.row; ++i) partials[i] = 1e30f;   // never cleared on the GPU either
     a.off_tab = st.region_floats;
     a.debug = 0;
+    a.nblocks = 0;
     const size_t lds = std::max((size_t)st.region_floats * 4 + (size_t)(1 + C::DS) * C::TAB * 4, (size_t)st.combine_bytes);
     a.sg = geom_of(st, partials, ngroups, lds);
     if (want_sparsity) emu::launch([&] { stats_mfma_body<C, true>(a); }, dim3(gx), dim3(st.threads), lds);
@@ -259,13 +260,69 @@ static int run_gibbs_stats(GibbsArgs a, int Lf, int S, int grid, int threads, fl
   }
 }
 
+// The whole local phase of a training step in one launch (train_local_body): chain + model half in
+// `ggrid` blocks, data half in `dgrid` blocks, interleaved; both partial sets reduced on the host.
+template <class C>
+static int run_train_local(GibbsArgs g, int Lf, int S, int ggrid, int dgrid, int threads, const uint32_t* letters, int n, int L,
+                           int LW, float* partials_m, float* partials_d, int cap, float* sums_d, float* sums_m, int skip_begin,
+                           int skip_len) {
+  if constexpr (C::FUSE_STATS) {
+    const ModelShape ms = shape_of<C>();
+    const GibbsLayout gl = gibbs_layout(ms, Lf, S, true);
+    g.Lv = gl.Lv; g.nvb = gl.nvb; g.nhb = gl.nhb; g.Lrow = gl.Lrow; g.LWs = gl.LWs;
+    g.divVB = make_fastdiv((uint32_t)gl.nvb); g.divHB = make_fastdiv((uint32_t)gl.nhb);
+    g.divRow = make_fastdiv((uint32_t)(gl.Lrow * ms.NW)); g.divLfw = make_fastdiv((uint32_t)(Lf * ms.NW));
+    if (!C::DS) g.hmp = nullptr;
+    const StatsMfmaLayout sm = stats_mfma_layout(ms, 0, Lf, threads, 0, false);
+    const int tabs = (1 + C::DS) * C::TAB * 4, Lh = L - C::M + 1;
+    const StatsMfmaLayout sd = stats_mfma_layout(ms, 1, Lh, threads, tabs, false);
+    const long ngroups = (long)n * sd.GPC;
+    const int wpr = (sd.threads / 64) / sd.NR;
+    const long nunits = (ngroups + 1) / 2;
+    if (dgrid > (nunits + wpr - 1) / wpr) dgrid = (int)((nunits + wpr - 1) / wpr);
+    if ((long)ggrid * sm.row > cap || (long)dgrid * sd.row > cap) return -2;
+    for (size_t i = 0; i < (size_t)ggrid * sm.row; ++i) partials_m[i] = 1e30f;
+    for (size_t i = 0; i < (size_t)dgrid * sd.row; ++i) partials_d[i] = 1e30f;
+    g.nblocks = ggrid;
+    g.stats_off = (gl.lds_bytes / 4 + 3) & ~3;
+    const size_t glds = std::max((size_t)(g.stats_off + sm.region_floats) * 4, (size_t)sm.combine_bytes);
+    const size_t dlds = std::max((size_t)sd.region_floats * 4 + tabs, (size_t)sd.combine_bytes);
+    const size_t lds = std::max(glds, dlds);
+    g.sg = geom_of(sm, partials_m, (long)S * sm.GPC, lds);
+    TrainLocalArgs t;
+    t.g = g;
+    t.d.tables = g.tables; t.d.letters = letters; t.d.n = n; t.d.L = L; t.d.Lh = Lh; t.d.LW = LW;
+    t.d.off_tab = sd.region_floats; t.d.debug = 0; t.d.nblocks = dgrid;
+    t.d.sg = geom_of(sd, partials_d, ngroups, lds);
+    emu::launch([&] { train_local_body<C>(t); }, dim3(ggrid + dgrid), dim3(threads), lds);
+    host_reduce(partials_m, ggrid, sm.row, C::K, C::K * 4 * C::M, C::DS, 0, skip_begin, skip_len, (float)g.nchains, sums_m);
+    host_reduce(partials_d, dgrid, sd.row, C::K, C::K * 4 * C::M, C::DS, 1, -1, 0, (float)n, sums_d);
+    return sm.row;
+  } else {
+    return -3;
+  }
+}
+
+extern "C" int emu_train_local(int id, const float* tables, uint32_t* hm, uint32_t* hmp, uint32_t* vout, int nchains, int Lf, int S,
+                               int steps, uint64_t seed, uint32_t step, uint32_t off, int ggrid, int dgrid, int threads,
+                               const uint32_t* letters, int n, int L, int LW, float* partials_m, float* partials_d, int cap,
+                               float* sums_d, float* sums_m, int skip_begin, int skip_len) {
+  GibbsArgs g;
+  g.tables = tables; g.hm = hm; g.hmp = hmp; g.vout = vout; g.ones = nullptr; g.debug = 0;
+  g.nchains = nchains; g.Lf = Lf; g.S = S; g.steps = steps; g.rng = make_rng(seed, step, off);
+  int row = -1;
+  CFG_DISPATCH(id, row = run_train_local<C>(g, Lf, S, ggrid, dgrid, threads, letters, n, L, LW, partials_m, partials_d, cap,
+                                            sums_d, sums_m, skip_begin, skip_len));
+  return row;
+}
+
 extern "C" {
 
 int emu_gibbs_stats(int id, const float* tables, uint32_t* hm, uint32_t* hmp, uint32_t* vout, int nchains, int Lf, int S,
                     int steps, uint64_t seed, uint32_t step, uint32_t off, int grid, int threads, float* partials,
                     int partials_cap, float* sums, int skip_begin, int skip_len) {
   GibbsArgs a;
-  a.tables = tables; a.hm = hm; a.hmp = hmp; a.vout = vout; a.ones = nullptr; a.debug = 0;
+  a.tables = tables; a.hm = hm; a.hmp = hmp; a.vout = vout; a.ones = nullptr; a.debug = 0; a.nblocks = 0;
   a.nchains = nchains; a.Lf = Lf; a.S = S; a.steps = steps; a.rng = make_rng(seed, step, off);
   int row = -1;
   CFG_DISPATCH(id, row = run_gibbs_stats<C>(a, Lf, S, grid, threads, partials, partials_cap, sums, skip_begin, skip_len));

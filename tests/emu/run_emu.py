@@ -305,6 +305,22 @@ def test_train_step():
         fused = r != -3
         if fused:
             assert r == row, r
+            # ... and the whole local phase in ONE launch (chain + model half and data half interleaved)
+            # must give the same chains and the same sums as the two launches above
+            hm1, _ = pack_hidden(f32(o.fantasy_h), NW)
+            hmp1 = pack_hidden(f32(o.fantasy_h_prime), NW)[0] if ds else np.zeros_like(hm1)
+            vout1 = np.zeros((B, lws), dtype=np.uint32)
+            sums1 = np.zeros(count, dtype=np.float32)
+            pm, pd = np.zeros(32 * row, dtype=np.float32), np.zeros(32 * row, dtype=np.float32)
+            r1 = lib.emu_train_local(cid, fp(tables), up(hm1), up(hmp1), up(vout1), B, Lf, 2, o.cd_k,
+                                     ctypes.c_uint64(o.seed), o.gibbs_step, o.seq_offset, 2, 3, threads,
+                                     up(letters), n, L, lib.emu_letter_words(L), fp(pm), fp(pd), pm.size,
+                                     fp(sums1[data_off:]), fp(sums1[model_off:]), skipb, skipl)
+            assert r1 == row, r1
+            assert np.array_equal(hm1, hm) and np.array_equal(hmp1, hmp) and np.array_equal(vout1, vout)
+            np.testing.assert_allclose(sums1[data_off:n_d], sums[data_off:n_d], rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(sums1[model_off:n_m], sums[model_off:n_m], rtol=1e-5, atol=1e-6)
+            assert sums1[n_d] == n and sums1[n_m] == B
             v = np.zeros((B, 1, 4, Lv), dtype=np.float32)
             lib.emu_decode(up(vout), fp(v), B, Lv, lws, 2)
             h_after = unpack_hidden(hm, K)

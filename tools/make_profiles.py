@@ -1,0 +1,57 @@
+"""Copies the evidence collected by tools/runs/evidence.sh (gpurun_out/<tag>/) into profiles/ under
+round-prefixed names and regenerates profiles/gibbs_traffic.json (what bench.py quotes as
+roofline.traffic) from the PMC passes of the Gibbs-only run.
+usage: python tools/make_profiles.py gpurun_out/<tag> r02"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+src, rnd = sys.argv[1], sys.argv[2]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+dst = os.path.join(ROOT, "profiles")
+
+
+def cp(a, b):
+    if os.path.exists(os.path.join(src, a)):
+        shutil.copy(os.path.join(src, a), os.path.join(dst, "%s_%s" % (rnd, b)))
+        print("profiles/%s_%s" % (rnd, b))
+
+
+cp("bench_cfg2.json", "bench_cfg2.json")
+cp("bench_cfg4.json", "bench_cfg4.json")
+cp("bench_cfg5.json", "bench_cfg5.json")
+cp("bench_cfg2_under_rocprof.json", "bench_cfg2_under_rocprof.json")
+cp("prof_bench/bench_kernel_stats.csv", "bench_cfg2_kernel_stats.csv")
+cp("gibbs_steps_per_launch_scan.txt", "gibbs_steps_per_launch_scan.txt")
+cp("pmc_summary.txt", "pmc_summary.txt")
+cp("pytest.log", "gpu_tests.log")
+
+# Gibbs traffic per config from the FETCH_SIZE / WRITE_SIZE / instruction passes of tools/prof_gibbs.py
+out = {}
+for cfg in ("cfg2", "cfg4", "cfg5"):
+    vals = {}
+    for p, names in (("f", ["FETCH_SIZE"]), ("w", ["WRITE_SIZE"]), ("a", ["SQ_INSTS_VALU", "SQ_INSTS_LDS"])):
+        for f in glob.glob(os.path.join(src, "pmc_gibbs_%s_%s" % (cfg, p), "**", "*counter_collection.csv"), recursive=True):
+            acc = defaultdict(lambda: defaultdict(float))
+            for r in csv.DictReader(open(f)):
+                if r["Kernel_Name"].startswith("crbm_gibbs") and r["Counter_Name"] in names:
+                    acc[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+            for name in acc:
+                ids = sorted(acc[name], key=int)
+                ids = ids[len(ids) // 4:]
+                vals[name] = sum(acc[name][i] for i in ids) / len(ids)
+    if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+        out[cfg] = {
+            "hbm_bytes_per_launch": int((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024),
+            "fetch_size_kb_raw": vals["FETCH_SIZE"], "write_size_kb": vals["WRITE_SIZE"],
+            "correction": "gfx950 FETCH_SIZE reports 1/2 of a wide coalesced streaming read (MI355X_MICROARCH.md, HBM): doubled",
+            "valu_wave_insts_per_launch": vals.get("SQ_INSTS_VALU"), "lds_wave_insts_per_launch": vals.get("SQ_INSTS_LDS"),
+            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / SQ_INSTS_* (separate passes) of python3 tools/prof_gibbs.py %s "
+                      "(tools/runs/evidence.sh; profiles/%s_pmc_summary.txt)" % (cfg, rnd),
+        }
+json.dump(out, open(os.path.join(dst, "gibbs_traffic.json"), "w"), indent=1)
+print("profiles/gibbs_traffic.json", sorted(out))
