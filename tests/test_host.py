@@ -165,3 +165,56 @@ def test_codes_detection():
     assert CRBM._is_codes(np.zeros((3, 9), np.uint8))
     assert not CRBM._is_codes(np.zeros((3, 1, 4, 9), np.float32))
     assert not CRBM._is_codes(np.zeros((3, 9), np.float32))
+
+
+def test_limits_are_refused_at_construction():
+    """K > 64 and M > 32 must not wait for the middle of fit()."""
+    from crbm_amd import CRBM
+    with pytest.raises(Exception, match="num_motifs > 64"):
+        CRBM(65, 5)
+    with pytest.raises(Exception, match="motif_length > 32"):
+        CRBM(4, 33)
+    CRBM(64, 32, pooling=4)                   # the largest model, pooled: fine until a GPU is needed
+
+
+def test_shape_checks_before_the_c_side_reads(monkeypatch):
+    """set_fantasy / set_velocities hand raw pointers to C, which reads B*K*Lf floats."""
+    from crbm_amd import CRBM
+    m = CRBM(3, 4, batchsize=8, fantasy_hidden_len=10)
+    monkeypatch.setattr(m, "_h", lambda: None)           # no GPU here: the checks must fire before any call
+    monkeypatch.setattr(m, "_call", lambda *a: (_ for _ in ()).throw(AssertionError("reached the library")))
+    with pytest.raises(ValueError, match="expected shape"):
+        m.set_fantasy(np.zeros((4, 3, 1, 10), dtype=np.float32), np.zeros((4, 3, 1, 10), dtype=np.float32))
+    with pytest.raises(ValueError, match="expected shape"):
+        m.set_velocities(np.zeros((3, 1, 4, 5)), np.zeros((1, 3)), np.zeros((1, 4)))
+    with pytest.raises(ValueError, match="hid_prime"):
+        m.set_fantasy(np.zeros((8, 3, 1, 10), dtype=np.float32))
+
+
+def test_load_state_defers_device_state(tmp_path):
+    """loadState must leave the model attachable: nothing touches the GPU until the handle is made."""
+    import joblib
+    from crbm_amd import CRBM
+    K, M, B, Lf = 3, 4, 8, 16
+    rng = np.random.default_rng(0)
+    fh = rng.binomial(1, 0.2, size=(B, K, 1, Lf)).astype(np.uint8)
+    extra = {"velocities": (np.zeros((K, 1, 4, M), np.float32), np.zeros((1, K), np.float32), np.zeros((1, 4), np.float32)),
+             "fantasy_bits": (np.packbits(fh, axis=3), np.packbits(fh[::-1], axis=3)), "fantasy_hidden_len": Lf,
+             "world_size": 2, "rng": (77, 5, 1)}
+    m0 = CRBM(K, M, batchsize=B, fantasy_hidden_len=Lf)
+    params = (m0.motifs.get_value(), m0.bias.get_value(), m0.c.get_value())
+    hyper = (K, M, 4, True, B, 0.1, 0.95, m0.rho, 0.1, 1, 5, 100, 'entropy')
+    fn = str(tmp_path / "s.pkl")
+    joblib.dump((params, hyper, extra), fn, protocol=2)
+    m = CRBM.loadState(fn)
+    assert m._handle is None and m._pending_state is not None and m.seed == 77
+    got = []
+    m.rank, m.world_size = 1, 2                          # as dist.attach would set them
+    m.set_velocities = lambda *a: got.append(("v",))
+    m.set_fantasy = lambda h, hp: got.append(("f", h, hp))
+    m.set_rng = lambda *a: got.append(("r", a))
+    m._install_state(m._pending_state)
+    f = [g for g in got if g[0] == "f"][0]
+    np.testing.assert_array_equal(f[1], fh[4:8].astype(np.float32))      # rank 1 of 2 takes chains 4..7
+    np.testing.assert_array_equal(f[2], fh[::-1][4:8].astype(np.float32))
+    assert [g for g in got if g[0] == "r"][0][1] == (77, 5, 1)

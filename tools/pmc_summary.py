@@ -8,7 +8,7 @@ import sys
 from collections import defaultdict
 
 root = sys.argv[1]
-KERNELS = ("crbm_gibbs_sparse_stats", "crbm_gibbs_sparse", "crbm_gibbs", "crbm_stats_mfma_data", "crbm_stats_mfma_model",
+KERNELS = ("crbm_train_local", "crbm_gibbs_sparse_stats", "crbm_gibbs_sparse", "crbm_gibbs", "crbm_stats_mfma_data", "crbm_stats_mfma_model",
            "crbm_update_tables", "crbm::reduce_partials_pair_kernel")
 for cfg in ("cfg2", "cfg4", "cfg5"):
     for run in ("train", "gibbs"):
