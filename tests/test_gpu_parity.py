@@ -24,7 +24,7 @@ def make_pair(K, M, ds=True, batchsize=8, cd_k=2, Lf=200, seed=5, wscale=1.0, bs
     W = (rng.standard_normal((K, 1, 4, M)) * wscale).astype(np.float32)
     m = CRBM(K, M, doublestranded=ds, batchsize=batchsize, cd_k=cd_k, fantasy_hidden_len=Lf, seed=seed, **kw)
     o = OracleCRBM(K, M, doublestranded=ds, batchsize=batchsize, cd_k=cd_k, fantasy_hidden_len=Lf, seed=seed,
-                   W=W, **{k: v for k, v in kw.items() if k in ("rho", "lambda_rate", "learning_rate", "momentum")})
+                   W=W, **{k: v for k, v in kw.items() if k in ("rho", "lambda_rate", "learning_rate", "momentum", "pooling")})
     b = (o.b + bshift).astype(np.float32)
     c = (rng.standard_normal((1, 4)) * 0.1).astype(np.float32)
     m.motifs.set_value(W)

@@ -27,14 +27,23 @@ if __name__ == "__main__":
         n = int(rng.integers(1, 40))
         L = M + int(rng.integers(0, 700 if big else 150))
         k = int(rng.integers(1, 4))
+        pool = [1, 1, 1, 2, 3, 4][int(rng.integers(0, 6))]         # half of the cases pooled
+        Lf = -(-Lf // pool) * pool
+        L = M - 1 + max(1, (L - M + 1) // pool) * pool            # hidden length a multiple of pooling
         variant = ["", "dense", "sparse"][int(rng.integers(0, 3))]
         if variant:
             os.environ["CRBM_TOPDOWN"] = variant
         else:
             os.environ.pop("CRBM_TOPDOWN", None)
+        stats = ["", "two", "split"][int(rng.integers(0, 3))]      # launch structure of the training step
+        if stats:
+            os.environ["CRBM_STATS"] = stats
+        else:
+            os.environ.pop("CRBM_STATS", None)
         t0 = time.time()
         try:
-            m, o = T.make_pair(K, M, ds=ds, batchsize=B, cd_k=k, Lf=Lf, bshift=float(rng.uniform(2, 7)), wscale=float(rng.uniform(0.3, 1.5)))
+            m, o = T.make_pair(K, M, ds=ds, batchsize=B, cd_k=k, Lf=Lf, bshift=float(rng.uniform(2, 7)), wscale=float(rng.uniform(0.3, 1.5)),
+                               pooling=pool)
             D = synthetic_onehot(n, L, seed=case)
             m._trainingFct(D)
             o.train_step(D)
@@ -53,7 +62,7 @@ if __name__ == "__main__":
         except Exception as e:   # report every failing shape, keep going
             bad += 1
             status = "FAIL %s" % (str(e)[:300].replace("\n", " "))
-        print("case %d K=%d M=%d ds=%d Lf=%d B=%d n=%d L=%d k=%d td=%s: %s (%.1fs)" % (
-            case, K, M, ds, Lf, B, n, L, k, variant or "auto", status, time.time() - t0), flush=True)
+        print("case %d K=%d M=%d ds=%d pool=%d Lf=%d B=%d n=%d L=%d k=%d td=%s stats=%s: %s (%.1fs)" % (
+            case, K, M, ds, pool, Lf, B, n, L, k, variant or "default", stats or "one", status, time.time() - t0), flush=True)
     print("SOAK DONE, failures:", bad)
     sys.exit(1 if bad else 0)
