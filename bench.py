@@ -372,9 +372,11 @@ def main():
 
     if watchdog is not None:
         watchdog.cancel()
-    emit(train)
+    if rank == 0:
+        out["secondary_ok"] = not failed        # the training section is secondary: its failure is reported in the line
+    emit(train)                                 # (train.error) and through the flag; the headline above stays valid
     control.close()
-    if failed:
+    if failed and os.environ.get("CRBM_BENCH_STRICT", "0") == "1":
         sys.exit(4)
 
 
