@@ -378,9 +378,14 @@ int prepare_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool 
   const int lds = std::max(st.region_floats * 4 + tabs, st.combine_bytes);
   ARGCHK(lds <= 160 * 1024, "model too large for the statistics kernel");
   const int wpr = (st.threads / 64) / st.NR;                  // waves per role = units a block works on at a time
-  const int per_cu = std::max(1, std::min(2048 / st.threads, (160 * 1024) / std::max(1, lds)));
-  const int cap = h->stats_rows > 0 ? h->stats_rows : h->num_cu * per_cu;
-  const int gx = (int)std::max<long>(1, std::min<long>((nunits + wpr - 1) / wpr, cap));
+  // Grid: a persistent set of blocks, every wave with the same number of units (a ragged last round costs
+  // a whole unit time: at config #2 768 blocks of 8 units per wave take 73 us per training step, 832 blocks
+  // 78).  Stand-alone: as many blocks as are resident at once; riding in the training launch: three per CU
+  // beside the four chain blocks (measured optimum, fewer partial rows to combine and reduce).
+  const int per_cu = own ? std::max(1, std::min(2048 / st.threads, (160 * 1024) / std::max(1, lds))) : 3;
+  const long cap = h->stats_rows > 0 ? h->stats_rows : (long)h->num_cu * per_cu;
+  const long upw = std::max<long>(1, (nunits + cap * wpr - 1) / (cap * wpr));        // units per wave
+  const int gx = (int)std::max<long>(1, (nunits + upw * wpr - 1) / (upw * wpr));
   HIPCHK(pbuf.ensure((size_t)gx * st.row));
   a.nblocks = gx;
   a.sg = stats_geom(st, pbuf.p, ngroups, lds);

@@ -1906,16 +1906,18 @@ __device__ __forceinline__ void reduce_partials_body(const ReduceArgs& a) {
     else if (r < 3 * KAM + 3 * K) valid = a.want_sparsity != 0;
     else valid = true;
     if (valid) {
-      float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;   // four rows in flight; fixed order
+      // eight rows in flight per thread (the kernel is a chain of memory round trips: ~2 000 rows of a few KB); fixed order
+      float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f, t4 = 0.f, t5 = 0.f, t6 = 0.f, t7 = 0.f;
       int i = grp;
-      for (; i + 96 < a.nrows; i += 128) {
-        t0 += a.partials[(size_t)i * a.row + r];
-        t1 += a.partials[(size_t)(i + 32) * a.row + r];
-        t2 += a.partials[(size_t)(i + 64) * a.row + r];
-        t3 += a.partials[(size_t)(i + 96) * a.row + r];
+      for (; i + 224 < a.nrows; i += 256) {
+        const float v0 = a.partials[(size_t)i * a.row + r], v1 = a.partials[(size_t)(i + 32) * a.row + r];
+        const float v2 = a.partials[(size_t)(i + 64) * a.row + r], v3 = a.partials[(size_t)(i + 96) * a.row + r];
+        const float v4 = a.partials[(size_t)(i + 128) * a.row + r], v5 = a.partials[(size_t)(i + 160) * a.row + r];
+        const float v6 = a.partials[(size_t)(i + 192) * a.row + r], v7 = a.partials[(size_t)(i + 224) * a.row + r];
+        t0 += v0; t1 += v1; t2 += v2; t3 += v3; t4 += v4; t5 += v5; t6 += v6; t7 += v7;
       }
       for (; i < a.nrows; i += 32) t0 += a.partials[(size_t)i * a.row + r];
-      t = (t0 + t1) + (t2 + t3);
+      t = ((t0 + t1) + (t2 + t3)) + ((t4 + t5) + (t6 + t7));
     }
   }
   part[grp][col] = t;
