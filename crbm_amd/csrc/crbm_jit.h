@@ -69,6 +69,7 @@ inline uint64_t jit_fnv1a(const std::string& s, uint64_t h = 1469598103934665603
 inline std::string jit_stub(int K, int M, int DS, int G, int POOL, int gibbs_wpe) {
   char attr[96] = "", sattr[96] = "";
   if (gibbs_wpe > 0) snprintf(attr, sizeof(attr), "__attribute__((amdgpu_waves_per_eu(1, %d)))", gibbs_wpe);
+  else snprintf(attr, sizeof(attr), "__attribute__((amdgpu_waves_per_eu(4)))");   // 4 blocks of 4 waves per CU: at most 128 registers
   // the variant that also carries the statistics accumulators must keep the occupancy of the plain
   // kernel's geometry (4 blocks of 4 waves per CU for small models): cap it at 128 registers there
   if (gibbs_wpe > 0) snprintf(sattr, sizeof(sattr), "__attribute__((amdgpu_waves_per_eu(1, %d)))", gibbs_wpe);

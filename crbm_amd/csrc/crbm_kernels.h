@@ -60,6 +60,7 @@ __device__ __forceinline__ void store4_streaming(uint32_t* dst, uint32_t x, uint
   const u4v val = {x, y, z, w};
   __builtin_nontemporal_store(val, reinterpret_cast<u4v*>(dst));
 }
+__device__ __forceinline__ void store1_streaming(uint32_t* dst, uint32_t x) { __builtin_nontemporal_store(x, dst); }
 // x = hi + lo with both halves f16 (round to nearest): 22 significant bits, v_cvt_pk_f16_f32 +
 // v_cvt_f32_f16 + v_pk_add_f32 per pair
 __device__ __forceinline__ void split_f16(const float (&x)[8], HalfFrag& hi, HalfFrag& lo) {
@@ -80,12 +81,21 @@ __device__ __forceinline__ floatx4 mfma_16x16x32_f16(const HalfFrag& a, const Ha
   typedef _Float16 half8 __attribute__((ext_vector_type(8)));
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
 }
+// two floats = one v_pk_*_f32 operand; a * b + c as one v_pk_fma_f32; `opaque` hides where a value came
+// from (no instruction), so that float(field) + 1 stays a packed add instead of a second conversion
+typedef float floatx2 __attribute__((vector_size(8)));
+__device__ __forceinline__ floatx2 fma2(floatx2 a, floatx2 b, floatx2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ floatx2 opaque(floatx2 v) { asm volatile("" : "+v"(v)); return v; }
 #else   // CPU emulation build (tests/emu/shim/hip/hip_runtime.h implements the wave-wide parts)
 typedef float floatx4 __attribute__((vector_size(16)));
+typedef float floatx2 __attribute__((vector_size(8)));
+__device__ __forceinline__ floatx2 fma2(floatx2 a, floatx2 b, floatx2 c) { return floatx2{fmaf(a[0], b[0], c[0]), fmaf(a[1], b[1], c[1])}; }
+__device__ __forceinline__ floatx2 opaque(floatx2 v) { return v; }
 __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return a ^ b ^ c; }
 __device__ __forceinline__ void store4_streaming(uint32_t* dst, uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
   *reinterpret_cast<uint4*>(dst) = make_uint4(x, y, z, w);
 }
+__device__ __forceinline__ void store1_streaming(uint32_t* dst, uint32_t x) { *dst = x; }
 __device__ __forceinline__ void split_f16(const float (&x)[8], HalfFrag& hi, HalfFrag& lo) { emu::split_f16(x, hi.r, lo.r); }
 __device__ __forceinline__ floatx4 mfma_16x16x32_f16(const HalfFrag& a, const HalfFrag& b, floatx4 c) {
   float d[4] = {c[0], c[1], c[2], c[3]};
@@ -209,6 +219,15 @@ __device__ __forceinline__ float wave_max_nonneg(float v) {
 // (2^-12 per unit).  Returns the K-bit mask; optionally the probabilities.
 // ---------------------------------------------------------------------------
 // WANT_P: 0 none, 1 p = sigma(x), 2 p = 2^14 * sigma(x) (the scale of the MFMA statistics, below)
+//
+// The two coarse tests are taken as sign bits: d1 = 4096 - coarse (1 + e) and d2 = 4096 - (coarse + 1)(1 + e)
+// (one fused multiply-add each, two units per packed instruction); the sign of d2 is "not certainly 1",
+// the sign of d1 "certainly 0".  Both are shifted into a word per group (v_alignbit_b32, units in
+// descending order so that unit 0 ends in bit 0): two instructions per unit where compares, selects
+// and ors took six.  e = inf (x < -88) gives d2 = -inf (h = 0, correct); d1 can then be NaN for
+// coarse = 0, whose sign only decides whether the exact path below is taken -- it returns 0 as well.
+__device__ __forceinline__ uint32_t shift_in_sign(uint32_t acc, float d) { return (acc << 1) | (__float_as_uint(d) >> 31); }
+
 template <class C, int WANT_P>
 __device__ __forceinline__ void sample_hidden(const float (&z)[C::KP], uint32_t n, uint32_t s, uint32_t kind,
                                               uint32_t strand, const RngView& rng, uint32_t step,
@@ -218,24 +237,37 @@ __device__ __forceinline__ void sample_hidden(const float (&z)[C::KP], uint32_t 
 #pragma unroll
   for (int g = 0; g < C::NGRP; ++g) {
     const Philox4 rc = philox4x32_10(n, s, rng_word2(kind, strand, 0, (uint32_t)g), step, rng.seed_lo, rng.seed_hi);
-    uint32_t amb = 0u;   // units of this group that need the fine field
-    auto unit = [&](auto I) {
+    constexpr int kFull = 10;
+    const int cnt = C::K - 10 * g < kFull ? C::K - 10 * g : kFull;   // units of this group
+    uint32_t not_one = 0u, zero = 0u;     // bit i: unit 10g+i is not certainly 1 / is certainly 0
+    auto pair = [&](auto I) {             // units i + 1 and i of the group (i even), in that order
       constexpr int i = decltype(I)::value;
       const int k = 10 * g + i;
       if (k < C::K) {
-        const float e = exp_neg_x(z[k]);
-        const float af = (float)philox_field12<i>(rc);
-        const float x1 = fmaf(af, e, af);          // coarse * (1 + e)
-        const float x2 = x1 + (1.0f + e);          // (coarse + 1) * (1 + e)
-        const uint32_t one = x2 <= 4096.0f ? 1u : 0u;
-        amb |= (x1 <= 4096.0f && !(x2 <= 4096.0f)) ? (1u << i) : 0u;
-        mask[k >> 5] |= one << (k & 31);
-        if (WANT_P == 1) p[k] = fast_rcp(1.0f + e);
-        if (WANT_P == 2) p[k] = fast_rcp(fmaf(e, STATS_PSCALE_INV, STATS_PSCALE_INV));
+        const bool two = k + 1 < C::K;
+        const floatx2 e = {exp_neg_x(z[k]), exp_neg_x(z[two ? k + 1 : k])};
+        const floatx2 ope = e + 1.0f;
+        const floatx2 af = opaque(floatx2{(float)philox_field12<i>(rc), (float)philox_field12<i + 1>(rc)});
+        const floatx2 c4096 = {4096.0f, 4096.0f};
+        const floatx2 d1 = fma2(-af, ope, c4096);             // >= 0: coarse (1 + e) <= 4096
+        const floatx2 d2 = fma2(-(af + 1.0f), ope, c4096);    // >= 0: (coarse + 1)(1 + e) <= 4096, h = 1
+        if (two) {
+          zero = shift_in_sign(zero, d1[1]);
+          not_one = shift_in_sign(not_one, d2[1]);
+        }
+        zero = shift_in_sign(zero, d1[0]);
+        not_one = shift_in_sign(not_one, d2[0]);
+        if (WANT_P == 1) { p[k] = fast_rcp(ope[0]); if (two) p[k + 1] = fast_rcp(ope[1]); }
+        if (WANT_P == 2) {
+          const floatx2 os = ope * STATS_PSCALE_INV;
+          p[k] = fast_rcp(os[0]);
+          if (two) p[k + 1] = fast_rcp(os[1]);
+        }
       }
     };
-    unit(IC<0>{}); unit(IC<1>{}); unit(IC<2>{}); unit(IC<3>{}); unit(IC<4>{});
-    unit(IC<5>{}); unit(IC<6>{}); unit(IC<7>{}); unit(IC<8>{}); unit(IC<9>{});
+    pair(IC<8>{}); pair(IC<6>{}); pair(IC<4>{}); pair(IC<2>{}); pair(IC<0>{});
+    uint32_t ones = ~not_one & ((1u << cnt) - 1u);
+    const uint32_t amb = not_one & ~zero;   // units of this group that need the fine field
     if (__any(amb != 0u)) {
       const Philox4 rf = philox4x32_10(n, s, rng_word2(kind, strand, 1, (uint32_t)g), step, rng.seed_lo, rng.seed_hi);
       auto fix = [&](auto I) {
@@ -246,14 +278,17 @@ __device__ __forceinline__ void sample_hidden(const float (&z)[C::KP], uint32_t 
             // P*4096 - coarse lies in [0,1) up to rounding; compare with fine/4096
             const float t = 4096.0f * fast_rcp(1.0f + exp_neg_x(z[k]));
             const float frac = t - (float)philox_field12<i>(rc);
-            const uint32_t one = frac * 4096.0f > (float)philox_field12<i>(rf) ? 1u : 0u;
-            mask[k >> 5] |= one << (k & 31);
+            ones |= (frac * 4096.0f > (float)philox_field12<i>(rf) ? 1u : 0u) << i;
           }
         }
       };
       fix(IC<0>{}); fix(IC<1>{}); fix(IC<2>{}); fix(IC<3>{}); fix(IC<4>{});
       fix(IC<5>{}); fix(IC<6>{}); fix(IC<7>{}); fix(IC<8>{}); fix(IC<9>{});
     }
+    constexpr int kBitsPerWord = 32;
+    const int w0 = (10 * g) / kBitsPerWord, sh = (10 * g) % kBitsPerWord;
+    mask[w0] |= ones << sh;
+    if (sh + cnt > kBitsPerWord) mask[w0 + 1] |= ones >> (kBitsPerWord - sh);
   }
 }
 
@@ -271,9 +306,15 @@ __device__ __forceinline__ uint64_t letter_window(const uint32_t* w, int s) {
   return win;
 }
 
-// z[k] (+)= sum over letter groups of T[g][tuple][k]  (z = -log2(e) * activation).
+// z[k] (+)= sum over letter groups of T[g][tuple][k]  (z = -log2(e) * activation).  The sums are kept
+// as pairs of floats: one v_pk_add_f32 per two motifs (the compiler leaves scalar adds otherwise).
 template <class C, bool ACCUMULATE = false>
 __device__ __forceinline__ void conv_gather(const float* T, uint64_t win, float (&x)[C::KP]) {
+  floatx2 acc[2 * C::NQ];
+  if (ACCUMULATE) {
+#pragma unroll
+    for (int q = 0; q < 2 * C::NQ; ++q) acc[q] = floatx2{x[2 * q], x[2 * q + 1]};
+  }
   auto group = [&](int g, auto FIRST) {
     constexpr bool first = decltype(FIRST)::value != 0;   // the first group of a fresh sum assigns (saves KP adds of 0)
     const uint32_t r = (uint32_t)(win >> (2 * C::G * g)) & (uint32_t)(C::ROWS - 1);
@@ -282,9 +323,9 @@ __device__ __forceinline__ void conv_gather(const float* T, uint64_t win, float 
     for (int q = 0; q < C::NQ; ++q) {
       const float4 t = row[q];
       if (first) {
-        x[4 * q + 0] = t.x; x[4 * q + 1] = t.y; x[4 * q + 2] = t.z; x[4 * q + 3] = t.w;
+        acc[2 * q] = floatx2{t.x, t.y}; acc[2 * q + 1] = floatx2{t.z, t.w};
       } else {
-        x[4 * q + 0] += t.x; x[4 * q + 1] += t.y; x[4 * q + 2] += t.z; x[4 * q + 3] += t.w;
+        acc[2 * q] += floatx2{t.x, t.y}; acc[2 * q + 1] += floatx2{t.z, t.w};
       }
     }
   };
@@ -297,6 +338,8 @@ __device__ __forceinline__ void conv_gather(const float* T, uint64_t win, float 
 #pragma unroll 1
     for (int g = 1; g < C::NG; ++g) group(g, IC<0>{});
   }
+#pragma unroll
+  for (int q = 0; q < 2 * C::NQ; ++q) { x[2 * q] = acc[q][0]; x[2 * q + 1] = acc[q][1]; }
 }
 
 // ---------------------------------------------------------------------------
@@ -406,7 +449,7 @@ __device__ __forceinline__ void pooled_sample(const float (&p)[C::KP], const flo
   }
 }
 
-// global precomputed tables -> LDS (plain float4 copy)
+// global precomputed tables -> LDS (plain float4 copy; batching the loads of a thread measured slower)
 template <int NFLOATS>
 __device__ __forceinline__ void copy_tables(float* dst, const float* src) {
   static_assert(NFLOATS % 4 == 0, "tables are float4 granular");
@@ -1031,14 +1074,17 @@ __device__ void gibbs_body(const GibbsArgs& a, int bid = -1) {   // bid: block o
   uint32_t* hmp = hm + (size_t)a.S * a.Lrow * NW;
   uint32_t* let = hmp + (C::DS ? (size_t)a.S * a.Lrow * NW : 0);
 
-  if (!(a.debug & 1)) {
-  if (SPARSE) {
-    copy_tables<C::TAB * (1 + C::DS)>(smem, a.tables);
-    copy_tables<C::WS * (1 + C::DS) + 4>(smem + C::SP_WS, a.tables + C::OFF_WS);
-  } else {
-    copy_tables<C::TABLES>(smem, a.tables);
-  }
-  }
+  // The tables are copied while the state loads of the block's first tile are in flight (below).
+  bool tables_done = (a.debug & 1) != 0;
+  auto copy_all_tables = [&]() {
+    if (SPARSE) {
+      copy_tables<C::TAB * (1 + C::DS)>(smem, a.tables);
+      copy_tables<C::WS * (1 + C::DS) + 4>(smem + C::SP_WS, a.tables + C::OFF_WS);
+    } else {
+      copy_tables<C::TABLES>(smem, a.tables);
+    }
+    tables_done = true;
+  };
 
   const int rowW = a.Lrow * NW;
   const uint32_t per = (uint32_t)(a.Lf * NW);           // state words per chain
@@ -1092,7 +1138,8 @@ __device__ void gibbs_body(const GibbsArgs& a, int bid = -1) {   // bid: block o
         constexpr int UN = 2;
         const uint4* src = reinterpret_cast<const uint4*>(a.hm + g0);
         const uint4* srcp = C::DS ? reinterpret_cast<const uint4*>(a.hmp + g0) : nullptr;
-        for (uint32_t base = threadIdx.x; base < nwords / 4; base += UN * blockDim.x) {
+        for (uint32_t base0 = 0; base0 < nwords / 4; base0 += UN * blockDim.x) {   // the same rounds for every thread
+          const uint32_t base = base0 + threadIdx.x;
           uint4 t[UN], tp[UN];
 #pragma unroll
           for (int u = 0; u < UN; ++u) {
@@ -1102,6 +1149,7 @@ __device__ void gibbs_body(const GibbsArgs& a, int bid = -1) {   // bid: block o
               if (C::DS) tp[u] = srcp[i4];
             }
           }
+          if (!tables_done) copy_all_tables();
 #pragma unroll
           for (int u = 0; u < UN; ++u) {
             const uint32_t i4 = base + u * blockDim.x;
@@ -1119,7 +1167,8 @@ __device__ void gibbs_body(const GibbsArgs& a, int bid = -1) {   // bid: block o
         }
       } else {
         constexpr int UN = 8;
-        for (uint32_t base = threadIdx.x; base < nwords; base += UN * blockDim.x) {
+        for (uint32_t base0 = 0; base0 < nwords; base0 += UN * blockDim.x) {
+          const uint32_t base = base0 + threadIdx.x;
           uint32_t t[UN], tp[UN];
 #pragma unroll
           for (int u = 0; u < UN; ++u) {
@@ -1129,6 +1178,7 @@ __device__ void gibbs_body(const GibbsArgs& a, int bid = -1) {   // bid: block o
               if (C::DS) tp[u] = a.hmp[g0 + i];
             }
           }
+          if (!tables_done) copy_all_tables();
 #pragma unroll
           for (int u = 0; u < UN; ++u) {
             const uint32_t i = base + u * blockDim.x;
@@ -1141,6 +1191,7 @@ __device__ void gibbs_body(const GibbsArgs& a, int bid = -1) {   // bid: block o
         }
       }
     }
+    if (!tables_done) copy_all_tables();
     for (int idx = threadIdx.x; idx < ns * a.LWs; idx += blockDim.x) let[idx] = 0u;
     for (int st = 0; st < a.steps; ++st) {
       __syncthreads();
@@ -1271,10 +1322,11 @@ __device__ void gibbs_body(const GibbsArgs& a, int bid = -1) {   // bid: block o
                 uint32_t mask[NW];
                 sample_hidden<C, 2>(x, gn, (uint32_t)s, KIND_CHAIN_H, (uint32_t)strand, a.rng,
                                     a.rng.step + (uint32_t)st, mask, p);
-                uint32_t* dst = (strand ? hmp : hm) + (size_t)nl * rowW + (size_t)(s + M - 1) * NW;
+                // the last pass of the launch: the new state goes straight to global memory
+                uint32_t* dst = (strand ? a.hmp : a.hm) + (size_t)(n0 + nl) * per + (size_t)s * NW;
 #pragma unroll
                 for (int w = 0; w < NW; ++w) {
-                  dst[w] = mask[w];
+                  if (!(a.debug & 4)) store1_streaming(dst + w, mask[w]);
                   nset += __popc(mask[w]);
                 }
 #pragma unroll
@@ -1293,7 +1345,7 @@ __device__ void gibbs_body(const GibbsArgs& a, int bid = -1) {   // bid: block o
           __builtin_amdgcn_wave_barrier();       // the slice is rewritten by the next unit
         }
       }
-      if (!fused_pass)
+      if (!fused_pass) {
       // ---- h | v : x[k,s] = b[k] + sum_j W[k, letter[s+j], j]; h = [sigma(x) > u] ----
       // one hidden position per item (nhb = Lf items per chain): the K units of a position
       // already give the instruction-level parallelism, and single positions spread evenly
@@ -1319,18 +1371,28 @@ __device__ void gibbs_body(const GibbsArgs& a, int bid = -1) {   // bid: block o
           sample_hidden<C, 0>(x, gn, (uint32_t)s, KIND_CHAIN_H, (uint32_t)strand, a.rng,
                                   a.rng.step + (uint32_t)st, mask, p);
           }
-          uint32_t* dst = (strand ? hmp : hm) + (size_t)nl * rowW + (size_t)(s + M - 1) * NW;
+          if (st == a.steps - 1) {
+            // the last pass of the launch: the new state goes straight to global memory (the stores
+            // drain behind the remaining items instead of in a phase of their own after a barrier)
+            uint32_t* dst = (strand ? a.hmp : a.hm) + (size_t)(n0 + nl) * per + (size_t)s * NW;
 #pragma unroll
-          for (int w = 0; w < NW; ++w) {
-            dst[w] = mask[w];
-            if (st == a.steps - 1) nset += __popc(mask[w]);
+            for (int w = 0; w < NW; ++w) {
+              if (!(a.debug & 4)) store1_streaming(dst + w, mask[w]);
+              nset += __popc(mask[w]);
+            }
+          } else {
+            uint32_t* dst = (strand ? hmp : hm) + (size_t)nl * rowW + (size_t)(s + M - 1) * NW;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) dst[w] = mask[w];
           }
         }
       }
+      }
     }
-    __syncthreads();
-    // LDS -> chain state (contiguous in global memory, 16-byte stores where aligned)
-    if (!(a.debug & 4)) {
+    // LDS -> chain state (contiguous in global memory, 16-byte stores where aligned): only a launch
+    // without steps (state round trip) still has the state in LDS here
+    if (a.steps == 0) __syncthreads();
+    if (a.steps == 0 && !(a.debug & 4)) {
       const uint32_t nwords = (uint32_t)ns * per;
       const size_t g0 = (size_t)n0 * per;
       auto lds_index = [&](uint32_t i) {

@@ -27,6 +27,7 @@ struct float4 {
   float x, y, z, w;
 };
 static inline float4 make_float4(float a, float b, float c, float d) { return float4{a, b, c, d}; }
+struct alignas(8) float2 { float x, y; };
 struct alignas(8) uint2 { uint32_t x, y; };
 static inline uint2 make_uint2(uint32_t x, uint32_t y) { uint2 r; r.x = x; r.y = y; return r; }
 struct uint4 {
@@ -127,6 +128,7 @@ static inline unsigned long long __ballot(int pred) {
 static inline void __builtin_amdgcn_wave_barrier() {
   pthread_barrier_wait(&emu::t_ctx->wave_bar[emu::t_threadIdx.x >> 6]);
 }
+static inline void __builtin_amdgcn_sched_barrier(int) {}
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 
 namespace emu {

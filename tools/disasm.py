@@ -17,12 +17,12 @@ notes = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", f], ca
 cur = {}
 for line in notes.splitlines():
     line = line.strip()
-    for key in (".name:", ".vgpr_count:", ".agpr_count:", ".sgpr_count:", ".vgpr_spill_count:", ".sgpr_spill_count:", ".group_segment_fixed_size:"):
+    for key in (".name:", ".vgpr_count:", ".agpr_count:", ".sgpr_count:", ".vgpr_spill_count:", ".sgpr_spill_count:", ".group_segment_fixed_size:", ".private_segment_fixed_size:"):
         if line.startswith(key) or line.startswith("- " + key):
             cur[key] = line.split(":", 1)[1].strip()
     if line.startswith(".wavefront_size") or line.startswith("- .wavefront_size"):
         pass
     if ".vgpr_spill_count:" in line and ".name:" in cur:
-        sys.stderr.write("%-28s vgpr %s agpr %s sgpr %s spills v%s s%s\n" % (cur.get(".name:"), cur.get(".vgpr_count:"), cur.get(".agpr_count:"), cur.get(".sgpr_count:"), cur.get(".vgpr_spill_count:"), cur.get(".sgpr_spill_count:")))
+        sys.stderr.write("%-28s vgpr %s agpr %s sgpr %s spills v%s s%s scratch %s B\n" % (cur.get(".name:"), cur.get(".vgpr_count:"), cur.get(".agpr_count:"), cur.get(".sgpr_count:"), cur.get(".vgpr_spill_count:"), cur.get(".sgpr_spill_count:"), cur.get(".private_segment_fixed_size:")))
         cur = {}
 print(subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", "--no-show-raw-insn", f], capture_output=True, text=True).stdout)
