@@ -19,7 +19,9 @@
 #include <cstdlib>
 #include <fstream>
 #include <sstream>
+#include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 namespace crbm {
@@ -201,9 +203,17 @@ inline hipError_t jit_launch(hipFunction_t f, const Args& args, unsigned gx, uns
   void* params[] = {&copy};
   if (lds > 48 * 1024) {
     // opt-in for large dynamic LDS where the runtime wants one; module functions do not need it on
-    // ROCm and the call may fail for them -- its error must not linger for a later hipGetLastError()
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipGetLastError();
+    // ROCm and the call may fail for them -- its error must not linger for a later hipGetLastError().
+    // Once per function and size: the call costs microseconds of host time, a training step has three launches.
+    static std::mutex mu;
+    static std::unordered_map<hipFunction_t, unsigned> opted;
+    std::lock_guard<std::mutex> lock(mu);
+    unsigned& have = opted[f];
+    if (lds > have) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipGetLastError();
+      have = lds;
+    }
   }
   return hipModuleLaunchKernel(f, gx, gy, 1, block, 1, 1, lds, stream, params, nullptr);
 }
