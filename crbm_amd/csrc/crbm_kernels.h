@@ -1354,13 +1354,13 @@ __device__ void gibbs_body(const GibbsArgs& a, int bid = -1) {   // bid: block o
         const uint32_t nl = fastdiv_tile(it, a.divHB);
         const int s = (int)(it - nl * (uint32_t)a.nhb);
         const uint32_t gn = a.rng.seq_offset + (uint32_t)(n0 + nl);
-        const uint64_t win = letter_window<M>(let + (size_t)nl * a.LWs, s);
+        const uint32_t* lrow = let + nl * (uint32_t)a.LWs;        // LDS offsets: 32-bit arithmetic
+        const uint64_t win = letter_window<M>(lrow, s);
 #pragma unroll
         for (int strand = 0; strand <= C::DS; ++strand) {
           float x[KP], p[KP];
           uint32_t mask[NW];
           if constexpr (C::POOL > 1) {
-            const uint32_t* lrow = let + (size_t)nl * a.LWs;
             auto zfun = [&](int pos, float (&z)[KP]) { conv_gather<C>(strand ? Tr : Tf, letter_window<M>(lrow, pos), z); };
             float cb[KP], S[KP], u[KP];
             pooled_probs<C::POOL, KP>(zfun, s, p, cb, S);
@@ -1374,14 +1374,15 @@ __device__ void gibbs_body(const GibbsArgs& a, int bid = -1) {   // bid: block o
           if (st == a.steps - 1) {
             // the last pass of the launch: the new state goes straight to global memory (the stores
             // drain behind the remaining items instead of in a phase of their own after a barrier)
-            uint32_t* dst = (strand ? a.hmp : a.hm) + (size_t)(n0 + nl) * per + (size_t)s * NW;
+            // (item `it` of the tile is word it * NW of its contiguous state: nhb = Lf positions per chain)
+            uint32_t* dst = (strand ? a.hmp : a.hm) + (size_t)n0 * per + it * (uint32_t)NW;
 #pragma unroll
             for (int w = 0; w < NW; ++w) {
               if (!(a.debug & 4)) store1_streaming(dst + w, mask[w]);
               nset += __popc(mask[w]);
             }
           } else {
-            uint32_t* dst = (strand ? hmp : hm) + (size_t)nl * rowW + (size_t)(s + M - 1) * NW;
+            uint32_t* dst = (strand ? hmp : hm) + (nl * (uint32_t)(rowW - (int)per) + it * (uint32_t)NW + (uint32_t)((M - 1) * NW));
 #pragma unroll
             for (int w = 0; w < NW; ++w) dst[w] = mask[w];
           }

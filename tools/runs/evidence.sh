@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 timeout -k 10 900 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest.log
 timeout -k 10 300 python bench.py > $O/bench_cfg2.json 2> $O/bench_cfg2.err; echo "bench cfg2 rc=$?"
 for cfg in cfg4 cfg5; do
-  timeout -k 10 300 python bench.py --config $cfg --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_${cfg}.json 2> $O/bench_${cfg}.err; echo "bench $cfg rc=$?"
+  timeout -k 10 300 python bench.py --config $cfg --steps 2000 --warmup 200 --no-cpu-baseline > $O/bench_${cfg}.json 2> $O/bench_${cfg}.err; echo "bench $cfg rc=$?"
 done
 KS=0,1,2,4,16 timeout -k 10 120 python tools/gibbs_k_scan.py cfg2 > $O/gibbs_steps_per_launch_scan.txt 2>&1
 cd /tmp
