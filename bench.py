@@ -225,8 +225,12 @@ def main():
     # 6 GiB of copies also bring the clocks up before the short runs the driver asks for
     copy_gbs = ctypes.c_float()
     model._call("crbm_copy_bandwidth", 1 << 30, 5, ctypes.byref(copy_gbs))
-    # chains start at h = 0 (convRBM.py:168); 10 burn-in steps, then warm-up
-    model._call("crbm_gibbs_steps", 10)
+    # chains start at h = 0 (convRBM.py:168): 500 burn-in steps (12 ms), then the W warm-up launches.
+    # The burn-in is part of building the workload, not of the measurement: a persistent chain is never at
+    # h = 0 in training, and a run as short as the driver's (20 launches = 0.5 ms) would otherwise be timed
+    # while the GPU is still leaving its idle power state (measured: 24.6 us per launch after 10 burn-in
+    # steps, 23.6 after 500, 23.5 after 2000; 22.8 in the steady state of a 2000-launch run).
+    model._call("crbm_gibbs_steps", int(os.environ.get("CRBM_BENCH_BURNIN", "500")))
     for _ in range(args.warmup):
         model._call("crbm_gibbs_steps_async", k)
 
@@ -283,7 +287,7 @@ def main():
             "ms_per_step": 1e3 * kernel_s / args.steps,
             "wall_ms_per_step": 1e3 * wall / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic", "chain_burn_in_steps": int(os.environ.get("CRBM_BENCH_BURNIN", "500")),
             "config": {"workload": args.config + ": " + cfg["desc"], "chains_per_gpu": cfg["chains"],
                        "gibbs_steps_per_launch": k, "visible": "4x%d" % cfg["L"],
                        "hidden": "%dx%d" % (cfg["K"], cfg["L"] - cfg["M"] + 1),
