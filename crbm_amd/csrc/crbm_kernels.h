@@ -61,6 +61,8 @@ __device__ __forceinline__ void store4_streaming(uint32_t* dst, uint32_t x, uint
   __builtin_nontemporal_store(val, reinterpret_cast<u4v*>(dst));
 }
 __device__ __forceinline__ void store1_streaming(uint32_t* dst, uint32_t x) { __builtin_nontemporal_store(x, dst); }
+// all vector-memory operations of this wave have completed (gfx9 encoding: vmcnt = 0, expcnt and lgkmcnt untouched)
+__device__ __forceinline__ void wait_vector_memory() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 // x = hi + lo with both halves f16 (round to nearest): 22 significant bits, v_cvt_pk_f16_f32 +
 // v_cvt_f32_f16 + v_pk_add_f32 per pair
 __device__ __forceinline__ void split_f16(const float (&x)[8], HalfFrag& hi, HalfFrag& lo) {
@@ -96,6 +98,7 @@ __device__ __forceinline__ void store4_streaming(uint32_t* dst, uint32_t x, uint
   *reinterpret_cast<uint4*>(dst) = make_uint4(x, y, z, w);
 }
 __device__ __forceinline__ void store1_streaming(uint32_t* dst, uint32_t x) { *dst = x; }
+__device__ __forceinline__ void wait_vector_memory() {}
 __device__ __forceinline__ void split_f16(const float (&x)[8], HalfFrag& hi, HalfFrag& lo) { emu::split_f16(x, hi.r, lo.r); }
 __device__ __forceinline__ floatx4 mfma_16x16x32_f16(const HalfFrag& a, const HalfFrag& b, floatx4 c) {
   float d[4] = {c[0], c[1], c[2], c[3]};
@@ -137,6 +140,14 @@ __device__ __forceinline__ uint32_t philox_field12(const Philox4& r) {
   constexpr int w = (12 * I) / 32, b = (12 * I) % 32;
   if (b <= 20) return (r.v[w] >> b) & 0xFFFu;
   return ((r.v[w] >> b) | (r.v[(w + 1) & 3] << ((32 - b) & 31))) & 0xFFFu;
+}
+
+// the same for a field index known only at run time (the rare exact path of the chain kernel)
+__device__ __forceinline__ uint32_t philox_field12_dyn(const Philox4& r, int i) {
+  const int b = 12 * i, w = b >> 5, sh = b & 31;
+  uint32_t v = philox_pick(r, w) >> sh;
+  if (sh > 20) v |= philox_pick(r, (w + 1) & 3) << (32 - sh);
+  return v & 0xFFFu;
 }
 
 __device__ __forceinline__ float u01(uint32_t r) { return (float)(r >> 8) * 5.9604644775390625e-8f; }
@@ -228,10 +239,13 @@ __device__ __forceinline__ float wave_max_nonneg(float v) {
 // coarse = 0, whose sign only decides whether the exact path below is taken -- it returns 0 as well.
 __device__ __forceinline__ uint32_t shift_in_sign(uint32_t acc, float d) { return (acc << 1) | (__float_as_uint(d) >> 31); }
 
-template <class C, int WANT_P>
+// DEFER: the undecided units are not resolved here; their bits come back in pending[group] (mask has 0
+// there) and the caller resolves them later (gibbs_body queues them per block).
+template <class C, int WANT_P, bool DEFER = false>
 __device__ __forceinline__ void sample_hidden(const float (&z)[C::KP], uint32_t n, uint32_t s, uint32_t kind,
                                               uint32_t strand, const RngView& rng, uint32_t step,
-                                              uint32_t (&mask)[C::NW], float (&p)[C::KP]) {
+                                              uint32_t (&mask)[C::NW], float (&p)[C::KP],
+                                              uint32_t* pending = nullptr) {
 #pragma unroll
   for (int w = 0; w < C::NW; ++w) mask[w] = 0u;
 #pragma unroll
@@ -268,7 +282,8 @@ __device__ __forceinline__ void sample_hidden(const float (&z)[C::KP], uint32_t 
     pair(IC<8>{}); pair(IC<6>{}); pair(IC<4>{}); pair(IC<2>{}); pair(IC<0>{});
     uint32_t ones = ~not_one & ((1u << cnt) - 1u);
     const uint32_t amb = not_one & ~zero;   // units of this group that need the fine field
-    if (__any(amb != 0u)) {
+    if constexpr (DEFER) pending[g] = amb;
+    if (!DEFER && __any(amb != 0u)) {
       const Philox4 rf = philox4x32_10(n, s, rng_word2(kind, strand, 1, (uint32_t)g), step, rng.seed_lo, rng.seed_hi);
       auto fix = [&](auto I) {
         constexpr int i = decltype(I)::value;
@@ -1073,6 +1088,15 @@ __device__ void gibbs_body(const GibbsArgs& a, int bid = -1) {   // bid: block o
   uint32_t* hm = reinterpret_cast<uint32_t*>(smem + LTAB);
   uint32_t* hmp = hm + (size_t)a.S * a.Lrow * NW;
   uint32_t* let = hmp + (C::DS ? (size_t)a.S * a.Lrow * NW : 0);
+  uint32_t* fixq = let + (size_t)a.S * a.LWs;   // [count][-][FIXQ_CAP entries]: undecided units of the running h|v pass
+#ifdef CRBM_INLINE_EXACT_PATH                     // A/B knob (CRBM_JIT_DEFINES): every wave resolves its own undecided units
+  constexpr bool DEFER = false;
+#else
+  // Measured: double-stranded models gain (config #5: 180 -> 155 us per step), single-stranded
+  // ones lose to the extra barrier and the serial drain (config #2: 16.9 -> 17.5 us per step).  Pooled
+  // models draw both fields for every group anyway.
+  constexpr bool DEFER = C::POOL == 1 && C::DS;
+#endif
 
   // The tables are copied while the state loads of the block's first tile are in flight (below).
   bool tables_done = (a.debug & 1) != 0;
@@ -1109,6 +1133,7 @@ __device__ void gibbs_body(const GibbsArgs& a, int bid = -1) {   // bid: block o
     stats_build_lut<false>(reinterpret_cast<uint32_t*>(sreg));
     for (int i = lane; i < SR::ROWS * STATS_RS; i += 64) sPt[i] = 0.f;   // the zero row stays zero
   }
+  if (threadIdx.x == 0) fixq[0] = 0u;
   // the pads of the mask rows (M-1 positions in front, the rest behind) stay zero for the whole kernel
   {
     const int padw = rowW - (int)per, front = (M - 1) * NW;
@@ -1193,8 +1218,74 @@ __device__ void gibbs_body(const GibbsArgs& a, int bid = -1) {   // bid: block o
     }
     if (!tables_done) copy_all_tables();
     for (int idx = threadIdx.x; idx < ns * a.LWs; idx += blockDim.x) let[idx] = 0u;
+    // The exact path of the hidden sampler, block-wide (DEFER).  A unit whose coarse 12-bit field cannot
+    // decide it (2^-12 of all units, but some lane of a wave in 14.5 % of all rounds at K = 10) is not
+    // resolved by its wave -- that costs the whole wave a second Philox call and a pass over its ten
+    // units -- but queued: (item, unit, strand) in one word.  After the pass the block drains the queue,
+    // one entry per thread: activation of that one unit (same table rows, same order of additions),
+    // both Philox calls, the exact comparison of sample_hidden, one atomic OR into the mask word.
+    auto resolve = [&](uint32_t e, int st, bool last) -> uint32_t {
+      const uint32_t it = e & 0xFFFFFu, k = (e >> 20) & 63u, strand = e >> 26;
+      const uint32_t nl = fastdiv_tile(it, a.divHB);
+      const int s = (int)(it - nl * (uint32_t)a.nhb);
+      const uint32_t gn = a.rng.seq_offset + (uint32_t)(n0 + nl);
+      const uint64_t win = letter_window<M>(let + nl * (uint32_t)a.LWs, s);
+      const float* T = (strand ? Tr : Tf) + k;
+      float z = 0.f;
+#pragma unroll
+      for (int g = 0; g < C::NG; ++g) {
+        const uint32_t r = (uint32_t)(win >> (2 * C::G * g)) & (uint32_t)(C::ROWS - 1);
+        const float t = T[((size_t)g * C::ROWS + r) * KP];
+        z = g == 0 ? t : z + t;
+      }
+      const uint32_t g10 = k / 10u, i10 = k - 10u * g10, step = a.rng.step + (uint32_t)st;
+      const Philox4 rc = philox4x32_10(gn, (uint32_t)s, rng_word2(KIND_CHAIN_H, strand, 0, g10), step, a.rng.seed_lo, a.rng.seed_hi);
+      const Philox4 rf = philox4x32_10(gn, (uint32_t)s, rng_word2(KIND_CHAIN_H, strand, 1, g10), step, a.rng.seed_lo, a.rng.seed_hi);
+      const float t = 4096.0f * fast_rcp(1.0f + exp_neg_x(z));
+      const float frac = t - (float)philox_field12_dyn(rc, (int)i10);
+      const uint32_t one = frac * 4096.0f > (float)philox_field12_dyn(rf, (int)i10) ? 1u : 0u;
+      if (one) {
+        const uint32_t bit = 1u << (k & 31u), w = k >> 5;
+        if (last) { if (!(a.debug & 4)) atomicOr((strand ? a.hmp : a.hm) + (size_t)n0 * per + it * (uint32_t)NW + w, bit); }
+        else atomicOr((strand ? hmp : hm) + (nl * (uint32_t)(rowW - (int)per) + it * (uint32_t)NW + (uint32_t)((M - 1) * NW)) + w, bit);
+      }
+      return one;
+    };
+    // queue the undecided units of one item (rare; lanes without any do nothing)
+    auto defer_units = [&](const uint32_t (&pending)[C::NGRP], uint32_t it, uint32_t strand, int st, bool last) -> uint32_t {
+      uint32_t any = 0u, ones = 0u;
+#pragma unroll
+      for (int g = 0; g < C::NGRP; ++g) any |= pending[g];
+      if (__any(any != 0u)) {
+#pragma unroll
+        for (int g = 0; g < C::NGRP; ++g) {
+          uint32_t m = pending[g];
+          while (m) {
+            const uint32_t i = (uint32_t)__ffs(m) - 1u;
+            m &= m - 1u;
+            const uint32_t e = it | ((10u * (uint32_t)g + i) << 20) | (strand << 26);
+            const uint32_t slot = atomicAdd(&fixq[0], 1u);
+            if (slot < (uint32_t)FIXQ_CAP) fixq[2 + slot] = e;
+            else ones += resolve(e, st, last);        // queue full (never at the sizes that run): resolve in place
+          }
+        }
+      }
+      return ones;
+    };
+    auto drain_queue = [&](int st, bool last) {
+      // the last pass stored its mask words to global memory: they must have arrived before another
+      // wave's atomic OR may touch them (s_waitcnt vmcnt(0); the barrier itself only waits for LDS)
+      if (last) wait_vector_memory();
+      __syncthreads();                                // every mask word of the pass is stored, every entry queued
+      const uint32_t nq = min(fixq[0], (uint32_t)FIXQ_CAP);
+      for (uint32_t e = threadIdx.x; e < nq; e += blockDim.x) {
+        const uint32_t one = resolve(fixq[2 + e], st, last);
+        if (last) nset += (int)one;
+      }
+    };
     for (int st = 0; st < a.steps; ++st) {
       __syncthreads();
+      if (threadIdx.x == 0) fixq[0] = 0u;             // read by drain_queue before this barrier, filled again after the next
       // ---- v | h : y[a,p] = c[a] + sum_{k,j} W[k,a,j] h[k,p-j] (+ rc strand) ----
       for (uint32_t it = threadIdx.x; it < (uint32_t)(ns * a.nvb); it += blockDim.x) {
         const uint32_t nl = fastdiv_tile(it, a.divVB);
@@ -1320,8 +1411,9 @@ __device__ void gibbs_body(const GibbsArgs& a, int bid = -1) {   // bid: block o
                 float x[KP], p[KP];
                 conv_gather<C>(strand ? Tr : Tf, win, x);
                 uint32_t mask[NW];
-                sample_hidden<C, 2>(x, gn, (uint32_t)s, KIND_CHAIN_H, (uint32_t)strand, a.rng,
-                                    a.rng.step + (uint32_t)st, mask, p);
+                uint32_t pend[C::NGRP];
+                sample_hidden<C, 2, DEFER>(x, gn, (uint32_t)s, KIND_CHAIN_H, (uint32_t)strand, a.rng,
+                                           a.rng.step + (uint32_t)st, mask, p, pend);
                 // the last pass of the launch: the new state goes straight to global memory
                 uint32_t* dst = (strand ? a.hmp : a.hm) + (size_t)(n0 + nl) * per + (size_t)s * NW;
 #pragma unroll
@@ -1329,6 +1421,7 @@ __device__ void gibbs_body(const GibbsArgs& a, int bid = -1) {   // bid: block o
                   if (!(a.debug & 4)) store1_streaming(dst + w, mask[w]);
                   nset += __popc(mask[w]);
                 }
+                if constexpr (DEFER) nset += (int)defer_units(pend, nl * (uint32_t)a.nhb + (uint32_t)s, (uint32_t)strand, st, true);
 #pragma unroll
                 for (int k = 0; k < C::K; ++k) col[(size_t)(strand * KW + k) * STATS_RS] = p[k];
               }
@@ -1359,7 +1452,7 @@ __device__ void gibbs_body(const GibbsArgs& a, int bid = -1) {   // bid: block o
 #pragma unroll
         for (int strand = 0; strand <= C::DS; ++strand) {
           float x[KP], p[KP];
-          uint32_t mask[NW];
+          uint32_t mask[NW], pend[C::NGRP];
           if constexpr (C::POOL > 1) {
             auto zfun = [&](int pos, float (&z)[KP]) { conv_gather<C>(strand ? Tr : Tf, letter_window<M>(lrow, pos), z); };
             float cb[KP], S[KP], u[KP];
@@ -1368,8 +1461,8 @@ __device__ void gibbs_body(const GibbsArgs& a, int bid = -1) {   // bid: block o
             pooled_sample<C>(p, cb, u, mask);
           } else {
           conv_gather<C>(strand ? Tr : Tf, win, x);
-          sample_hidden<C, 0>(x, gn, (uint32_t)s, KIND_CHAIN_H, (uint32_t)strand, a.rng,
-                                  a.rng.step + (uint32_t)st, mask, p);
+          sample_hidden<C, 0, DEFER>(x, gn, (uint32_t)s, KIND_CHAIN_H, (uint32_t)strand, a.rng,
+                                     a.rng.step + (uint32_t)st, mask, p, pend);
           }
           if (st == a.steps - 1) {
             // the last pass of the launch: the new state goes straight to global memory (the stores
@@ -1386,9 +1479,14 @@ __device__ void gibbs_body(const GibbsArgs& a, int bid = -1) {   // bid: block o
 #pragma unroll
             for (int w = 0; w < NW; ++w) dst[w] = mask[w];
           }
+          if constexpr (DEFER) {
+            const uint32_t ones = defer_units(pend, it, (uint32_t)strand, st, st == a.steps - 1);
+            if (st == a.steps - 1) nset += (int)ones;
+          }
         }
       }
       }
+      if constexpr (DEFER) drain_queue(st, st == a.steps - 1);
     }
     // LDS -> chain state (contiguous in global memory, 16-byte stores where aligned): only a launch
     // without steps (state round trip) still has the state in LDS here

@@ -146,6 +146,9 @@ inline int choose_group(int K, int M, int ds, int budget_bytes) {
 // v|h: a thread owns 4 consecutive visible positions (nvb = ceil(Lv/4) items per
 // chain); h|v: one hidden position per item (nhb = Lf).  Hidden position s sits at index
 // s + M-1 of a zero-padded mask row of Lrow positions (multiple of 4).
+// Behind the letter rows sits the block's queue of undecided hidden units (crbm_kernels.h, gibbs_body):
+// word 0 = count, words 2.. = entries (item | unit << 20 | strand << 26).
+constexpr int FIXQ_WORDS = 64, FIXQ_CAP = FIXQ_WORDS - 2;
 struct GibbsLayout {
   int S, Lv, nvb, nhb, Lrow, LWs;
   int lds_bytes;
@@ -158,7 +161,7 @@ inline GibbsLayout gibbs_layout(const ModelShape& ms, int Lf, int S, bool sparse
   g.nhb = Lf;
   g.Lrow = 4 * cdiv(4 * g.nvb + ms.M - 1 + 3, 4);
   g.LWs = letter_words(4 * g.nvb);
-  const long words = (long)(sparse ? ms.SP_TABLES : ms.TABLES) + (long)(1 + ms.DS) * S * g.Lrow * ms.NW + (long)S * g.LWs;
+  const long words = (long)(sparse ? ms.SP_TABLES : ms.TABLES) + (long)(1 + ms.DS) * S * g.Lrow * ms.NW + (long)S * g.LWs + FIXQ_WORDS;
   g.lds_bytes = (int)(words * 4);
   return g;
 }
