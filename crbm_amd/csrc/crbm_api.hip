@@ -587,7 +587,15 @@ GibbsGeom choose_gibbs_geometry(const ModelShape& ms, int Lf, int B, int num_cu,
   const int forceS = env_int("CRBM_GIBBS_S", 0), forceT = env_int("CRBM_GIBBS_THREADS", 0);
   GibbsGeom best{1, 256, 1, 0};
   double best_score = -1.0;
-  for (int threads : {256, 128, 64}) {   // the kernels are compiled with __launch_bounds__(256)
+  // 256 first: larger blocks (one table copy shared by up to 16 waves; the chain kernels are then compiled
+  // with that launch bound) win only where they score strictly better -- models whose tables leave room
+  // for fewer than four 256-thread blocks per CU.  The fused statistics variants are built for 256.
+  double best_occupancy = 0.0;
+  for (int threads : {256, 128, 64, 512, 1024}) {
+    // measured: config #4 (two 256-thread blocks per CU) 2.62 -> 2.26 ms per launch with one 1024-thread
+    // block; config #5 (three blocks per CU) is no faster with two 512-thread blocks -- so only when the
+    // small blocks reach at most half the waves
+    if (threads > 256 && (ms.FUSE_STATS || best_occupancy > 0.5 || env_int("CRBM_GIBBS_MAX_THREADS", 1024) < threads)) continue;
     if (forceT > 0 && threads != forceT) continue;
     for (int S = 1; S <= std::min(B, 64); ++S) {
       if (forceS > 0 && S != forceS) continue;
@@ -608,6 +616,7 @@ GibbsGeom choose_gibbs_geometry(const ModelShape& ms, int Lf, int B, int num_cu,
       if (score > best_score) {
         best_score = score;
         best = GibbsGeom{S, threads, (int)std::min(ntiles, (double)num_cu * blocks_cu), gl.lds_bytes};
+        if (threads <= 256) best_occupancy = occupancy;
       }
     }
   }
@@ -617,6 +626,8 @@ GibbsGeom choose_gibbs_geometry(const ModelShape& ms, int Lf, int B, int num_cu,
 }
 
 // waves per SIMD the sparse Gibbs variant reaches with its geometry; 0 when >= 4 (no hint needed)
+int gibbs_block_bound(int threads) { return threads > 512 ? 1024 : threads > 256 ? 512 : 256; }
+
 int gibbs_wpe_hint(const GibbsGeom& g) {
   if (g.lds <= 0) return 0;
   const int blocks_cu = std::max(1, std::min((160 * 1024) / g.lds, 2048 / g.threads));
@@ -641,8 +652,10 @@ int crbm_precompile(const crbm_config* cfg) {
   bool cached = false;
   std::string file, err;
   const int Lf_pc = cfg->fantasy_hidden_len > 0 ? cfg->fantasy_hidden_len : 200;
-  const int wpe = gibbs_wpe_hint(choose_gibbs_geometry(ms, Lf_pc, cfg->batchsize, env_int("CRBM_NUM_CU", 256), true));
-  if (jit_compile(ms.K, ms.M, ms.DS, ms.G, ms.POOL, wpe, &code, &cached, &file, &err) != 0) {
+  const GibbsGeom gs = choose_gibbs_geometry(ms, Lf_pc, cfg->batchsize, env_int("CRBM_NUM_CU", 256), true);
+  int tb = gs.threads;
+  if (ms.DENSE) tb = std::max(tb, choose_gibbs_geometry(ms, Lf_pc, cfg->batchsize, env_int("CRBM_NUM_CU", 256), false).threads);
+  if (jit_compile(ms.K, ms.M, ms.DS, ms.G, ms.POOL, gibbs_wpe_hint(gs), gibbs_block_bound(tb), &code, &cached, &file, &err) != 0) {
     g_create_error = err;
     return CRBM_ERR_HIP;
   }
@@ -707,7 +720,8 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
   }
   {
     std::string err;
-    if (jit_load(hh->K, hh->M, hh->ds, hh->G, hh->ms.POOL, hh->gibbs_wpe, &hh->jk, &err) != 0) {
+    const int tb = gibbs_block_bound(std::max(hh->has_dense ? hh->threadsv[0] : 0, hh->threadsv[1]));
+    if (jit_load(hh->K, hh->M, hh->ds, hh->G, hh->ms.POOL, hh->gibbs_wpe, tb, &hh->jk, &err) != 0) {
       g_create_error = "kernel specialisation failed: " + err;
       return bail(CRBM_ERR_HIP);
     }

@@ -68,7 +68,8 @@ inline uint64_t jit_fnv1a(const std::string& s, uint64_t h = 1469598103934665603
 // gibbs_wpe: waves per SIMD the launch geometry can actually reach when that is
 // below 4 (LDS-limited large models): tells the register allocator not to squeeze
 // the kernel for an occupancy it will never see; 0 = no hint.
-inline std::string jit_stub(int K, int M, int DS, int G, int POOL, int gibbs_wpe) {
+// gibbs_tb: block-size bound of the chain kernels (256, 512 or 1024: large models share one table copy per CU)
+inline std::string jit_stub(int K, int M, int DS, int G, int POOL, int gibbs_wpe, int gibbs_tb = 256) {
   char attr[96] = "", sattr[96] = "";
   if (gibbs_wpe > 0) snprintf(attr, sizeof(attr), "__attribute__((amdgpu_waves_per_eu(1, %d)))", gibbs_wpe);
   else snprintf(attr, sizeof(attr), "__attribute__((amdgpu_waves_per_eu(4)))");   // 4 blocks of 4 waves per CU: at most 128 registers
@@ -85,21 +86,21 @@ inline std::string jit_stub(int K, int M, int DS, int G, int POOL, int gibbs_wpe
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_build_tables(crbm::TablesArgs a) { crbm::build_tables_body<ModelCfg>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_update_tables(crbm::UpdateTablesArgs a) { crbm::update_tables_body<ModelCfg>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_hgv(crbm::HgvArgs a) { crbm::hgv_body<ModelCfg>(a); }\n"
-           "extern \"C\" __global__ void __launch_bounds__(256) CRBM_GIBBS_ATTR crbm_gibbs_sparse(crbm::GibbsArgs a) { crbm::gibbs_body<ModelCfg, true>(a); }\n"
+           "extern \"C\" __global__ void __launch_bounds__(%d) CRBM_GIBBS_ATTR crbm_gibbs_sparse(crbm::GibbsArgs a) { crbm::gibbs_body<ModelCfg, true>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) CRBM_GIBBS_STATS_ATTR crbm_gibbs_sparse_stats(crbm::GibbsArgs a) { if constexpr (ModelCfg::FUSE_STATS) crbm::gibbs_body<ModelCfg, true, true>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) CRBM_GIBBS_STATS_ATTR crbm_train_local(crbm::TrainLocalArgs a) { crbm::train_local_body<ModelCfg>(a); }\n"
-           "extern \"C\" __global__ void __launch_bounds__(256) crbm_gibbs(crbm::GibbsArgs a) { if constexpr (ModelCfg::DENSE) crbm::gibbs_body<ModelCfg, ModelCfg::DENSE ? false : true>(a); }\n"
+           "extern \"C\" __global__ void __launch_bounds__(%d) crbm_gibbs(crbm::GibbsArgs a) { if constexpr (ModelCfg::DENSE) crbm::gibbs_body<ModelCfg, ModelCfg::DENSE ? false : true>(a); }\n"
            "using RoleData = crbm::StatsRole<ModelCfg, true>;\nusing RoleModel = crbm::StatsRole<ModelCfg, false>;\n"
            "extern \"C\" __global__ void __launch_bounds__(RoleData::THREADS) crbm_stats_mfma_data(crbm::StatsMfmaArgs a) { crbm::stats_mfma_body<ModelCfg, true>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(RoleModel::THREADS) crbm_stats_mfma_model(crbm::StatsMfmaArgs a) { crbm::stats_mfma_body<ModelCfg, false>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_free_energy(crbm::FeArgs a) { crbm::free_energy_body<ModelCfg>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_hit_summary(crbm::HitArgs a) { crbm::hit_summary_body<ModelCfg>(a); }\n",
-           attr, sattr, K, M, DS, G, POOL);
+           attr, sattr, K, M, DS, G, POOL, gibbs_tb, gibbs_tb);
   return buf;
 }
 
 // Compile (or fetch from the cache) the code object; no device needed.
-inline int jit_compile(int K, int M, int DS, int G, int POOL, int gibbs_wpe, std::vector<char>* code, bool* from_cache,
+inline int jit_compile(int K, int M, int DS, int G, int POOL, int gibbs_wpe, int gibbs_tb, std::vector<char>* code, bool* from_cache,
                        std::string* cache_file, std::string* err) {
   const std::string dir = jit_source_dir();
   std::string kernels, layout;
@@ -107,7 +108,7 @@ inline int jit_compile(int K, int M, int DS, int G, int POOL, int gibbs_wpe, std
     *err = "kernel sources not found in " + dir + " (set CRBM_KERNEL_SRC_DIR)";
     return -1;
   }
-  const std::string stub = jit_stub(K, M, DS, G, POOL, gibbs_wpe);
+  const std::string stub = jit_stub(K, M, DS, G, POOL, gibbs_wpe, gibbs_tb);
   std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
                                    "-I" + dir, "-I/opt/rocm/include"};
   if (const char* e = getenv("CRBM_JIT_DEFINES")) {   // tuning knobs, e.g. "-DCRBM_STATS_MAX_TILES=16"
@@ -172,9 +173,9 @@ inline int jit_compile(int K, int M, int DS, int G, int POOL, int gibbs_wpe, std
   return 0;
 }
 
-inline int jit_load(int K, int M, int DS, int G, int POOL, int gibbs_wpe, JitKernels* out, std::string* err) {
+inline int jit_load(int K, int M, int DS, int G, int POOL, int gibbs_wpe, int gibbs_tb, JitKernels* out, std::string* err) {
   std::vector<char> code;
-  if (jit_compile(K, M, DS, G, POOL, gibbs_wpe, &code, &out->from_cache, &out->cache_file, err) != 0) return -1;
+  if (jit_compile(K, M, DS, G, POOL, gibbs_wpe, gibbs_tb, &code, &out->from_cache, &out->cache_file, err) != 0) return -1;
   hipError_t e = hipModuleLoadData(&out->module, code.data());
   if (e != hipSuccess) {
     *err = std::string("hipModuleLoadData: ") + hipGetErrorString(e);
