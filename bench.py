@@ -230,7 +230,11 @@ def main():
     # h = 0 in training, and a run as short as the driver's (20 launches = 0.5 ms) would otherwise be timed
     # while the GPU is still leaving its idle power state (measured: 24.6 us per launch after 10 burn-in
     # steps, 23.6 after 500, 23.5 after 2000; 22.8 in the steady state of a 2000-launch run).
-    model._call("crbm_gibbs_steps", int(os.environ.get("CRBM_BENCH_BURNIN", "500")))
+    # (as launches of k steps like the timed ones: every launch of the chain kernel in this process is then
+    # the same work, and a profiler's per-kernel average equals avg_launch_us)
+    for _ in range(max(1, int(os.environ.get("CRBM_BENCH_BURNIN", "500")) // k)):
+        model._call("crbm_gibbs_steps_async", k)
+    model._call("crbm_sync")
     for _ in range(args.warmup):
         model._call("crbm_gibbs_steps_async", k)
 
