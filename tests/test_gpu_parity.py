@@ -76,11 +76,20 @@ def assert_chain_steps(model, o, steps):
             assert np.all(gap[badv] < TIE), "visible sample differs away from a tie"
             ties += int(badv.sum())
         clean = ~badv.any(axis=1)                                                # chains whose v agrees: h must too
+        pool = int(getattr(o, "pooling", 1))
         for got, want, prob, u in ((gh, h, P, uh),) + (((ghp, hp, Pp, uhp),) if ds else ()):
             bad = (got != want) & clean[:, None, None, None]
-            if bad.any():
+            if bad.any() and pool == 1:
                 assert np.all(np.abs(prob - u)[bad] < TIE), "hidden sample differs away from a tie"
                 ties += int(bad.sum())
+            elif bad.any():
+                # pooled units: one draw per group (the uniform of its first position) against the
+                # cumulative probabilities of the group (convRBM.py:259-267)
+                badg = bad.reshape(B, K, 1, Lf // pool, pool).any(axis=4)
+                cum = np.cumsum(prob.reshape(B, K, 1, Lf // pool, pool), axis=4)
+                ug = u.reshape(B, K, 1, Lf // pool, pool)[..., :1]
+                assert np.all(np.min(np.abs(cum - ug), axis=4)[badg] < TIE), "pooled hidden sample differs away from a tie"
+                ties += int(badg.sum())
         o.fantasy_h, o.fantasy_h_prime = h, (hp if ds else None)
         o.last_v_model = v
         o.gibbs_step += 1

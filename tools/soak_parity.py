@@ -16,6 +16,7 @@ import test_gpu_parity as T  # noqa: E402
 if __name__ == "__main__":
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    only = int(os.environ["SOAK_ONLY"]) if "SOAK_ONLY" in os.environ else None   # re-run one case of a seed
     bad = 0
     for case in range(n_cases):
         big = case % 4 == 3                              # every fourth case: large model / long sequences
@@ -40,16 +41,36 @@ if __name__ == "__main__":
             os.environ["CRBM_STATS"] = stats
         else:
             os.environ.pop("CRBM_STATS", None)
+        bshift, wscale = float(rng.uniform(2, 7)), float(rng.uniform(0.3, 1.5))
+        if only is not None and case != only:
+            continue
         t0 = time.time()
         try:
-            m, o = T.make_pair(K, M, ds=ds, batchsize=B, cd_k=k, Lf=Lf, bshift=float(rng.uniform(2, 7)), wscale=float(rng.uniform(0.3, 1.5)),
-                               pooling=pool)
+            m, o = T.make_pair(K, M, ds=ds, batchsize=B, cd_k=k, Lf=Lf, bshift=bshift, wscale=wscale, pooling=pool)
             D = synthetic_onehot(n, L, seed=case)
             m._trainingFct(D)
             o.train_step(D)
-            np.testing.assert_allclose(m.motifs.get_value(), o.W, rtol=2e-4, atol=2e-5)
-            np.testing.assert_allclose(m.bias.get_value(), o.b, rtol=2e-4, atol=2e-5)
-            np.testing.assert_allclose(m.c.get_value(), o.c, rtol=2e-4, atol=2e-5)
+            if only is not None:      # diagnosis of a single case: how many samples of the chain differ?
+                hh, hhp = m.get_fantasy()
+                vv = m.get_fantasy_visible()
+                print("  differing samples: visible %d of %d, hidden %d of %d; max |dW| %.3g" % (
+                    int((vv != o.last_v_model).any(axis=2).sum()), vv.shape[0] * vv.shape[3],
+                    int((hh != o.fantasy_h).sum()), hh.size, float(np.abs(m.motifs.get_value() - o.W).max())), flush=True)
+            tie_note = ""
+            try:
+                np.testing.assert_allclose(m.motifs.get_value(), o.W, rtol=2e-4, atol=2e-5)
+                np.testing.assert_allclose(m.bias.get_value(), o.b, rtol=2e-4, atol=2e-5)
+                np.testing.assert_allclose(m.c.get_value(), o.c, rtol=2e-4, atol=2e-5)
+            except AssertionError:
+                # With a few dozen chains one differing sample moves the model statistics by 1/(chains * Lf):
+                # legitimate only if every differing sample of the chain sits on a p == u tie.  Replay the
+                # chain of a fresh pair one step at a time from identical states (raises on anything else).
+                m2, o2 = T.make_pair(K, M, ds=ds, batchsize=B, cd_k=k, Lf=Lf, bshift=bshift, wscale=wscale, pooling=pool)
+                ties = T.assert_chain_steps(m2, o2, k)
+                if ties < 1:
+                    raise
+                tie_note = " (update differs through %d sample(s) on a p == u tie)" % ties
+                m, o = m2, o2
             h, hp = m.get_fantasy()
             mism = float((h != o.fantasy_h).mean())
             assert mism < 2e-3, ("chain mismatch", mism)
@@ -58,7 +79,7 @@ if __name__ == "__main__":
             s = m.motifHitSummary(D)
             np.testing.assert_allclose(s["max"], P.max(axis=(2, 3)), rtol=2e-4, atol=1e-6)
             np.testing.assert_allclose(s["position_mean"], P.mean(axis=(0, 2)), rtol=2e-4, atol=1e-6)
-            status = "ok"
+            status = "ok" + tie_note
         except Exception as e:   # report every failing shape, keep going
             bad += 1
             status = "FAIL %s" % (str(e)[:300].replace("\n", " "))
