@@ -613,6 +613,38 @@ def test_long_sequences_use_exact_division():
     np.testing.assert_allclose(model._topDownActivity(h, hp), o._topDownActivity(h, hp), rtol=1e-5, atol=2e-5)
 
 
+def test_exact_path_queue_of_double_stranded_chains():
+    """Double-stranded chain kernels queue the hidden units their coarse random field cannot decide
+    (2^-12 of all units) per block and resolve them after the pass.  One chain per tile with
+    2 x 64 x 2000 hidden units per step makes ~62 such units per block and step -- around the queue's
+    capacity, so both the queue and its overflow path (resolved in place) run -- and every sample is
+    compared with the oracle, ties only; then the same through a training step (fused or not)."""
+    K, M, Lf, B = 64, 8, 2000, 3
+    model, o = make_pair(K, M, ds=True, batchsize=B, Lf=Lf, cd_k=2, bshift=4.0, wscale=0.5)
+    import ctypes
+    from crbm_amd._lib import CrbmLaunchInfo
+    info = CrbmLaunchInfo()
+    hnd = model._h()                                   # creates the device handle (and model._lib)
+    model._lib.crbm_get_launch_info(hnd, ctypes.byref(info))
+    assert info.gibbs_seqs_per_tile <= 2, info.gibbs_seqs_per_tile
+    ties = assert_chain_steps(model, o, 3)
+    assert ties >= 0
+    # the same with a queue of three entries: nearly every undecided unit takes the overflow path
+    os.environ["CRBM_JIT_DEFINES"] = "-DCRBM_FIXQ_CAP=3"
+    try:
+        model1, o1 = make_pair(K, M, ds=True, batchsize=B, Lf=Lf, cd_k=2, bshift=4.0, wscale=0.5)
+        assert_chain_steps(model1, o1, 2)
+    finally:
+        del os.environ["CRBM_JIT_DEFINES"]
+    # a medium model whose tiles hold several chains (queue shared by the chains of a tile)
+    model2, o2 = make_pair(20, 15, ds=True, batchsize=16, Lf=486, cd_k=2, bshift=4.0)
+    assert_chain_steps(model2, o2, 3)
+    D = synthetic_onehot(12, 500, seed=3)
+    model2._trainingFct(D)
+    o2.train_step(D)
+    np.testing.assert_allclose(model2.motifs.get_value(), o2.W, rtol=RTOL, atol=2e-6)
+
+
 def test_full_size_statistics_are_additive():
     """Config #2 at 8192 data rows: the packed raw sums of a batch equal the sum
     of the raw sums of its two halves (what the RCCL all-reduce relies on), and
