@@ -131,6 +131,8 @@ struct crbm_handle {
   int gibbs_threads = 256, gibbs_grid = 0;
   // top-down variants of the Gibbs kernel: [0] dense tables (small models only), [1] set-bit walk
   GibbsLayout glv[2];
+  GibbsLayout gl_solo;                 // geometry of plain chain launches of the sparse variant when it differs (solo_threads > 0)
+  int solo_threads = 0, solo_grid = 0;
   int threadsv[2] = {256, 256}, gridv[2] = {0, 0};
   bool has_dense = false;
   int gibbs_wpe = 0;                   // register-allocation hint compiled into the sparse Gibbs kernel
@@ -315,10 +317,16 @@ int launch_gibbs(crbm_handle* h, int steps, hipStream_t s = nullptr, ReduceArgs*
   if (rc) return rc;
   GibbsArgs a;
   unsigned lds = 0;
+  const bool solo = !model_reduce && h->variant == 1 && h->solo_threads > 0;
+  const GibbsLayout gl_keep = h->gl;
+  const int threads_keep = h->gibbs_threads, grid_keep = h->gibbs_grid;
+  if (solo) { h->gl = h->gl_solo; h->gibbs_threads = h->solo_threads; h->gibbs_grid = h->solo_grid; }
   rc = prepare_gibbs(h, steps, model_reduce, &a, &lds);
+  const unsigned grid = (unsigned)h->gibbs_grid, threads = (unsigned)h->gibbs_threads;
+  if (solo) { h->gl = gl_keep; h->gibbs_threads = threads_keep; h->gibbs_grid = grid_keep; }
   if (rc) return rc;
   hipFunction_t fn = model_reduce ? h->jk.gibbs_sparse_stats : (h->variant ? h->jk.gibbs_sparse : h->jk.gibbs);
-  HIPCHK(jit_launch(fn, a, (unsigned)h->gibbs_grid, 1, (unsigned)h->gibbs_threads, lds, s));
+  HIPCHK(jit_launch(fn, a, grid, 1, threads, lds, s));
   h->gibbs_step += (uint32_t)steps;
   h->launches_since_read += 1;
   return CRBM_OK;
@@ -583,7 +591,9 @@ struct GibbsGeom {
   int S, threads, grid, lds;
 };
 
-GibbsGeom choose_gibbs_geometry(const ModelShape& ms, int Lf, int B, int num_cu, bool sparse) {
+// solo: geometry of launches that only advance the chains (crbm_gibbs_steps*, the chain launch of models
+// whose statistics run in kernels of their own): free of the 256-thread build of the fused variants.
+GibbsGeom choose_gibbs_geometry(const ModelShape& ms, int Lf, int B, int num_cu, bool sparse, bool solo = false) {
   const int forceS = env_int("CRBM_GIBBS_S", 0), forceT = env_int("CRBM_GIBBS_THREADS", 0);
   GibbsGeom best{1, 256, 1, 0};
   double best_score = -1.0;
@@ -595,7 +605,12 @@ GibbsGeom choose_gibbs_geometry(const ModelShape& ms, int Lf, int B, int num_cu,
     // measured: config #4 (two 256-thread blocks per CU) 2.62 -> 2.26 ms per launch with one 1024-thread
     // block; config #5 (three blocks per CU) is no faster with two 512-thread blocks -- so only when the
     // small blocks reach at most half the waves
-    if (threads > 256 && (ms.FUSE_STATS || best_occupancy > 0.5 || env_int("CRBM_GIBBS_MAX_THREADS", 1024) < threads)) continue;
+    // Solo launches of single-stranded models take the large blocks whenever they score better (config #2:
+    // one 1024-thread block of 32 chains per CU 22.7 us per launch against 23.8 with four 256-thread blocks:
+    // one table copy per CU, and the short last round of the v|h pass spreads over all SIMDs); double-stranded
+    // ones do not (config #5: 150 -> 153 / 156 us with 512 / 1024 threads -- the queue drain grows with the block).
+    const bool big_ok = solo ? !ms.DS : (!ms.FUSE_STATS && best_occupancy <= 0.5);
+    if (threads > 256 && (!big_ok || env_int("CRBM_GIBBS_MAX_THREADS", 1024) < threads)) continue;
     if (forceT > 0 && threads != forceT) continue;
     for (int S = 1; S <= std::min(B, 64); ++S) {
       if (forceS > 0 && S != forceS) continue;
@@ -655,6 +670,7 @@ int crbm_precompile(const crbm_config* cfg) {
   const GibbsGeom gs = choose_gibbs_geometry(ms, Lf_pc, cfg->batchsize, env_int("CRBM_NUM_CU", 256), true);
   int tb = gs.threads;
   if (ms.DENSE) tb = std::max(tb, choose_gibbs_geometry(ms, Lf_pc, cfg->batchsize, env_int("CRBM_NUM_CU", 256), false).threads);
+  tb = std::max(tb, choose_gibbs_geometry(ms, Lf_pc, cfg->batchsize, env_int("CRBM_NUM_CU", 256), true, true).threads);
   if (jit_compile(ms.K, ms.M, ms.DS, ms.G, ms.POOL, gibbs_wpe_hint(gs), gibbs_block_bound(tb), &code, &cached, &file, &err) != 0) {
     g_create_error = err;
     return CRBM_ERR_HIP;
@@ -711,6 +727,14 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
     hh->gridv[v] = geom.grid;
   }
   {
+    const GibbsGeom solo = choose_gibbs_geometry(hh->ms, hh->Lf, hh->B, hh->num_cu, true, true);
+    if (solo.lds > 0 && (solo.threads != hh->threadsv[1] || solo.S != hh->glv[1].S || solo.grid != hh->gridv[1])) {
+      hh->gl_solo = gibbs_layout(hh->ms, hh->Lf, solo.S, true);
+      hh->solo_threads = solo.threads;
+      hh->solo_grid = solo.grid;
+    }
+  }
+  {
     // The set-bit walk is the variant of every model (its cost follows the hidden activity,
     // ~2 % under the reference's sparsity target); CRBM_TOPDOWN=dense pins the table variant
     // of small models for A/B runs.  Never switched at run time: the two round differently.
@@ -720,7 +744,7 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
   }
   {
     std::string err;
-    const int tb = gibbs_block_bound(std::max(hh->has_dense ? hh->threadsv[0] : 0, hh->threadsv[1]));
+    const int tb = gibbs_block_bound(std::max(std::max(hh->has_dense ? hh->threadsv[0] : 0, hh->threadsv[1]), hh->solo_threads));
     if (jit_load(hh->K, hh->M, hh->ds, hh->G, hh->ms.POOL, hh->gibbs_wpe, tb, &hh->jk, &err) != 0) {
       g_create_error = "kernel specialisation failed: " + err;
       return bail(CRBM_ERR_HIP);
@@ -752,7 +776,7 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
   TRY(hipMalloc((void**)&hh->d_flags, 16)); TRY(hipMemset(hh->d_flags, 0, 16));
   TRY(hipMalloc((void**)&hh->d_ones, 16)); TRY(hipMemset(hh->d_ones, 0, 16));
   {
-    const size_t slots = (size_t)std::max(hh->gridv[0] * (hh->threadsv[0] / 64), hh->gridv[1] * (hh->threadsv[1] / 64)) + 64;
+    const size_t slots = (size_t)std::max(std::max(hh->gridv[0] * (hh->threadsv[0] / 64), hh->gridv[1] * (hh->threadsv[1] / 64)), hh->solo_grid * (hh->solo_threads / 64)) + 64;
     TRY(hipMalloc((void**)&hh->d_nset, slots * 4)); TRY(hipMemset(hh->d_nset, 0, slots * 4));
   }
   TRY(hipMalloc((void**)&hh->d_sums, (size_t)hh->sl.count * 4)); TRY(hipMemset(hh->d_sums, 0, (size_t)hh->sl.count * 4));
@@ -1657,8 +1681,10 @@ int crbm_get_launch_info(const crbm_handle* h, crbm_launch_info* out) {
   const StatsMfmaLayout st = stats_mfma_layout(h->ms, 1, h->Lf, 0, tabs);
   const int lds = std::max(st.region_floats * 4 + tabs, st.combine_bytes);
   out->nq = h->ms.NQ; out->group = h->G;
-  out->gibbs_grid = h->gibbs_grid; out->gibbs_block = h->gibbs_threads;
-  out->gibbs_seqs_per_tile = h->gl.S; out->gibbs_lds_bytes = h->gl.lds_bytes;
+  // the geometry of a plain chain launch (crbm_gibbs_steps*): the solo one where the model has it
+  const bool solo = h->variant == 1 && h->solo_threads > 0;
+  out->gibbs_grid = solo ? h->solo_grid : h->gibbs_grid; out->gibbs_block = solo ? h->solo_threads : h->gibbs_threads;
+  out->gibbs_seqs_per_tile = solo ? h->gl_solo.S : h->gl.S; out->gibbs_lds_bytes = solo ? h->gl_solo.lds_bytes : h->gl.lds_bytes;
   out->stats_grid_x = h->stats_rows > 0 ? h->stats_rows
                                         : h->num_cu * std::max(1, std::min(2048 / st.threads, (160 * 1024) / std::max(1, lds)));
   out->stats_grid_y = 1;

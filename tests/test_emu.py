@@ -23,7 +23,7 @@ def _gcc_file(name):
 @pytest.fixture(scope="module")
 def emu_env():
     if not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in SOURCES):
-        cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+        cmd = ["g++", "-std=c++17", "-O1", "-g1", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
                "-fno-sanitize-recover=undefined", "-mf16c", "-fPIC", "-shared", "-I", os.path.join(EMU, "shim"), "-I", CSRC,
                os.path.join(EMU, "emu_main.cpp"), "-o", LIB, "-lpthread"]
         subprocess.check_call(cmd)
