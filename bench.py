@@ -313,7 +313,8 @@ def main():
                          "valu_wave_insts_per_launch": valu_insts,
                          "valu_issue_us": (valu_insts * 4 / (256 * 4) / 2.4e3) if valu_insts else None,
                          "note": "achieved = algorithmic bytes of the dense fp32 layout (SURVEY 8d) / launch time; "
-                                 "the kernel keeps chain state bit-packed, so real HBM traffic is state_bytes_per_launch"},
+                                 "the kernel keeps chain state bit-packed, so real HBM traffic is state_bytes_per_launch "
+                                 "(and frac can exceed 1: the dense-layout roofline stops binding once the state is packed)"},
             "launch": {"grid": info.gibbs_grid, "block": info.gibbs_block, "chains_per_tile": info.gibbs_seqs_per_tile,
                        "lds_bytes": info.gibbs_lds_bytes, "table_group": info.group},
         }
