@@ -17,10 +17,18 @@ chain applied to one batch of 8192 chains per GPU -- the PCD-1 Gibbs step of
 BASELINE.json's metric, config #2 (10 motifs of length 15, visible 4x200,
 single-stranded); chains are sharded over ranks with no data-path collective
 (weak scaling), so `value` = N_gpus * K / T in "8192-chain batch Gibbs steps
-per second", T = the HIP-event time of the K launches on the library's stream
-(max over ranks).  The host wall clock around the same region is reported as
-`wall_ms_per_step`.  Inputs (chain state, parameters) are resident in HBM when
-the timed region starts.
+per second", T = the HOST clock around the K launches, bracketed by a barrier
+and a stream synchronisation on both sides, max over ranks (metric_version 3;
+round 2 quoted the HIP-event time, which is still reported as
+`device_ms_per_step` and is what the roofline object prices the kernel with).
+Inputs (chain state, parameters) are resident in HBM when the timed region
+starts.
+
+With one GPU and `rocprofv3` on PATH the counters behind the roofline object
+(VALU issue cycles, HBM bytes) are collected for THIS box by three short child
+runs of tools/prof_gibbs.py under `rocprofv3 --pmc`, started before this process
+touches the GPU; otherwise the tracked values of profiles/gibbs_traffic.json
+are quoted and marked as not measured in this run.
 """
 import argparse
 import ctypes
@@ -121,6 +129,7 @@ def cpu_baseline(cfg, budget_s=10.0):
            "sample": "%d Gibbs steps of the full %d-chain batch (oracle/crbm_cpu.c, dense fp32, OpenMP, %d threads), %.1f s"
                      % (done, n, cores, dt),
            "value_1thread": (done1 / dt1) * sub / n,
+           "parallel_efficiency": (done / dt) / ((done1 / dt1) * sub / n * cores),
            "sample_1thread": "%d Gibbs steps of %d chains on 1 thread (%.1f s), scaled to the %d-chain batch"
                              % (done1, sub, dt1, n)}
     try:
@@ -146,6 +155,65 @@ def cpu_baseline(cfg, budget_s=10.0):
     return out
 
 
+PMC_PASSES = (("valu", "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_TRANS_F32 SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT"),
+              ("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE"))
+N_SIMD = 256 * 4          # MI355X: 256 CUs x 4 SIMDs
+N_SE = 32                 # SQ_BUSY_CYCLES is summed over the 32 shader engines
+
+
+def pmc_of_csv(path, kernel_prefix):
+    """mean per dispatch of every counter of the kernels whose name starts with `kernel_prefix`
+    (rocprofv3 counter_collection.csv: one row per counter instance; the first quarter of the dispatches is dropped)"""
+    import csv
+    from collections import defaultdict
+    acc = defaultdict(lambda: defaultdict(float))
+    for r in csv.DictReader(open(path)):
+        if r["Kernel_Name"].startswith(kernel_prefix):
+            acc[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+    out = {}
+    for name, per in acc.items():
+        ids = sorted(per, key=int)
+        ids = ids[len(ids) // 4:]
+        out[name] = sum(per[i] for i in ids) / len(ids)
+    return out
+
+
+def measure_pmc(config, launches=24, timeout_s=150):
+    """The chain kernel's counters on THIS box: one child `rocprofv3 --kernel-trace --pmc ...` per pass
+    (FETCH_SIZE and WRITE_SIZE cannot share one, MI355X_MICROARCH.md), the program directly behind `--`.
+    Must run before this process initialises the GPU.  Returns ({counter: mean per launch}, note)."""
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    vals = {}
+    tmp = tempfile.mkdtemp(prefix="crbm_pmc_")
+    try:
+        for tag, counters in PMC_PASSES:
+            d = os.path.join(tmp, tag)
+            cmd = [exe, "--kernel-trace", "--pmc"] + counters.split() + ["--output-format", "csv", "-d", d, "-o", "p", "--",
+                   sys.executable, os.path.join(ROOT, "tools", "prof_gibbs.py"), config, str(launches)]
+            try:
+                r = subprocess.run(cmd, cwd=tmp, env=dict(os.environ, TMPDIR=tmp), stdout=subprocess.PIPE,
+                                   stderr=subprocess.STDOUT, timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                return None, "rocprofv3 pass '%s' timed out" % tag
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, "rocprofv3 pass '%s' failed (rc %d)" % (tag, r.returncode)
+            for f in files:
+                vals.update(pmc_of_csv(f, "crbm_gibbs"))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    need = ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES")
+    if any(k not in vals for k in need):
+        return None, "rocprofv3 output lacks %s" % [k for k in need if k not in vals]
+    return vals, "measured in this run: rocprofv3 --kernel-trace --pmc (passes: %s) of tools/prof_gibbs.py %s %d" % (
+        " | ".join(c for _, c in PMC_PASSES), config, launches)
+
+
 def free_port():
     s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
     s.bind(("127.0.0.1", 0))
@@ -158,11 +226,13 @@ def spawn_ranks(n, argv):
     """Start n ranks of this script (nothing in this process has touched a GPU), relay rank 0's
     stdout, fail if any rank fails."""
     port = free_port()
+    secret = os.urandom(16).hex()
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("CRBM_JOB_SECRET", secret)        # keys the control plane's message authentication
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     out = b""
@@ -191,6 +261,7 @@ def main():
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="do not collect the chain kernel's PMC counters in child runs")
     ap.add_argument("--multi-step", action="store_true", help="also time 16 Gibbs steps per launch (informational)")
     args = ap.parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -207,6 +278,14 @@ def main():
     # ranks on one device).  The driver's runs never set it.
     share_gpu = os.environ.get("CRBM_BENCH_SHARE_GPU", "0") == "1"
     device = 0 if share_gpu else local_rank
+
+    # counters of the chain kernel on this box (children under rocprofv3, before this process touches the GPU)
+    pmc, pmc_note = None, "not collected (multi-rank run, or --no-pmc)"
+    if world == 1 and not args.no_pmc and os.environ.get("CRBM_BENCH_PMC", "1") != "0":
+        try:
+            pmc, pmc_note = measure_pmc(args.config)
+        except Exception as e:                      # a report, never a reason to lose the line
+            pmc, pmc_note = None, "rocprofv3 child failed: %s" % str(e)[:200]
 
     from crbm_amd import _lib
     from crbm_amd import dist as cdist
@@ -232,7 +311,8 @@ def main():
     # steps, 23.6 after 500, 23.5 after 2000; 22.8 in the steady state of a 2000-launch run).
     # (as launches of k steps like the timed ones: every launch of the chain kernel in this process is then
     # the same work, and a profiler's per-kernel average equals avg_launch_us)
-    for _ in range(max(1, int(os.environ.get("CRBM_BENCH_BURNIN", "500")) // k)):
+    burn_launches = max(1, int(os.environ.get("CRBM_BENCH_BURNIN", "500")) // k)
+    for _ in range(burn_launches):
         model._call("crbm_gibbs_steps_async", k)
     model._call("crbm_sync")
     for _ in range(args.warmup):
@@ -248,7 +328,8 @@ def main():
     wall, kernel_s = control.allreduce_max([wall, total_ms.value / 1e3])
     launches = args.steps
     steps_done = args.steps * k                  # Gibbs steps per rank in the timed region
-    value = world * steps_done / kernel_s
+    value = world * steps_done / wall            # host clock (barrier + synchronise on both sides), max over ranks
+    value_device = world * steps_done / kernel_s
 
     # informational, opt-in (--multi-step): the same chain advanced 16 steps per launch (no
     # per-launch fixed cost).  Off by default so that every crbm_gibbs launch of a default
@@ -270,51 +351,78 @@ def main():
         lib.crbm_get_launch_info(h, ctypes.byref(info))
         alg_bytes = algorithmic_bytes_per_seq(cfg["K"], cfg["M"], cfg["L"], cfg["ds"]) * cfg["chains"] * k
         avg_launch_s = kernel_s / launches
-        achieved = alg_bytes / avg_launch_s / 1e9
-        # HBM bytes per launch come from separate rocprofv3 --pmc passes of the same command (they
-        # cannot be collected inside this process); the tracked summary is quoted, with its source
-        traffic = valu_insts = traffic_src = None
-        tfile = os.path.join(ROOT, "profiles", "gibbs_traffic.json")
-        if os.path.exists(tfile):
+        alg_gbs = alg_bytes / avg_launch_s / 1e9
+        # Counters of the chain kernel: measured on this box by the child runs above, else the tracked
+        # summary of an earlier box (profiles/gibbs_traffic.json), named as such
+        counters, counters_src = pmc, pmc_note
+        if counters is None:
+            tfile = os.path.join(ROOT, "profiles", "gibbs_traffic.json")
             try:
-                pmc = json.load(open(tfile)).get(args.config, {})
-                traffic = pmc.get("hbm_bytes_per_launch")
-                valu_insts = pmc.get("valu_wave_insts_per_launch")
-                traffic_src = pmc.get("source")
+                t = json.load(open(tfile)).get(args.config, {})
+                counters = t.get("counters")
+                counters_src = "NOT measured in this run (%s); quoted from %s" % (pmc_note, t.get("source"))
             except Exception:
-                traffic = valu_insts = traffic_src = None
+                counters = None
+        roof = {"kernel": "crbm_gibbs_sparse" if info.gibbs_sparse else "crbm_gibbs",   # name in the rocprofv3 summaries
+                "avg_launch_us": 1e6 * avg_launch_s, "counters_source": counters_src,
+                "measured_copy_gbs": float(copy_gbs.value),
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "algorithmic_gbs": alg_gbs, "algorithmic_frac": alg_gbs / HBM_PEAK_GBS,
+                "algorithmic_note": "SURVEY 8(d) bytes of the reference's dense fp32 layout / launch time / 8 TB/s: an "
+                                    "equivalent-dense rate, not a bandwidth utilisation (the chain state is bit-packed, so it may "
+                                    "exceed 1); north_star's '>= 50 % of HBM roofline' is stated in these units",
+                "state_bytes_per_launch": int(lib.crbm_gibbs_state_bytes(h)),
+                "us_per_step_at_16_steps_per_launch": us_per_step_k16}
+        if counters:
+            # HBM bytes: 2 x FETCH_SIZE + WRITE_SIZE (KB) -- gfx950 tallies a wide streaming read at half its bytes
+            # (MI355X_MICROARCH.md, HBM).  VALU issue: SQ_ACTIVE_INST_VALU counts quad-cycles in which a wave has a
+            # vector instruction in issue; summed over waves / 1024 SIMDs = cycles a SIMD's vector issue is busy.
+            # SQ_BUSY_CYCLES / 32 shader engines = the launch in shader cycles: the fraction needs no clock.
+            traffic = (2.0 * counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024.0
+            launch_cycles = counters["SQ_BUSY_CYCLES"] / N_SE
+            valu_cycles = 4.0 * counters["SQ_ACTIVE_INST_VALU"] / N_SIMD
+            roof.update({
+                "bound": "valu_issue", "achieved": valu_cycles, "peak": launch_cycles,
+                "unit": "shader cycles per launch: a SIMD's vector-issue-busy cycles (achieved) vs the launch (peak)",
+                "frac": valu_cycles / launch_cycles,
+                "traffic": traffic, "hbm_actual_gbs": traffic / avg_launch_s / 1e9,
+                "hbm_actual_frac": traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS,
+                "valu_wave_insts_per_launch": counters["SQ_INSTS_VALU"],
+                "valu_trans_insts_per_launch": counters.get("SQ_INSTS_VALU_TRANS_F32"),
+                "valu_cycles_per_wave_inst": 4.0 * counters["SQ_ACTIVE_INST_VALU"] / counters["SQ_INSTS_VALU"],
+                "valu_issue_us": valu_cycles / (launch_cycles / (1e6 * avg_launch_s)),
+                "shader_clock_mhz_during_launch": launch_cycles / (1e6 * avg_launch_s),
+                "lds_bank_conflict_share": (counters["SQ_LDS_BANK_CONFLICT"] / counters["SQ_LDS_IDX_ACTIVE"])
+                                           if counters.get("SQ_LDS_IDX_ACTIVE") else None,
+                "note": "the kernel is bound by vector-instruction issue (and the LDS gathers behind it), not by HBM: "
+                        "frac = SIMD vector-issue-busy cycles / launch cycles, both from PMC counters of the same launches "
+                        "(profiled launches run a few per cent slower than the timed ones); hbm_actual_frac prices the "
+                        "measured HBM bytes against 8 TB/s"})
+        else:
+            roof.update({"bound": "valu_issue", "achieved": None, "peak": None, "unit": "shader cycles per launch",
+                         "frac": None, "traffic": None, "note": "no counters available: " + str(counters_src)})
         out = {
             "metric": "Gibbs-steps/sec (PCD-1) at batch 8192x4x200, 10 motifs len 15" if args.config == "cfg2"
                       else "Gibbs-steps/sec, " + cfg["desc"],
             "value": value, "unit": "8192-chain batch Gibbs steps/s (summed over GPUs)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * kernel_s / args.steps,
-            "wall_ms_per_step": 1e3 * wall / args.steps,
+            "ms_per_step": 1e3 * wall / args.steps,
+            "device_ms_per_step": 1e3 * kernel_s / args.steps, "value_device": value_device,
+            "metric_version": 3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic", "chain_burn_in_steps": int(os.environ.get("CRBM_BENCH_BURNIN", "500")),
+            "dtype": "f32", "data": "synthetic",
+            "warmup_effective": args.warmup + burn_launches, "chain_burn_in_launches": burn_launches,
             "config": {"workload": args.config + ": " + cfg["desc"], "chains_per_gpu": cfg["chains"],
                        "gibbs_steps_per_launch": k, "visible": "4x%d" % cfg["L"],
                        "hidden": "%dx%d" % (cfg["K"], cfg["L"] - cfg["M"] + 1),
                        "parallelism": "chains sharded over %d GPU(s), no collective in the Gibbs step" % world,
                        "hidden_activity": activity},
-            "timing": "HIP events on the library's stream around the K launches, max over ranks; "
-                      "wall_ms_per_step is the host clock around the same region (barrier + synchronise on both sides)",
+            "timing": "value and ms_per_step: host clock around the K launches, barrier + stream synchronise on both sides, "
+                      "max over ranks (metric_version 3; version 2 = round 2 quoted the HIP-event time, now device_ms_per_step / "
+                      "value_device; version 1 = round 1, host clock).  warmup_effective counts the chain burn-in launches "
+                      "(chains start at h = 0) together with the --warmup launches",
             "chain_steps_per_s": value * cfg["chains"],
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "measured_copy_gbs": float(copy_gbs.value),
-                         "frac_of_measured_copy": achieved / float(copy_gbs.value) if copy_gbs.value > 0 else None,
-                         "kernel": "crbm_gibbs_sparse" if info.gibbs_sparse else "crbm_gibbs",   # name in the rocprofv3 summaries
-                         "avg_launch_us": 1e6 * avg_launch_s,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "state_bytes_per_launch": int(lib.crbm_gibbs_state_bytes(h)),
-                         "us_per_step_at_16_steps_per_launch": us_per_step_k16,
-                         # what actually binds the kernel (PMC, profiles/): VALU issue time of one launch
-                         "valu_wave_insts_per_launch": valu_insts,
-                         "valu_issue_us": (valu_insts * 4 / (256 * 4) / 2.4e3) if valu_insts else None,
-                         "note": "achieved = algorithmic bytes of the dense fp32 layout (SURVEY 8d) / launch time; "
-                                 "the kernel keeps chain state bit-packed, so real HBM traffic is state_bytes_per_launch "
-                                 "(and frac can exceed 1: the dense-layout roofline stops binding once the state is packed)"},
+            "roofline": roof,
             "launch": {"grid": info.gibbs_grid, "block": info.gibbs_block, "chains_per_tile": info.gibbs_seqs_per_tile,
                        "lds_bytes": info.gibbs_lds_bytes, "table_group": info.group},
         }
@@ -349,29 +457,52 @@ def main():
     if not args.no_train:
         try:
             rccl = world > 1 and not share_gpu
-            if rccl:
-                # the 128-byte RCCL id travels over the control plane; all ranks were built from the
-                # same seeded parameters, the broadcast makes that a guarantee
-                uid = cdist.exchange_unique_id(rank, world, control=control)
-                buf = (ctypes.c_uint8 * _lib.UNIQUE_ID_BYTES).from_buffer_copy(uid)
-                model._call("crbm_comm_init", buf, world, rank)
-                model._call("crbm_comm_broadcast_state", 0)
             n = cfg["chains"]
             D = synthetic_onehot(n, cfg["L"], seed=1234 + rank)
             model._call("crbm_dataset_upload", fptr(D), n, cfg["L"])
             tms = ctypes.c_float()
-            model._call("crbm_time_train", 0, n, 5, ctypes.byref(tms))
             tsteps = max(10, min(200, args.steps // 10))
-            barrier()
-            t1 = time.perf_counter()
-            model._call("crbm_time_train", 0, n, tsteps, ctypes.byref(tms))
-            barrier()
-            twall = time.perf_counter() - t1
-            twall, tdev = control.allreduce_max([twall, tms.value / 1e3])
+
+            def timed_steps():
+                model._call("crbm_time_train", 0, n, 5, ctypes.byref(tms))
+                barrier()
+                t1 = time.perf_counter()
+                model._call("crbm_time_train", 0, n, tsteps, ctypes.byref(tms))
+                barrier()
+                return control.allreduce_max([time.perf_counter() - t1, tms.value / 1e3])
+
+            local_dev = rccl_init_s = allreduce_us = None
+            if rccl:
+                # the same steps first WITHOUT the communicator (every rank for itself: no collective, replicas drift
+                # apart, the broadcast below makes them one model again): the difference to the steps with it is
+                # what the all-reduce adds to the critical path of a step
+                _, local_dev = timed_steps()
+                # the 128-byte RCCL id travels over the control plane
+                t2 = time.perf_counter()
+                uid = cdist.exchange_unique_id(rank, world, control=control)
+                buf = (ctypes.c_uint8 * _lib.UNIQUE_ID_BYTES).from_buffer_copy(uid)
+                model._call("crbm_comm_init", buf, world, rank)
+                model._call("crbm_comm_broadcast_state", 0)
+                rccl_init_s = control.allreduce_max([time.perf_counter() - t2])[0]
+            twall, tdev = timed_steps()
             train = {"train_steps_per_s": tsteps / tdev, "global_batch": n * world, "cd_k": k,
                      "all_reduce": "rccl" if rccl else "none", "ms_per_train_step": 1e3 * tdev / tsteps,
-                     "wall_ms_per_train_step": 1e3 * twall / tsteps, "steps": tsteps}
+                     "wall_ms_per_train_step": 1e3 * twall / tsteps, "steps": tsteps,
+                     "statistics_dtype": "P enters the MFMA contraction as two f16 halves (22 significant bits; fp32 has 24), "
+                                         "accumulation in fp32; the chain itself computes in f32"}
             if rccl:
+                ams = ctypes.c_float()
+                model._call("crbm_time_allreduce", 10, ctypes.byref(ams))
+                barrier()
+                model._call("crbm_time_allreduce", 100, ctypes.byref(ams))
+                allreduce_us = control.allreduce_max([1e3 * ams.value / 100])[0]
+                train.update({"ms_per_train_step_without_all_reduce": 1e3 * local_dev / tsteps,
+                              "all_reduce_us": 1e6 * (tdev - local_dev) / tsteps,
+                              "all_reduce_alone_us": allreduce_us, "rccl_init_s": rccl_init_s,
+                              "all_reduce_note": "all_reduce_us = device time of a step with the communicator minus the same step "
+                                                 "without it (what the collective adds to the critical path); all_reduce_alone_us = "
+                                                 "back-to-back ncclAllReduce launches of the %d-float sums buffer, HIP events"
+                                                 % int(lib.crbm_sums_count(h))})
                 sums = control.gather(cdist.replica_checksum(model))
                 train["replicas_identical"] = len(set(sums)) == 1
                 failed = failed or not train["replicas_identical"]

@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libcrbm_hip.so")
 
 UNIQUE_ID_BYTES = 128
+ABI_VERSION = 2          # CRBM_AMD_ABI_VERSION of include/crbm_amd.h
 
 CRBM_OK = 0
 ERR_INVALID, ERR_HIP, ERR_NOT_ONEHOT, ERR_NOT_BINARY, ERR_RCCL, ERR_NO_GPU = -1, -2, -3, -4, -5, -6
@@ -76,7 +77,7 @@ SIGNATURES = {
     "crbm_dataset_select": (_I32, [_H, _I32]),
     "crbm_train_step_resident": (_I32, [_H, _I32, _I32]),
     "crbm_train_epoch_resident": (_I32, [_H, _I32]),
-    "crbm_train_epoch_sharded": (_I32, [_H, _I32, _I32]),
+    "crbm_train_epoch_sharded": (_I32, [_H, _I32, _I32, _I32]),
     "crbm_gibbs_steps": (_I32, [_H, _I32]),
     "crbm_gibbs_steps_async": (_I32, [_H, _I32]),
     "crbm_sync": (_I32, [_H]),
@@ -104,6 +105,7 @@ SIGNATURES = {
     "crbm_sums_count": (_I32, [_H]),
     "crbm_train_local": (_I32, [_H, _F, _I32, _I32, _F]),
     "crbm_train_apply": (_I32, [_H, _F, _I32]),
+    "crbm_time_allreduce": (_I32, [_H, _I32, _F]),
     "crbm_get_launch_info": (_I32, [_H, ctypes.POINTER(CrbmLaunchInfo)]),
     "crbm_copy_bandwidth": (_I32, [_H, ctypes.c_int64, _I32, _F]),
     "crbm_gibbs_state_bytes": (ctypes.c_int64, [_H]),
@@ -130,7 +132,7 @@ def load():
         fn = getattr(lib, name)     # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.crbm_abi_version() != 1:
+    if lib.crbm_abi_version() != ABI_VERSION:
         raise CrbmLibraryError("ABI version mismatch")
     _lib = lib
     return lib

@@ -500,9 +500,13 @@ class CRBM(object):
             if sharded:
                 # each rank uploads only the rows it owns of every mini-batch (1/world of the set)
                 from . import dist
+                # every rank knows every share: all of them refuse together (a lone raise on the empty
+                # rank would leave the others waiting in the all-reduce for ever)
+                empty = dist.empty_shards(ntrain, self.batchsize, self.world_size)
+                if empty:
+                    raise Exception("fewer training rows than ranks: rank(s) %s would own none of the %d rows"
+                                    % (empty, ntrain))
                 mine = dist.shard_rows(ntrain, self.batchsize, self.rank, self.world_size)
-                if mine.size == 0:
-                    raise Exception("fewer training rows than ranks: rank %d owns none" % self.rank)
                 self._upload(training_data[mine], 0)
                 if evaluates:
                     ntest = self._upload(test_data, 1)[0]
@@ -515,7 +519,7 @@ class CRBM(object):
             # the batch loop of convRBM.py:612-615 runs inside the library: the steps are
             # enqueued back to back, with one host synchronisation per epoch
             if sharded:
-                self._call("crbm_train_epoch_sharded", self.batchsize, ntrain)
+                self._call("crbm_train_epoch_sharded", self.batchsize, ntrain, int(training_data.shape[-1]))
             else:
                 self._call("crbm_train_epoch_resident", self.batchsize)
             if not evaluates:

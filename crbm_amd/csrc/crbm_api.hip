@@ -1040,23 +1040,28 @@ int crbm_train_epoch_resident(crbm_handle* h, int32_t batchsize) {
 // [start + n*r/R, start + n*(r+1)/R) (n = end - start) and the resident set is their
 // concatenation in slice order (crbm_amd.dist.shard_rows builds it), so a rank
 // uploads 1/R of the data instead of all of it.
-int crbm_train_epoch_sharded(crbm_handle* h, int32_t batchsize, int32_t total_rows) {
+int crbm_train_epoch_sharded(crbm_handle* h, int32_t batchsize, int32_t total_rows, int32_t L) {
   ENTER();
   const int slot = h->slot;
   ARGCHK(batchsize >= 1 && total_rows >= 1, "batchsize and total_rows must be positive");
-  const int L = h->dataset_L[slot], LW = letter_words(std::max(L, 1));
+  // L comes from the caller, not from this rank's slot: a rank with an empty share has nothing resident,
+  // and all ranks must divide the all-reduced sums by the same counts
+  int rc = check_data_shape(h, 1, L);
+  if (rc) return rc;
+  const int LW = letter_words(L);
   long have = 0;
   for (int start = 0; start < total_rows; start += batchsize) {
     const long n = std::min(total_rows, start + batchsize) - start;
     have += (n * (h->rank + 1)) / h->nranks - (n * h->rank) / h->nranks;
   }
   ARGCHK(have == h->dataset_n[slot], "resident rows do not match this rank's share of total_rows");
+  ARGCHK(have == 0 || h->dataset_L[slot] == L, "resident rows have another sequence length than L");
   ARGCHK(have > 0 || h->comm, "no resident data set (call crbm_dataset_upload)");
   size_t off = 0;
   for (int start = 0; start < total_rows; start += batchsize) {
     const long n = std::min(total_rows, start + batchsize) - start;
     const int mine = (int)((n * (h->rank + 1)) / h->nranks - (n * h->rank) / h->nranks);
-    int rc = train_core(h, h->dataset[slot].p + off * LW, mine, L);
+    rc = train_core(h, h->dataset[slot].p + off * LW, mine, L);
     if (rc) return rc;
     off += (size_t)mine;
   }
@@ -1671,6 +1676,22 @@ int crbm_train_apply(crbm_handle* h, const float* sums_in, int32_t L_data) {
   int rc = launch_update(h, L_data);
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(h->stream));
+  return CRBM_OK;
+}
+
+int crbm_time_allreduce(crbm_handle* h, int32_t launches, float* total_ms) {
+  ENTER();
+  ARGCHK(launches >= 1 && total_ms, "bad argument");
+  *total_ms = 0.f;
+  if (!h->comm) return CRBM_OK;
+  HIPCHK(hipEventRecord(h->ev0, h->stream));
+  for (int i = 0; i < launches; ++i) {
+    ncclResult_t r = g_rccl.AllReduce(h->d_sums, h->d_sums, (size_t)h->sl.count, ncclFloat, ncclSum, h->comm, h->stream);
+    if (r != ncclSuccess) return fail(h, CRBM_ERR_RCCL, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r));
+  }
+  HIPCHK(hipEventRecord(h->ev1, h->stream));
+  HIPCHK(hipEventSynchronize(h->ev1));
+  HIPCHK(hipEventElapsedTime(total_ms, h->ev0, h->ev1));
   return CRBM_OK;
 }
 

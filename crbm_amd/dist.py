@@ -14,8 +14,9 @@ scalars a benchmark reduces.  The data path -- the per-step all-reduce -- is
 RCCL over xGMI inside the library.
 """
 import ctypes
+import hashlib
+import hmac
 import os
-import pickle
 import socket
 import struct
 import time
@@ -26,7 +27,9 @@ from . import _lib
 
 _ID_PORT_OFFSET = 17
 _PORT_TRIES = 8            # rank 0 binds the first free port of MASTER_PORT + 17 + 101*i
-_MAGIC = b"CRBMCTL1"
+_MAGIC = b"CRBMCTL2"
+_HANDSHAKE_TIMEOUT = 5.0   # seconds a fresh connection gets to identify itself (a silent stranger must not stall the accept loop)
+_MAX_MSG = 1 << 32         # largest frame accepted (checkpoint gathers are tens of MB)
 
 
 def env_rank_world():
@@ -51,6 +54,14 @@ def shard_rows(total, batchsize, rank, world):
     return np.concatenate(rows) if rows else np.zeros(0, dtype=np.int64)
 
 
+def empty_shards(total, batchsize, world):
+    """Ranks that own no row at all of a `total`-row data set (every rank can compute this: fit()
+    must fail on ALL ranks, not only on the empty one, or the others hang in the all-reduce)."""
+    return [r for r in range(world)
+            if all(shard_range(min(total, s + batchsize) - s, r, world)[0] ==
+                   shard_range(min(total, s + batchsize) - s, r, world)[1] for s in range(0, total, batchsize))]
+
+
 def make_unique_id():
     """A fresh 128-byte RCCL id (crbm_comm_unique_id); call on one rank and ship it to the others."""
     lib = _lib.load()
@@ -61,9 +72,134 @@ def make_unique_id():
     return bytes(buf)
 
 
-# ---------------------------------------------------------------- control plane
-def _send_msg(sock, payload):
-    sock.sendall(struct.pack("<Q", len(payload)) + payload)
+# ---------------------------------------------------------------- wire format
+# Only plain data travels: None, bool, int, float, bytes, str, list/tuple, dict with str keys and
+# NumPy arrays of numeric dtype -- a tagged binary encoding decoded by this module alone.  Nothing a
+# peer sends is ever executed or unpickled (pickle.loads on bytes from a TCP peer).
+_NUMERIC_KINDS = "biuf"
+
+
+def _enc(obj, out):
+    if obj is None:
+        out.append(b"N")
+    elif isinstance(obj, (bool, np.bool_)):
+        out.append(b"T" if obj else b"F")
+    elif isinstance(obj, (int, np.integer)):
+        v = int(obj)
+        if -(1 << 63) <= v < (1 << 63):
+            out.append(b"i" + struct.pack("<q", v))
+        else:                                            # 64-bit checksums, seeds
+            raw = v.to_bytes((v.bit_length() + 8) // 8, "little", signed=True)
+            out.append(b"I" + struct.pack("<I", len(raw)) + raw)
+    elif isinstance(obj, (float, np.floating)):
+        out.append(b"f" + struct.pack("<d", float(obj)))
+    elif isinstance(obj, (bytes, bytearray)):
+        out.append(b"b" + struct.pack("<Q", len(obj)) + bytes(obj))
+    elif isinstance(obj, str):
+        raw = obj.encode("utf-8")
+        out.append(b"s" + struct.pack("<Q", len(raw)) + raw)
+    elif isinstance(obj, (list, tuple)):
+        out.append((b"l" if isinstance(obj, list) else b"t") + struct.pack("<Q", len(obj)))
+        for item in obj:
+            _enc(item, out)
+    elif isinstance(obj, dict):
+        out.append(b"d" + struct.pack("<Q", len(obj)))
+        for key, val in obj.items():
+            if not isinstance(key, str):
+                raise TypeError("control plane: dict keys must be str, got %r" % type(key))
+            _enc(key, out)
+            _enc(val, out)
+    elif isinstance(obj, np.ndarray):
+        if obj.dtype.kind not in _NUMERIC_KINDS:
+            raise TypeError("control plane: arrays must be numeric, got dtype %s" % obj.dtype)
+        arr = np.ascontiguousarray(obj)
+        dt = arr.dtype.str.encode("ascii")
+        out.append(b"a" + struct.pack("<BB", len(dt), arr.ndim) + dt + struct.pack("<%dQ" % arr.ndim, *arr.shape))
+        out.append(arr.tobytes())
+    else:
+        raise TypeError("control plane: cannot send %r" % type(obj))
+
+
+def encode(obj):
+    out = []
+    _enc(obj, out)
+    return b"".join(out)
+
+
+class _Reader(object):
+    def __init__(self, buf):
+        self.buf, self.pos = memoryview(buf), 0
+
+    def take(self, n):
+        if n < 0 or self.pos + n > len(self.buf):
+            raise ValueError("control plane: truncated message")
+        part = self.buf[self.pos:self.pos + n]
+        self.pos += n
+        return part
+
+    def unpack(self, fmt):
+        return struct.unpack(fmt, self.take(struct.calcsize(fmt)))
+
+
+def _dec(r, depth=0):
+    if depth > 32:
+        raise ValueError("control plane: message nested too deeply")
+    tag = bytes(r.take(1))
+    if tag == b"N":
+        return None
+    if tag in (b"T", b"F"):
+        return tag == b"T"
+    if tag == b"i":
+        return r.unpack("<q")[0]
+    if tag == b"I":
+        return int.from_bytes(bytes(r.take(r.unpack("<I")[0])), "little", signed=True)
+    if tag == b"f":
+        return r.unpack("<d")[0]
+    if tag == b"b":
+        return bytes(r.take(r.unpack("<Q")[0]))
+    if tag == b"s":
+        return bytes(r.take(r.unpack("<Q")[0])).decode("utf-8")
+    if tag in (b"l", b"t"):
+        items = [_dec(r, depth + 1) for _ in range(r.unpack("<Q")[0])]
+        return items if tag == b"l" else tuple(items)
+    if tag == b"d":
+        out = {}
+        for _ in range(r.unpack("<Q")[0]):
+            key = _dec(r, depth + 1)
+            if not isinstance(key, str):
+                raise ValueError("control plane: bad dict key")
+            out[key] = _dec(r, depth + 1)
+        return out
+    if tag == b"a":
+        nd, ndim = r.unpack("<BB")
+        dt = np.dtype(bytes(r.take(nd)).decode("ascii"))
+        if dt.kind not in _NUMERIC_KINDS or ndim > 8:
+            raise ValueError("control plane: bad array header")
+        shape = r.unpack("<%dQ" % ndim)
+        count = 1
+        for d in shape:
+            count *= d
+        return np.frombuffer(bytes(r.take(count * dt.itemsize)), dtype=dt).reshape(shape).copy()
+    raise ValueError("control plane: unknown tag %r" % tag)
+
+
+def decode(buf):
+    r = _Reader(buf)
+    obj = _dec(r)
+    if r.pos != len(r.buf):
+        raise ValueError("control plane: trailing bytes")
+    return obj
+
+
+def job_secret(world, port):
+    """Key of the per-message HMAC.  A launcher that wants real authentication passes a random
+    CRBM_JOB_SECRET to every rank (bench.py's own spawner does); otherwise the key is derived from
+    what all ranks of one job share (launcher run id, rendezvous port, world size), which still keeps
+    the ranks of two jobs on one host apart."""
+    s = os.environ.get("CRBM_JOB_SECRET")
+    if not s:
+        s = "|".join([os.environ.get("TORCHELASTIC_RUN_ID", ""), str(port), str(world)])
+    return hashlib.sha256(b"crbm-control-plane:" + s.encode("utf-8")).digest()
 
 
 def _recv_exact(sock, n):
@@ -77,29 +213,55 @@ def _recv_exact(sock, n):
     return b"".join(chunks)
 
 
-def _recv_msg(sock):
+def _send_msg(sock, payload, key):
+    sock.sendall(struct.pack("<Q", len(payload)) + hmac.new(key, payload, hashlib.sha256).digest() + payload)
+
+
+def _recv_msg(sock, key):
     (n,) = struct.unpack("<Q", _recv_exact(sock, 8))
-    return _recv_exact(sock, n)
+    if n > _MAX_MSG:
+        raise ConnectionError("control plane: oversized frame (%d bytes)" % n)
+    mac = _recv_exact(sock, 32)
+    payload = _recv_exact(sock, n)
+    if not hmac.compare_digest(mac, hmac.new(key, payload, hashlib.sha256).digest()):
+        raise ConnectionError("control plane: message authentication failed (a peer of another job?)")
+    return payload
+
+
+def _bind_address(addr):
+    """One-node jobs listen on loopback only; a real interface is used only when MASTER_ADDR names one."""
+    if not addr or addr in ("localhost", "127.0.0.1", "::1"):
+        return "127.0.0.1"
+    return addr
 
 
 class ControlPlane(object):
     """Star-shaped host channel of a one-node job: rank 0 listens, ranks 1..R-1
     connect once and stay connected.  Collectives are tiny and synchronous:
     `broadcast(obj)`, `gather(obj)`, `barrier()`, `allreduce_max(values)`,
-    `allreduce_sum(values)`.  World size 1 needs no sockets."""
+    `allreduce_sum(values)`.  World size 1 needs no sockets.
 
-    def __init__(self, rank=None, world=None, addr=None, port=None, timeout=120.0):
+    `timeout` bounds the rendezvous; `collective_timeout` (CRBM_CONTROL_TIMEOUT, default 1800 s)
+    bounds how long a rank waits inside a collective for its peers -- e.g. the other ranks of a job
+    whose rank 0 evaluates a test set between two collectives."""
+
+    def __init__(self, rank=None, world=None, addr=None, port=None, timeout=120.0, collective_timeout=None):
         if rank is None or world is None:
             rank, world = env_rank_world()
         self.rank, self.world = int(rank), int(world)
         self.peers = []          # rank 0: sockets of ranks 1..R-1, in rank order
         self.sock = None         # other ranks: socket to rank 0
+        if collective_timeout is None:
+            collective_timeout = float(os.environ.get("CRBM_CONTROL_TIMEOUT", "1800"))
+        self.collective_timeout = collective_timeout
         if self.world == 1:
             return
-        addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+        addr = _bind_address(addr or os.environ.get("MASTER_ADDR", "127.0.0.1"))
         base = int(port or int(os.environ.get("MASTER_PORT", "29500")) + _ID_PORT_OFFSET)
         ports = [base + 101 * i for i in range(_PORT_TRIES)]
-        hello = _MAGIC + struct.pack("<II", self.world, 0)
+        self.key = job_secret(self.world, base)
+        # hello = magic | world | rank | nonce, authenticated like every later message; rank 0 answers with
+        # an authenticated echo of the nonce, so neither side accepts a peer that lacks the job's key
         if self.rank == 0:
             srv = None
             for p in ports:
@@ -113,76 +275,96 @@ class ControlPlane(object):
                     srv = None
             if srv is None:
                 raise OSError("control plane: no free port among %s" % ports)
-            srv.listen(self.world)
-            srv.settimeout(timeout)
+            srv.listen(self.world + 8)
+            deadline = time.time() + timeout
             slots = {}
             try:
                 while len(slots) < self.world - 1:
-                    conn, _peer = srv.accept()
-                    conn.settimeout(timeout)
-                    conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                    head = _recv_exact(conn, len(hello))
-                    w, r = struct.unpack("<II", head[len(_MAGIC):])
-                    if head[:len(_MAGIC)] != _MAGIC or w != self.world or not (0 < r < self.world) or r in slots:
-                        conn.close()          # a stranger, or a rank of another job
+                    left = deadline - time.time()
+                    if left <= 0:
+                        raise TimeoutError("control plane: %d of %d ranks connected within %.0f s"
+                                           % (len(slots) + 1, self.world, timeout))
+                    srv.settimeout(left)
+                    try:
+                        conn, _peer = srv.accept()
+                    except socket.timeout:
                         continue
-                    conn.sendall(_MAGIC)
-                    slots[r] = conn
+                    try:
+                        conn.settimeout(_HANDSHAKE_TIMEOUT)
+                        conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                        hello = _recv_msg(conn, self.key)
+                        magic, w, r, nonce = hello[:8], *struct.unpack("<II", hello[8:16]), hello[16:]
+                        if magic != _MAGIC or w != self.world or not (0 < r < self.world) or r in slots or len(nonce) != 16:
+                            raise ConnectionError("not a rank of this job")
+                        _send_msg(conn, _MAGIC + nonce, self.key)
+                        conn.settimeout(self.collective_timeout)
+                        slots[r] = conn
+                    except (OSError, ConnectionError, ValueError, struct.error):
+                        conn.close()              # a stranger, a rank of another job, or a silent connection
             finally:
                 srv.close()
             self.peers = [slots[r] for r in range(1, self.world)]
         else:
             deadline = time.time() + timeout
-            mine = _MAGIC + struct.pack("<II", self.world, self.rank)
+            nonce = os.urandom(16)
+            mine = _MAGIC + struct.pack("<II", self.world, self.rank) + nonce
             while self.sock is None:
                 for p in ports:
+                    s = None
                     try:
-                        s = socket.create_connection((addr, p), timeout=5.0)
-                        s.settimeout(timeout)
+                        s = socket.create_connection((addr, p), timeout=_HANDSHAKE_TIMEOUT)
+                        s.settimeout(_HANDSHAKE_TIMEOUT)
                         s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                        s.sendall(mine)
-                        if _recv_exact(s, len(_MAGIC)) == _MAGIC:
+                        _send_msg(s, mine, self.key)
+                        if _recv_msg(s, self.key) == _MAGIC + nonce:
+                            s.settimeout(self.collective_timeout)
                             self.sock = s
                             break
                         s.close()
                     except (OSError, ConnectionError):
-                        pass
+                        if s is not None:
+                            s.close()
                 if self.sock is None:
                     if time.time() > deadline:
                         raise TimeoutError("control plane: rank 0 not reachable at %s ports %s" % (addr, ports))
                     time.sleep(0.05)
 
     # rank 0 gathers one object per rank, applies `combine` and sends the result to everyone
-    def _collect(self, obj, combine):
+    def _collect(self, obj, combine, what="collective"):
         if self.world == 1:
             return combine([obj])
-        if self.rank == 0:
-            items = [obj] + [pickle.loads(_recv_msg(p)) for p in self.peers]
-            out = combine(items)
-            blob = pickle.dumps(out, protocol=4)
-            for p in self.peers:
-                _send_msg(p, blob)
-            return out
-        _send_msg(self.sock, pickle.dumps(obj, protocol=4))
-        return pickle.loads(_recv_msg(self.sock))
+        try:
+            if self.rank == 0:
+                items = [obj] + [decode(_recv_msg(p, self.key)) for p in self.peers]
+                out = combine(items)
+                blob = encode(out)
+                for p in self.peers:
+                    _send_msg(p, blob, self.key)
+                return out
+            _send_msg(self.sock, encode(obj), self.key)
+            return decode(_recv_msg(self.sock, self.key))
+        except socket.timeout:
+            raise TimeoutError("control plane: %s on rank %d waited %.0f s for its peers -- every rank must make the "
+                               "same collective calls in the same order (saveState, fit and attach are collective); "
+                               "CRBM_CONTROL_TIMEOUT raises the limit" % (what, self.rank, self.collective_timeout))
 
     def broadcast(self, obj):
         """rank 0's `obj` on every rank."""
-        return self._collect(obj if self.rank == 0 else None, lambda items: items[0])
+        return self._collect(obj if self.rank == 0 else None, lambda items: items[0], "broadcast")
 
     def gather(self, obj):
         """list of every rank's `obj` (rank order) on every rank."""
-        return self._collect(obj, lambda items: items)
+        return self._collect(obj, lambda items: items, "gather")
 
     def barrier(self):
-        self._collect(None, lambda items: None)
+        self._collect(None, lambda items: None, "barrier")
 
     def allreduce_max(self, values):
-        return self._collect([float(v) for v in values], lambda items: [max(col) for col in zip(*items)])
+        return self._collect([float(v) for v in values], lambda items: [max(col) for col in zip(*items)], "allreduce_max")
 
     def allreduce_sum(self, values):
         return self._collect(np.asarray(values, dtype=np.float64),
-                             lambda items: np.sum(np.stack(items), axis=0))
+                             lambda items: np.sum(np.stack(items), axis=0), "allreduce_sum")
 
     def close(self):
         for p in self.peers:

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CRBM_AMD_ABI_VERSION 1
+#define CRBM_AMD_ABI_VERSION 2
 
 typedef enum crbm_status {
   CRBM_OK = 0,
@@ -128,8 +128,11 @@ int crbm_train_step_resident(crbm_handle* h, int32_t start, int32_t end);
 int crbm_train_epoch_resident(crbm_handle* h, int32_t batchsize);
 /* The same loop for a slot that holds only THIS rank's rows of every slice, in
  * slice order (rank r of R owns rows [n*r/R, n*(r+1)/R) of a slice of n rows):
- * every rank uploads 1/R of the `total_rows` data set instead of all of it. */
-int crbm_train_epoch_sharded(crbm_handle* h, int32_t batchsize, int32_t total_rows);
+ * every rank uploads 1/R of the `total_rows` data set instead of all of it.
+ * `L` is the sequence length of the GLOBAL data set: a rank whose share is empty
+ * has no resident rows to read it from, and every rank must normalise the
+ * all-reduced sums with the same counts. */
+int crbm_train_epoch_sharded(crbm_handle* h, int32_t batchsize, int32_t total_rows, int32_t L);
 /* The persistent chain alone (convRBM.py:397-408): k Gibbs steps on all
  * fantasy chains, parameters frozen.  Benchmark entry. */
 int crbm_gibbs_steps(crbm_handle* h, int32_t k);
@@ -212,6 +215,11 @@ int crbm_sums_count(const crbm_handle* h);
  * the caller reduces; apply consumes the reduced sums. */
 int crbm_train_local(crbm_handle* h, const float* D, int32_t n, int32_t L, float* sums_out);
 int crbm_train_apply(crbm_handle* h, const float* sums_in, int32_t L_data);
+/* Times `launches` back-to-back all-reduces of the packed sums buffer alone
+ * (HIP events on the library's stream; total in milliseconds): the collective's
+ * share of a data-parallel training step.  The buffer's contents
+ * are scratch at that point of a step; 0 ms without a communicator. */
+int crbm_time_allreduce(crbm_handle* h, int32_t launches, float* total_ms);
 
 /* ---- introspection used by bench/profiling ------------------------------- */
 typedef struct crbm_launch_info {

@@ -211,3 +211,86 @@ def test_shard_rows_cover_every_slice_once():
             want += list(range(start + lo, start + hi))
         assert parts[r].tolist() == want
     assert shard_rows(2, 8, 2, 3).size in (0, 1)              # a rank may own nothing of a short set
+
+
+def test_wire_format_round_trip_and_rejects_garbage():
+    """The control plane carries plain data in a tagged binary encoding of its own (no pickle):
+    everything the job sends round-trips, anything else is refused on either side."""
+    from crbm_amd.dist import encode, decode
+    state = {"motifs": np.arange(24, dtype=np.float32).reshape(2, 1, 4, 3), "seed": 2**63 + 5, "pending": None,
+             "bits": (np.packbits(np.ones(17, np.uint8)), None), "rng": (7, 1, 2), "list": [1.5, -2, True, "x", b"\x00\xff"],
+             "empty": np.zeros((0, 3), np.int64)}
+    back = decode(encode(state))
+    assert set(back) == set(state) and back["seed"] == state["seed"] and back["rng"] == (7, 1, 2)
+    np.testing.assert_array_equal(back["motifs"], state["motifs"])
+    assert back["motifs"].dtype == np.float32 and back["motifs"].flags.writeable
+    np.testing.assert_array_equal(back["bits"][0], state["bits"][0])
+    assert back["bits"][1] is None and back["list"] == state["list"] and back["empty"].shape == (0, 3)
+    with pytest.raises(TypeError):
+        encode({"f": lambda: 0})
+    with pytest.raises(TypeError):
+        encode(np.array(["a"], dtype=object))
+    import pickle
+    for junk in (pickle.dumps({"x": 1}), b"", b"a\x02\x01<f", encode([1, 2]) + b"N", b"l" + b"\xff" * 8):
+        with pytest.raises((ValueError, Exception)):
+            decode(junk)
+
+
+def _cp_pair_rank(rank, port, q):
+    from crbm_amd.dist import ControlPlane
+    cp = ControlPlane(rank, 2, addr="127.0.0.1", port=port, timeout=60.0)
+    q.put((rank, cp.gather(rank + 1)))
+    cp.close()
+
+
+def test_control_plane_survives_strangers(monkeypatch):
+    """a silent connection, a peer with the wrong key and a peer that claims a rank slot
+    must neither take a slot nor stall the rendezvous: the real rank 1 still gets in."""
+    import hashlib
+    import hmac as _hmac
+    import struct
+    import threading
+    import time
+    from crbm_amd import dist
+    monkeypatch.setenv("CRBM_JOB_SECRET", "s3cret-of-this-test")
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p0 = ctx.Process(target=_cp_pair_rank, args=(0, port, q))
+    p0.start()
+
+    def connect():
+        deadline = time.time() + 30
+        while True:
+            try:
+                return socket.create_connection(("127.0.0.1", port), timeout=2.0)
+            except OSError:
+                if time.time() > deadline:
+                    raise
+                time.sleep(0.05)
+
+    silent = connect()                                   # never says a word
+    wrong = connect()                                    # speaks the protocol, but with another job's key
+    hello = dist._MAGIC + struct.pack("<II", 2, 1) + b"n" * 16
+    badkey = hashlib.sha256(b"other job").digest()
+    wrong.sendall(struct.pack("<Q", len(hello)) + _hmac.new(badkey, hello, hashlib.sha256).digest() + hello)
+    t0 = time.time()
+    p1 = ctx.Process(target=_cp_pair_rank, args=(1, port, q))
+    p1.start()
+    got = dict(q.get(timeout=60) for _ in range(2))
+    took = time.time() - t0
+    for p in (p0, p1):
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    assert got[0] == got[1] == [1, 2]
+    assert took < 40, took                               # bounded by the handshake timeouts, not by 120 s each
+    assert wrong.recv(64) == b""                         # the impostor was dropped without an answer
+    silent.close(); wrong.close()
+
+
+def test_empty_shards_are_known_to_every_rank():
+    from crbm_amd.dist import empty_shards, shard_rows
+    assert empty_shards(1, 20, 2) == [0]                 # the lone row goes to rank 1: rank 0 owns nothing
+    assert empty_shards(40, 20, 2) == []
+    for total, bs, world in ((3, 8, 8), (17, 4, 3), (2, 2, 4)):
+        assert empty_shards(total, bs, world) == [r for r in range(world) if shard_rows(total, bs, r, world).size == 0]

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from oracle.crbm_oracle import (OracleCRBM, synthetic_onehot, hidden_uniforms, visible_uniforms,
-                                KIND_API_H, KIND_API_V, KIND_CHAIN_H, KIND_CHAIN_V)
+                                KIND_API_H, KIND_API_V, KIND_CHAIN_H, KIND_CHAIN_V, KIND_EVAL_H)
 
 pytestmark = pytest.mark.gpu
 
@@ -97,6 +97,55 @@ def assert_chain_steps(model, o, steps):
     return ties
 
 
+def install_oracle_state(model, o):
+    """The HIP model takes over the oracle's complete state: parameters, velocities, chains, step counter."""
+    ds = o.doublestranded
+    model.motifs.set_value(o.W.astype(np.float32))
+    model.bias.set_value(o.b.astype(np.float32))
+    model.c.set_value(o.c.astype(np.float32))
+    model.set_velocities(o.vW.astype(np.float32), o.vb.astype(np.float32), o.vc.astype(np.float32))
+    model.set_fantasy(o.fantasy_h.astype(np.float32), o.fantasy_h_prime.astype(np.float32) if ds else None)
+    model.set_rng(gibbs_step=o.gibbs_step)
+
+
+def assert_train_steps(model, o, batches, twin, step=None, rtol=RTOL, atol=2e-6):
+    """PCD-k updates one at a time.  After every update the chains and the last visible sample must be
+    IDENTICAL to the oracle's and the parameters agree at `rtol`; where a sample differs, the step's chain
+    is replayed on a fresh pair (`twin()` -> (model, oracle)) from the state before the step, one Gibbs
+    step at a time from identical states (assert_chain_steps: every differing sample must sit on a
+    p == u tie), and the HIP model then continues from the oracle's state.  `step(model, D)` runs one
+    update (default: the host-array entry point).  Returns the number of updates that met a tie."""
+    ds = o.doublestranded
+    tied = 0
+    for D in batches:
+        before = {k: np.copy(getattr(o, k)) for k in ("W", "b", "c", "vW", "vb", "vc", "fantasy_h")}
+        before["fantasy_h_prime"] = np.copy(o.fantasy_h_prime) if ds else None
+        g0 = o.gibbs_step
+        (step or (lambda m, d: m._trainingFct(d)))(model, D)
+        o.train_step(D)
+        h, hp = model.get_fantasy()
+        same = np.array_equal(h, o.fantasy_h) and (not ds or np.array_equal(hp, o.fantasy_h_prime)) \
+            and np.array_equal(model.get_fantasy_visible(), o.last_v_model)
+        if same:
+            np.testing.assert_allclose(model.motifs.get_value(), o.W, rtol=rtol, atol=atol)
+            np.testing.assert_allclose(model.bias.get_value(), o.b, rtol=rtol, atol=atol)
+            np.testing.assert_allclose(model.c.get_value(), o.c, rtol=rtol, atol=atol)
+            vW, vb, vc = model.get_velocities()
+            np.testing.assert_allclose(vW, o.vW, rtol=rtol, atol=atol)
+            np.testing.assert_allclose(vb, o.vb, rtol=rtol, atol=atol)
+            np.testing.assert_allclose(vc, o.vc, rtol=rtol, atol=atol)
+        else:
+            m2, o2 = twin()
+            for k, v in before.items():
+                setattr(o2, k, v)
+            o2.gibbs_step = g0
+            install_oracle_state(m2, o2)
+            assert assert_chain_steps(m2, o2, o.cd_k) >= 1, "chains differ although no sample sits on a tie"
+            tied += 1
+            install_oracle_state(model, o)
+    return tied
+
+
 # ---- reference tests/testcrbm.py:148-200 ------------------------------------
 @pytest.mark.parametrize("flip", [False, True])
 def test_bottomup(flip):
@@ -159,7 +208,8 @@ def test_topdown(kind, ds):
     ref = o._topDownSample(ctrl_p, u)
     bad = (sample != ref).any(axis=2)[:, 0]
     gap = np.min(np.abs(np.cumsum(ctrl_p[:, 0], axis=1) - u[:, None, :]), axis=1)
-    assert np.all(gap[bad] < 1e-6) and bad.mean() < 1e-3
+    assert np.all(gap[bad] < TIE), "visible sample differs away from a tie"
+    assert bad.sum() <= 1
 
 
 @pytest.mark.parametrize("ds", [False, True])
@@ -197,7 +247,13 @@ def test_hitprobs_free_energy_pfms(ds, tmp_path):
     mfe, nmh = model._evaluateData(data)
     omfe, onmh = o.evaluateData(data, eval_step=0)
     np.testing.assert_allclose(mfe, omfe, rtol=RTOL)
-    np.testing.assert_allclose(nmh, onmh, rtol=1e-3, atol=1e-6)
+    # nmh is the mean of a sample drawn with shared uniforms (convRBM.py:469-472): the count of ones may
+    # differ from the oracle's only by units on a p == u tie
+    Pd = o._computeHgivenV(data)[0]
+    ud = hidden_uniforms(model.seed, 0, np.arange(100), 10, 186, 0, KIND_EVAL_H)
+    ones_ref, near = int((Pd > ud).sum()), int((np.abs(Pd - ud) < TIE).sum())
+    assert abs(onmh * Pd.size - ones_ref) < 0.5
+    assert abs(int(round(float(nmh) * Pd.size)) - ones_ref) <= near
     # save / load round trip (tests/testcrbm.py:58-98)
     fn = str(tmp_path / "model.pkl")
     model.saveModel(fn)
@@ -254,11 +310,8 @@ def test_gibbs_topdown_variants_match_oracle(variant, ds, monkeypatch):
     hp0 = rng.binomial(1, 0.1, size=(B, K, 1, Lf)).astype(np.float32) if ds else None
     model.set_fantasy(h0, hp0)
     o.fantasy_h, o.fantasy_h_prime = h0.astype(np.float64), (hp0.astype(np.float64) if ds else None)
-    model.gibbsSteps(3)
-    o.gibbs_steps(3)
+    assert_chain_steps(model, o, 3)                   # sample for sample, ties only
     h, hp = model.get_fantasy()
-    assert (h != o.fantasy_h).mean() < 1e-4
-    assert (model.get_fantasy_visible() != o.last_v_model).mean() < 1e-4
     info = CrbmLaunchInfo()
     model._lib.crbm_get_launch_info(model._h(), ctypes.byref(info))
     assert info.gibbs_sparse == (1 if variant == "sparse" else 0)
@@ -406,6 +459,48 @@ def test_fit_matches_oracle_one_epoch():
     np.testing.assert_allclose(model.bias.get_value(), o.b, rtol=RTOL, atol=5e-6)
 
 
+def test_config1_fit_at_full_size(capsys):
+    """BASELINE config #1 at its stated size: `CRBM(10, 15).fit` on 1000 synthetic 200-bp sequences with the
+    reference's defaults (batchsize 20, cd_k 5, doublestranded, chains of hidden length 200; convRBM.py:68-71,
+    :168, :570-634) -- 50 PCD-5 updates through the resident-data epoch loop -- against the oracle's 50
+    `train_step`s: identical chains and 1e-4 on W, b, c, and the epoch's status line against the oracle's
+    evaluation.  Should a sample have landed on a p == u tie, the epoch is replayed update by update
+    (assert_train_steps: ties only)."""
+    import re
+    from crbm_amd import CRBM
+    data = synthetic_onehot(1000, 200, seed=1234)
+    W = np.random.default_rng(42).standard_normal((10, 1, 4, 15)).astype(np.float32)
+
+    def pair():
+        m = CRBM(num_motifs=10, motif_length=15, epochs=1, seed=2026)
+        m.motifs.set_value(W)
+        return m, OracleCRBM(10, 15, epochs=1, seed=2026, W=W)
+    m, o = pair()
+    assert (m.batchsize, m.cd_k, m.doublestranded, m.fantasy_hidden_len) == (20, 5, True, 200)
+    m.fit(data)
+    out = capsys.readouterr().out
+    bounds = o._iterateBatchIndices(1000, 20)
+    assert len(bounds) == 50
+    for lo, hi in bounds:
+        o.train_step(data[lo:hi])
+    h, hp = m.get_fantasy()
+    if np.array_equal(h, o.fantasy_h) and np.array_equal(hp, o.fantasy_h_prime):
+        np.testing.assert_allclose(m.motifs.get_value(), o.W, rtol=RTOL, atol=5e-6)
+        np.testing.assert_allclose(m.bias.get_value(), o.b, rtol=RTOL, atol=5e-6)
+        np.testing.assert_allclose(m.c.get_value(), o.c, rtol=RTOL, atol=5e-6)
+        # the status line (convRBM.py:616-630): batch means of evaluateData over the test set (= training set)
+        ev = [o.evaluateData(data[lo:hi], eval_step=i) for i, (lo, hi) in enumerate(bounds)]
+        line = [l for l in out.splitlines() if l.startswith("Epoch 0:")][0]
+        got = dict(re.findall(r"(\w+)=\s*(-?[0-9.]+)", line))
+        assert abs(float(got["FE"]) - np.mean([e[0] for e in ev])) < 2e-3
+        assert abs(float(got["NumH"]) - np.mean([e[1] for e in ev])) < 2e-4
+        twn, ic, medic = o.evaluateParams()
+        assert abs(float(got["WNorm"]) - twn) < 1.1e-2 and abs(float(got["IC"]) - ic) < 2e-3 and abs(float(got["medIC"]) - medic) < 2e-3
+    else:
+        m2, o2 = pair()
+        assert assert_train_steps(m2, o2, [data[lo:hi] for lo, hi in bounds], pair, atol=5e-6) >= 1
+
+
 # ---- golden fixtures ---------------------------------------------------------------
 def test_golden_fixtures(golden_dir):
     from crbm_amd import CRBM
@@ -425,11 +520,26 @@ def test_golden_fixtures(golden_dir):
                                    g[tag + "_pv"], rtol=RTOL, atol=1e-7)
         for step in range(int(g[tag + "_steps"])):
             m._trainingFct(D)
-        np.testing.assert_allclose(m.motifs.get_value(), g[tag + "_W_after"], rtol=RTOL, atol=5e-6)
-        np.testing.assert_allclose(m.bias.get_value(), g[tag + "_b_after"], rtol=RTOL, atol=5e-6)
-        np.testing.assert_allclose(m.c.get_value(), g[tag + "_c_after"], rtol=RTOL, atol=5e-6)
         h, _ = m.get_fantasy()
-        assert (h != g[tag + "_fh_after"]).mean() < 1e-3
+        if np.array_equal(h, g[tag + "_fh_after"]):
+            np.testing.assert_allclose(m.motifs.get_value(), g[tag + "_W_after"], rtol=RTOL, atol=5e-6)
+            np.testing.assert_allclose(m.bias.get_value(), g[tag + "_b_after"], rtol=RTOL, atol=5e-6)
+            np.testing.assert_allclose(m.c.get_value(), g[tag + "_c_after"], rtol=RTOL, atol=5e-6)
+            continue
+        # the chain left the fixture's: legitimate only through a sample on a p == u tie -- replay the
+        # fixture's training steps one by one beside the oracle that wrote it (tests/golden/make_golden.py)
+        def pair():
+            mm = CRBM(K, M, doublestranded=ds, batchsize=int(g[tag + "_B"]), cd_k=int(g[tag + "_cdk"]),
+                      fantasy_hidden_len=int(g[tag + "_Lf"]), seed=int(g[tag + "_seed"]), rho=float(g[tag + "_rho"]))
+            oo = OracleCRBM(K, M, doublestranded=ds, batchsize=int(g[tag + "_B"]), cd_k=int(g[tag + "_cdk"]),
+                            fantasy_hidden_len=int(g[tag + "_Lf"]), seed=int(g[tag + "_seed"]), rho=float(g[tag + "_rho"]),
+                            W=g[tag + "_W"])
+            oo.b, oo.c = g[tag + "_b"].astype(np.float64), g[tag + "_c"].astype(np.float64)
+            mm.motifs.set_value(g[tag + "_W"]); mm.bias.set_value(g[tag + "_b"]); mm.c.set_value(g[tag + "_c"])
+            return mm, oo
+        m3, o3 = pair()
+        assert assert_train_steps(m3, o3, [D] * int(g[tag + "_steps"]), pair, atol=5e-6) >= 1
+        np.testing.assert_allclose(o3.W, g[tag + "_W_after"], rtol=1e-6, atol=1e-6)      # the oracle still writes this fixture
 
 
 # ---- full BASELINE sizes: size-independent properties (the oracle is too slow here) ----------
@@ -725,17 +835,10 @@ def test_edge_shapes(K, M, ds, L, n):
     np.testing.assert_allclose(model._bottomUpActivity(D, True), o._bottomUpActivity(D, True), rtol=1e-5, atol=2e-5)
     np.testing.assert_allclose(model.motifHitProbs(D), o.motifHitProbs(D), rtol=RTOL, atol=1e-7)
     np.testing.assert_allclose(model.freeEnergy(D), o.freeEnergy(D), rtol=RTOL, atol=1e-6)
-    model.gibbsSteps(2)
-    o.gibbs_steps(2)
-    h, hp = model.get_fantasy()
-    assert (h != o.fantasy_h).mean() < 1e-3
-    if ds:
-        assert (hp != o.fantasy_h_prime).mean() < 1e-3
-    model._trainingFct(D)
-    o.train_step(D)
-    np.testing.assert_allclose(model.motifs.get_value(), o.W, rtol=RTOL, atol=5e-6)
-    np.testing.assert_allclose(model.bias.get_value(), o.b, rtol=RTOL, atol=5e-6)
-    np.testing.assert_allclose(model.c.get_value(), o.c, rtol=RTOL, atol=5e-6)
+    assert_chain_steps(model, o, 2)                    # sample for sample, ties only
+    model.set_fantasy(o.fantasy_h.astype(np.float32), o.fantasy_h_prime.astype(np.float32) if ds else None)
+    twin = lambda: make_pair(K, M, ds=ds, batchsize=4, Lf=Lf, cd_k=2, bshift=3.0, wscale=0.7)
+    assert_train_steps(model, o, [D], twin, atol=5e-6)
 
 
 # ---- pooling > 1 (convRBM.py:245-267, :586-599, :664-665) ---------------------------------

@@ -20,7 +20,7 @@ def test_abi_exports_every_declared_symbol():
     declared -= {"crbm_status", "crbm_config", "crbm_handle", "crbm_launch_info"}
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     lib = _lib.load()                      # binds every symbol or raises
-    assert lib.crbm_abi_version() == 1
+    assert lib.crbm_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define CRBM_AMD_ABI_VERSION (\d+)", header).group(1))
     assert lib.crbm_device_count() >= 0
 
 
