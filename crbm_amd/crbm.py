@@ -89,11 +89,12 @@ class CRBM(object):
         device = extra.pop("device", None)
         if extra:
             raise TypeError("unexpected keyword arguments: %s" % sorted(extra))
-        # limits of the HIP kernels (README "Limits"): refuse at construction, not in the middle of fit()
-        if num_motifs > 64:
-            raise Exception("num_motifs > 64 is not supported by the HIP kernels (K-bit hidden masks of at most 64 bits).")
-        if motif_length > 32:
-            raise Exception("motif_length > 32 is not supported by the HIP kernels (64-bit letter windows).")
+        # limits of the HIP kernels (README "Limits"): refuse at construction, not in the middle of fit().
+        # Beyond them the bound is the LDS (tables + one chain must fit 160 KB): crbm_create reports it.
+        if num_motifs > 256:
+            raise Exception("num_motifs > 256 is not supported by the HIP kernels.")
+        if motif_length > 64:
+            raise Exception("motif_length > 64 is not supported by the HIP kernels (letter windows of two 64-bit words).")
 
         # convRBM.py:111-123
         self.num_motifs = num_motifs

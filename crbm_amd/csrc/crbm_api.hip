@@ -568,9 +568,9 @@ int validate_config(const crbm_config* cfg) {
   crbm_handle* h = nullptr;   // fail() routes to the create-error slot
   if (!cfg) return fail(h, CRBM_ERR_INVALID, "null argument");
   ARGCHK(cfg->num_motifs >= 1, "Number of motifs must be positive.");
-  ARGCHK(cfg->num_motifs <= 64, "num_motifs > 64 is not supported by the HIP kernels");
+  ARGCHK(cfg->num_motifs <= MAX_MOTIFS, "num_motifs > 256 is not supported by the HIP kernels");
   ARGCHK(cfg->motif_length >= 1, "Motif length must be positive.");
-  ARGCHK(cfg->motif_length <= 32, "motif_length > 32 is not supported by the HIP kernels");
+  ARGCHK(cfg->motif_length <= MAX_MOTIF_LENGTH, "motif_length > 64 is not supported by the HIP kernels (two-word letter windows)");
   ARGCHK(cfg->input_dims == 4, "the HIP kernels require input_dims == 4 (DNA one-hot)");
   ARGCHK(cfg->pooling >= 1 && cfg->pooling <= 64, "pooling must be between 1 and 64");
   ARGCHK(cfg->fantasy_hidden_len % cfg->pooling == 0, "pooling must divide the hidden length of the fantasy chains");

@@ -307,24 +307,53 @@ __device__ __forceinline__ void sample_hidden(const float (&z)[C::KP], uint32_t 
   }
 }
 
-// M letters (2 bits each) starting at position s of a packed row.
+// M letters (2 bits each) starting at position s of a packed row: one 64-bit word for M <= 32,
+// a second one (letters 32..) for M <= 64 (MAX_MOTIF_LENGTH).
 template <int M>
-__device__ __forceinline__ uint64_t letter_window(const uint32_t* w, int s) {
+struct LetterWin {
+  uint64_t lo, hi;   // hi is never touched for M <= 32
+};
+
+template <int M>
+__device__ __forceinline__ LetterWin<M> letter_window(const uint32_t* w, int s) {
+  static_assert(M <= MAX_MOTIF_LENGTH, "letter windows hold at most 64 letters");
   const int i = s >> 4;
   const int sh = (s & 15) * 2;
+  LetterWin<M> out;
+  out.hi = 0ull;
   const uint64_t lo = (uint64_t)w[i] | ((uint64_t)w[i + 1] << 32);
-  uint64_t win = lo >> sh;
-  if (2 * M + 30 > 64) {
-    if (sh > 0) win |= (uint64_t)w[i + 2] << (64 - sh);
+  if constexpr (M <= 32) {
+    uint64_t win = lo >> sh;
+    if (2 * M + 30 > 64) {
+      if (sh > 0) win |= (uint64_t)w[i + 2] << (64 - sh);
+    }
+    if (M < 32) win &= (1ull << (2 * M)) - 1ull;
+    out.lo = win;
+  } else {
+    // bits [sh, sh + 2M) of the five words from w[i] on (the row's two pad words cover the last window: crbm_layout.h)
+    const uint64_t mid = (uint64_t)w[i + 2] | ((uint64_t)w[i + 3] << 32);
+    const uint64_t top = (uint64_t)w[i + 4];
+    out.lo = sh > 0 ? (lo >> sh) | (mid << (64 - sh)) : lo;
+    out.hi = sh > 0 ? (mid >> sh) | (top << (64 - sh)) : mid;
+    if (M < 64) out.hi &= (1ull << (2 * (M - 32))) - 1ull;
   }
-  if (M < 32) win &= (1ull << (2 * M)) - 1ull;
-  return win;
+  return out;
+}
+
+// bits [off, off + 8) of a window (off < 2 M; a group's letter tuple is at most 8 bits wide)
+template <int M>
+__device__ __forceinline__ uint32_t window_bits(const LetterWin<M>& win, int off) {
+  if constexpr (M <= 32) return (uint32_t)(win.lo >> off);
+  else {
+    if (off >= 64) return (uint32_t)(win.hi >> (off - 64));
+    return (uint32_t)(off > 0 ? (win.lo >> off) | (win.hi << (64 - off)) : win.lo);
+  }
 }
 
 // z[k] (+)= sum over letter groups of T[g][tuple][k]  (z = -log2(e) * activation).  The sums are kept
 // as pairs of floats: one v_pk_add_f32 per two motifs (the compiler leaves scalar adds otherwise).
 template <class C, bool ACCUMULATE = false>
-__device__ __forceinline__ void conv_gather(const float* T, uint64_t win, float (&x)[C::KP]) {
+__device__ __forceinline__ void conv_gather(const float* T, const LetterWin<C::M>& win, float (&x)[C::KP]) {
   floatx2 acc[2 * C::NQ];
   if (ACCUMULATE) {
 #pragma unroll
@@ -332,7 +361,7 @@ __device__ __forceinline__ void conv_gather(const float* T, uint64_t win, float 
   }
   auto group = [&](int g, auto FIRST) {
     constexpr bool first = decltype(FIRST)::value != 0;   // the first group of a fresh sum assigns (saves KP adds of 0)
-    const uint32_t r = (uint32_t)(win >> (2 * C::G * g)) & (uint32_t)(C::ROWS - 1);
+    const uint32_t r = window_bits<C::M>(win, 2 * C::G * g) & (uint32_t)(C::ROWS - 1);
     const float4* row = reinterpret_cast<const float4*>(T + (size_t)g * C::ROWS * C::KP) + (size_t)r * C::NQ;
 #pragma unroll
     for (int q = 0; q < C::NQ; ++q) {
@@ -581,7 +610,7 @@ __device__ void hgv_body(const HgvArgs& a) {
       const int nn = n0 + (int)nl;
       const uint32_t* lrow = a.letters + (size_t)nn * a.LW;
       auto zfun = [&](int pos, float (&z)[KP]) {
-        const uint64_t w = letter_window<M>(lrow, pos);
+        const LetterWin<M> w = letter_window<M>(lrow, pos);
         conv_gather<C>(T0, w, z);
         if (a.mode == 2) conv_gather<C, true>(T1, w, z);
       };
@@ -689,15 +718,17 @@ __device__ __forceinline__ uint32_t letter_plane16(uint32_t word, uint32_t a) {
   return (x | (x >> 8)) & 0xFFFFu;
 }
 
-// The letter windows of a unit (2 groups x 4 letters x 64 bits) are built by 32 lanes: lane t owns
-// letter (t & 3), letter word (t >> 2) & 3 (16 positions) of group slot (t >> 4) and stores its 16
-// plane bits straight into the window (win as 16-bit pieces: piece index slot*16 + letter*4 + word).
+// The letter windows of a unit (2 groups x 4 letters x NPW 16-bit pieces: 64 bits for M <= 32, 128
+// beyond) are built by 8 NPW lanes: lane t owns letter (t & 3), letter word (t >> 2) % NPW (16
+// positions) of group slot t / (4 NPW) and stores its 16 plane bits straight into the window
+// (win as 16-bit pieces: piece index (slot*4 + letter)*NPW + word).
 // Returns the number of its positions that count for the letter statistics: a group owns its 32
-// positions (words 0, 1), the last group of a chain also the tail up to L (words 2, 3).
+// positions (words 0, 1), the last group of a chain also the tail up to L (words 2 ..).
+template <int NPW>
 __device__ __forceinline__ float stats_window_piece(unsigned short* win16, int t, uint32_t word, bool group_valid, int gi, int GPC, int L) {
-  const int a = t & 3, w = (t >> 2) & 3, slot = t >> 4;
+  const int a = t & 3, w = (t >> 2) % NPW, slot = t / (4 * NPW);
   const uint32_t bits = group_valid ? letter_plane16(word, (uint32_t)a) : 0u;
-  win16[slot * 16 + a * 4 + w] = (unsigned short)bits;
+  win16[(slot * 4 + a) * NPW + w] = (unsigned short)bits;
   const int p0 = 32 * gi + 16 * w;                              // first position of this piece
   const int limit = (w < 2 || gi == GPC - 1) ? L : 0;           // positions >= limit do not count
   const int nbits = limit - p0 < 0 ? 0 : (limit - p0 > 16 ? 16 : limit - p0);
@@ -706,12 +737,12 @@ __device__ __forceinline__ float stats_window_piece(unsigned short* win16, int t
 
 // z[] = the gather of motif quads [q0, q0 + NQW) (clamped to the model's NQ); z = -log2(e) * activation
 template <class C, int NQW>
-__device__ __forceinline__ void conv_gather_quads(const float* T, uint64_t win, int q0, float (&z)[4 * NQW]) {
+__device__ __forceinline__ void conv_gather_quads(const float* T, const LetterWin<C::M>& win, int q0, float (&z)[4 * NQW]) {
 #pragma unroll
   for (int i = 0; i < 4 * NQW; ++i) z[i] = 0.f;   // quads beyond the model's NQ
   auto group = [&](int g, auto FIRST) {
     constexpr bool first = decltype(FIRST)::value != 0;   // the first group assigns
-    const uint32_t r = (uint32_t)(win >> (2 * C::G * g)) & (uint32_t)(C::ROWS - 1);
+    const uint32_t r = window_bits<C::M>(win, 2 * C::G * g) & (uint32_t)(C::ROWS - 1);
     const float4* row = reinterpret_cast<const float4*>(T + (size_t)g * C::ROWS * C::KP) + (size_t)r * C::NQ + q0;
 #pragma unroll
     for (int q = 0; q < NQW; ++q)
@@ -736,9 +767,9 @@ __device__ __forceinline__ void conv_gather_quads(const float* T, uint64_t win, 
 
 // One 32-position group (slot 0 or 1 of the wave's unit): all accumulator tiles of the wave.
 //   Pt  : the wave's column image (row kind*KW + i, stride STATS_RS, position slot*32 + t)
-//   win : the group's four 64-bit letter windows
+//   win : the group's four letter windows (NPW/2 words each)
 template <class C, int KINDS, int NTW, bool BYTE_LUT>
-__device__ __forceinline__ void stats_mfma_group(const float* Pt, const uint2* win, const uint32_t* lut, int nt0, int slot,
+__device__ __forceinline__ void stats_mfma_group(const float* Pt, const uint32_t* win, const uint32_t* lut, int nt0, int slot,
                                                  floatx4 (&acc)[4 * C::JT * KINDS * NTW]) {
   constexpr int KW = 16 * NTW < C::K ? 16 * NTW : C::K, ZROW = KINDS * KW;
   const int lane = threadIdx.x & 63, i16 = lane & 15, g = lane >> 4;
@@ -756,11 +787,22 @@ __device__ __forceinline__ void stats_mfma_group(const float* Pt, const uint2* w
     }
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
-    const uint2 w = win[a];
-    const unsigned long long bits = (unsigned long long)w.x | ((unsigned long long)w.y << 32);
+    unsigned long long bits = 0ull;
+    if constexpr (C::NPW == 4) {
+      const uint2 w = reinterpret_cast<const uint2*>(win)[a];
+      bits = (unsigned long long)w.x | ((unsigned long long)w.y << 32);
+    }
 #pragma unroll
     for (int jt = 0; jt < C::JT; ++jt) {
-      const uint32_t byte = (uint32_t)(bits >> (8 * g + i16 + 16 * jt));
+      uint32_t byte;
+      if constexpr (C::NPW == 4) byte = (uint32_t)(bits >> (8 * g + i16 + 16 * jt));
+      else {
+        // 128-bit window: the two words around bit 8 g + i16 + 16 jt (<= 87: word index <= 2), funnel-shifted
+        const int sa = 8 * g + i16 + 16 * jt;
+        const uint32_t* w32 = win + a * (C::NPW / 2) + (sa >> 5);
+        const unsigned long long two = (unsigned long long)w32[0] | ((unsigned long long)w32[1] << 32);
+        byte = (uint32_t)(two >> (sa & 31));
+      }
       HalfFrag af;
       if constexpr (BYTE_LUT) {
         const uint4 f = reinterpret_cast<const uint4*>(lut)[byte & 255u];
@@ -878,7 +920,8 @@ __device__ void stats_mfma_body(const StatsMfmaArgs& a, int bid = -1) {   // bid
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   uint32_t* lut = reinterpret_cast<uint32_t*>(smem);
   float* slice = smem + sg.off_slices + (size_t)wave * sg.slice;
-  uint2* win = reinterpret_cast<uint2*>(slice + sg.off_win);
+  constexpr int NPW = C::NPW;
+  uint32_t* win = reinterpret_cast<uint32_t*>(slice + sg.off_win);
   uint32_t* gw = reinterpret_cast<uint32_t*>(slice + sg.off_gw);
   float* Pt = slice + sg.off_pt;
   float* Tf = smem + a.off_tab;
@@ -904,15 +947,15 @@ __device__ void stats_mfma_body(const StatsMfmaArgs& a, int bid = -1) {   // bid
   if (bid < 0) bid = (int)blockIdx.x;
   const int nblk = a.nblocks > 0 ? a.nblocks : (int)gridDim.x;
   const int ustride = nblk * waves_per_role;
-  // letter words of a unit: lane t < 32 fetches word (t >> 2) & 3 of group slot (t >> 4) (four lanes,
+  // letter words of a unit: lane t < 8 NPW fetches word (t >> 2) % NPW of group slot t / (4 NPW) (four lanes,
   // one per letter, fetch the same word: one transaction) and later turns it into its window piece
   unsigned short* win16 = reinterpret_cast<unsigned short*>(win);
   auto fetch_word = [&](int u) -> uint32_t {
-    if (lane >= 32 || u >= nunits) return 0u;
-    const int G = 2 * u + (lane >> 4);
+    if (lane >= 8 * NPW || u >= nunits) return 0u;
+    const int G = 2 * u + lane / (4 * NPW);
     if (G >= ngroups) return 0u;
     const uint32_t chain = fastdiv((uint32_t)G, sg.divGPC);
-    const int w = 2 * (G - (int)chain * GPC) + ((lane >> 2) & 3);
+    const int w = 2 * (G - (int)chain * GPC) + (lane >> 2) % NPW;
     return w < a.LW ? a.letters[(size_t)chain * a.LW + w] : 0u;
   };
   int u = bid * waves_per_role + wave_in_role;
@@ -920,12 +963,12 @@ __device__ void stats_mfma_body(const StatsMfmaArgs& a, int bid = -1) {   // bid
   uint32_t pre = fetch_word(u);
   for (; u < nunits; u += ustride) {
     const int G0 = 2 * u;
-    if (lane < 32 && !(a.debug & 4)) {
-      const int G = G0 + (lane >> 4);
+    if (lane < 8 * NPW && !(a.debug & 4)) {
+      const int G = G0 + lane / (4 * NPW);
       int gi = 0;
       if (G < ngroups) gi = G - (int)fastdiv((uint32_t)G, sg.divGPC) * GPC;
       if ((lane & 3) == 0) gw[lane >> 2] = pre;        // the packed words themselves feed the h|v gather below
-      const float cnt = stats_window_piece(win16, lane, pre, G < ngroups, gi, GPC, a.L);
+      const float cnt = stats_window_piece<NPW>(win16, lane, pre, G < ngroups, gi, GPC, a.L);
       if (role == 0) vcount += cnt;
     }
     __builtin_amdgcn_wave_barrier();
@@ -968,7 +1011,7 @@ __device__ void stats_mfma_body(const StatsMfmaArgs& a, int bid = -1) {   // bid
         }
       } else
       if (valid) {
-        const uint64_t wl = letter_window<M>(gw + 4 * slot, e);
+        const LetterWin<M> wl = letter_window<M>(gw + NPW * slot, e);
         float z[4 * R::NQW];
         conv_gather_quads<C, R::NQW>(Tf, wl, 4 * nt0, z);
 #pragma unroll
@@ -995,7 +1038,7 @@ __device__ void stats_mfma_body(const StatsMfmaArgs& a, int bid = -1) {   // bid
 #pragma unroll
     for (int slot = 0; slot < 2; ++slot)
       if (G0 + slot < ngroups && !(a.debug & 1))
-        stats_mfma_group<C, KINDS, NTW, BYTE_LUT>(Pt, win + 4 * slot, lut, nt0, slot, acc);
+        stats_mfma_group<C, KINDS, NTW, BYTE_LUT>(Pt, win + 2 * NPW * slot, lut, nt0, slot, acc);
     __builtin_amdgcn_wave_barrier();                   // the slice is rewritten by the next unit
   }
   if (a.debug & 8) return;
@@ -1043,10 +1086,11 @@ __device__ __forceinline__ uint32_t sample_letter(float y0, float y1, float y2, 
 // requested before those of the current one are added (the LDS latency of a set
 // bit overlaps the adds of the previous one); a lane that runs out of bits points
 // at the leading zero rows.
+// unit_base: hidden unit of bit 0 (models with more than 64 motifs walk a mask in several words).
 template <class C>
-__device__ __forceinline__ void topdown_bits(unsigned long long w, const char* tab, int q_base, float (&y)[4][4]) {
+__device__ __forceinline__ void topdown_bits(unsigned long long w, const char* tab, int q_base, float (&y)[4][4], int unit_base = 0) {
   constexpr int K = C::K;
-  const char* tab_q = tab + (size_t)q_base * K * 16;
+  const char* tab_q = tab + ((size_t)q_base * K + unit_base) * 16;
   const char* idle = tab - K * 16;                     // + (4-i)*K*16 = rows 3-i: all zero
   auto rows_of = [&](unsigned long long bits) { return bits ? tab_q + (__ffsll(bits) - 1) * 16 : idle; };
   auto fetch = [&](const char* p, float4 (&t)[4]) {
@@ -1119,14 +1163,14 @@ __device__ void gibbs_body(const GibbsArgs& a, int bid = -1) {   // bid: block o
   // statistics state (STATS): the wave's LDS slice, accumulator tiles, letter counts
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   float* sreg = nullptr;
-  uint2* swin = nullptr;
+  uint32_t* swin = nullptr;
   float* sPt = nullptr;
   floatx4 sacc[STATS ? SR::NACC : 1];
   float vcount = 0.f;
   if constexpr (STATS) {
     sreg = smem + a.stats_off;
     float* sslice = sreg + a.sg.off_slices + (size_t)wave * a.sg.slice;
-    swin = reinterpret_cast<uint2*>(sslice + a.sg.off_win);
+    swin = reinterpret_cast<uint32_t*>(sslice + a.sg.off_win);
     sPt = sslice + a.sg.off_pt;
 #pragma unroll
     for (int t = 0; t < SR::NACC; ++t) sacc[t] = floatx4{0.f, 0.f, 0.f, 0.f};
@@ -1225,16 +1269,16 @@ __device__ void gibbs_body(const GibbsArgs& a, int bid = -1) {   // bid: block o
     // one entry per thread: activation of that one unit (same table rows, same order of additions),
     // both Philox calls, the exact comparison of sample_hidden, one atomic OR into the mask word.
     auto resolve = [&](uint32_t e, int st, bool last) -> uint32_t {
-      const uint32_t it = e & 0xFFFFFu, k = (e >> 20) & 63u, strand = e >> 26;
+      const uint32_t it = e & 0xFFFFFu, k = (e >> 20) & 0x7FFu, strand = e >> 31;
       const uint32_t nl = fastdiv_tile(it, a.divHB);
       const int s = (int)(it - nl * (uint32_t)a.nhb);
       const uint32_t gn = a.rng.seq_offset + (uint32_t)(n0 + nl);
-      const uint64_t win = letter_window<M>(let + nl * (uint32_t)a.LWs, s);
+      const LetterWin<M> win = letter_window<M>(let + nl * (uint32_t)a.LWs, s);
       const float* T = (strand ? Tr : Tf) + k;
       float z = 0.f;
 #pragma unroll
       for (int g = 0; g < C::NG; ++g) {
-        const uint32_t r = (uint32_t)(win >> (2 * C::G * g)) & (uint32_t)(C::ROWS - 1);
+        const uint32_t r = window_bits<C::M>(win, 2 * C::G * g) & (uint32_t)(C::ROWS - 1);
         const float t = T[((size_t)g * C::ROWS + r) * KP];
         z = g == 0 ? t : z + t;
       }
@@ -1263,7 +1307,7 @@ __device__ void gibbs_body(const GibbsArgs& a, int bid = -1) {   // bid: block o
           while (m) {
             const uint32_t i = (uint32_t)__ffs(m) - 1u;
             m &= m - 1u;
-            const uint32_t e = it | ((10u * (uint32_t)g + i) << 20) | (strand << 26);
+            const uint32_t e = it | ((10u * (uint32_t)g + i) << 20) | (strand << 31);
             const uint32_t slot = atomicAdd(&fixq[0], 1u);
             if (slot < (uint32_t)FIXQ_CAP) fixq[2 + slot] = e;
             else ones += resolve(e, st, last);        // queue full (never at the sizes that run): resolve in place
@@ -1353,8 +1397,17 @@ __device__ void gibbs_body(const GibbsArgs& a, int bid = -1) {   // bid: block o
             } else {
 #pragma unroll 1
               for (int q = 0; q < NSLOT; ++q) {
-                const uint2 mm = *reinterpret_cast<const uint2*>(mrow + 2 * q);
-                topdown_bits<C>((unsigned long long)mm.x | ((unsigned long long)mm.y << 32), tab, q, y);
+                if constexpr (NW == 2) {
+                  const uint2 mm = *reinterpret_cast<const uint2*>(mrow + 2 * q);
+                  topdown_bits<C>((unsigned long long)mm.x | ((unsigned long long)mm.y << 32), tab, q, y);
+                } else {
+                  // more than 64 motifs: 64 units at a time (a mask is NW words, 4-byte aligned only)
+#pragma unroll
+                  for (int w2 = 0; 2 * w2 < NW; ++w2) {
+                    const uint32_t lo = mrow[NW * q + 2 * w2], hi = 2 * w2 + 1 < NW ? mrow[NW * q + 2 * w2 + 1] : 0u;
+                    topdown_bits<C>((unsigned long long)lo | ((unsigned long long)hi << 32), tab, q, y, 64 * w2);
+                  }
+                }
               }
             }
           }
@@ -1380,8 +1433,9 @@ __device__ void gibbs_body(const GibbsArgs& a, int bid = -1) {   // bid: block o
         const int GPC = a.sg.GPC, ngl = ns * GPC;
         for (int u = wave; 2 * u < ngl; u += nwaves) {
           const int G0 = 2 * u;
-          if (lane < 32) {                      // letter windows of the two groups (and the letter counts)
-            const int G = G0 + (lane >> 4), w = (lane >> 2) & 3;
+          constexpr int NPW = C::NPW;
+          if (lane < 8 * NPW) {                 // letter windows of the two groups (and the letter counts)
+            const int G = G0 + lane / (4 * NPW), w = (lane >> 2) % NPW;
             int gi = 0;
             uint32_t word = 0u;
             if (G < ngl) {
@@ -1389,7 +1443,7 @@ __device__ void gibbs_body(const GibbsArgs& a, int bid = -1) {   // bid: block o
               gi = G - (int)nl * GPC;
               if (2 * gi + w < a.LWs) word = let[(size_t)nl * a.LWs + 2 * gi + w];
             }
-            vcount += stats_window_piece(reinterpret_cast<unsigned short*>(swin), lane, word, G < ngl, gi, GPC, a.Lv);
+            vcount += stats_window_piece<NPW>(reinterpret_cast<unsigned short*>(swin), lane, word, G < ngl, gi, GPC, a.Lv);
           }
           __builtin_amdgcn_wave_barrier();
           {
@@ -1405,7 +1459,7 @@ __device__ void gibbs_body(const GibbsArgs& a, int bid = -1) {   // bid: block o
             float* col = sPt + lane;
             if (valid) {
               const uint32_t gn = a.rng.seq_offset + (uint32_t)(n0 + nl);
-              const uint64_t win = letter_window<M>(let + (size_t)nl * a.LWs, s);
+              const LetterWin<M> win = letter_window<M>(let + (size_t)nl * a.LWs, s);
 #pragma unroll
               for (int strand = 0; strand <= C::DS; ++strand) {
                 float x[KP], p[KP];
@@ -1434,7 +1488,7 @@ __device__ void gibbs_body(const GibbsArgs& a, int bid = -1) {   // bid: block o
 #pragma unroll
           for (int slot = 0; slot < 2; ++slot)
             if (G0 + slot < ngl)
-              stats_mfma_group<C, SR::KINDS, SR::NTW, false>(sPt, swin + 4 * slot, reinterpret_cast<const uint32_t*>(sreg), 0, slot, sacc);
+              stats_mfma_group<C, SR::KINDS, SR::NTW, false>(sPt, swin + 2 * C::NPW * slot, reinterpret_cast<const uint32_t*>(sreg), 0, slot, sacc);
           __builtin_amdgcn_wave_barrier();       // the slice is rewritten by the next unit
         }
       }
@@ -1448,7 +1502,7 @@ __device__ void gibbs_body(const GibbsArgs& a, int bid = -1) {   // bid: block o
         const int s = (int)(it - nl * (uint32_t)a.nhb);
         const uint32_t gn = a.rng.seq_offset + (uint32_t)(n0 + nl);
         const uint32_t* lrow = let + nl * (uint32_t)a.LWs;        // LDS offsets: 32-bit arithmetic
-        const uint64_t win = letter_window<M>(lrow, s);
+        const LetterWin<M> win = letter_window<M>(lrow, s);
 #pragma unroll
         for (int strand = 0; strand <= C::DS; ++strand) {
           float x[KP], p[KP];
@@ -1595,7 +1649,7 @@ __device__ void free_energy_body(const FeArgs& a) {
         }
     } else
     for (int s = lane; s < a.Lh; s += 64) {
-      const uint64_t win = letter_window<M>(row, s);
+      const LetterWin<M> win = letter_window<M>(row, s);
       float x[KP];
       conv_gather<C>(Tf, win, x);
 #pragma unroll
@@ -1673,7 +1727,7 @@ __device__ void hit_summary_body(const HitArgs& a) {
       const int s = s0 + lane + 64 * i;
       if (s < a.Lh) {
         auto zfun = [&](int pos, float (&zz)[KP]) {
-          const uint64_t w = letter_window<M>(row, pos);
+          const LetterWin<M> w = letter_window<M>(row, pos);
           conv_gather<C>(Tf, w, zz);
           if (BOTH) conv_gather<C, true>(Tr, w, zz);
         };

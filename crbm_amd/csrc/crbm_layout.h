@@ -35,8 +35,15 @@ struct RngView {
 };
 
 // Packed one-hot letters: 16 letters per 32-bit word, two zero pad words so a
-// 64+32-bit window read never leaves the row.
+// window read (three words from the word of its first letter for M <= 32, five for
+// M <= 64: crbm_kernels.h, letter_window) never leaves the row.
 inline int letter_words(int L) { return (L + 15) / 16 + 2; }
+// Largest motif length the letter windows hold (two 64-bit words); the number of motifs is
+// bounded by what the LDS holds (tables + one chain: choose_gibbs_geometry refuses beyond)
+// and by the statistics kernel (one role of 64 threads per 16 motifs, at most 1024 threads per block).
+constexpr int MAX_MOTIF_LENGTH = 64, MAX_MOTIFS = 256;
+// 16-bit pieces of a statistics letter window (32 positions of a group + M - 1 behind them)
+constexpr int stats_npw(int M) { return M <= 32 ? 4 : 8; }
 
 constexpr int cpow4(int g) { return 1 << (2 * g); }
 constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -93,6 +100,8 @@ struct Cfg {
   // 16 output columns are 16 motifs of one column kind (P, P' of the rc strand, P(1-P))
   static constexpr int NT = cdiv(K, 16);                  // motif tiles per column kind
   static constexpr int JT = cdiv(M, 16);                  // filter-column tiles per letter
+  static constexpr int NPW = stats_npw(M);                // 16-bit pieces per letter window (64 or 128 bits)
+  static_assert(M <= MAX_MOTIF_LENGTH && K <= MAX_MOTIFS, "model beyond the kernels' limits");
   // the model half of the statistics rides in the Gibbs kernel's last h|v pass when all motifs of
   // a position fit one wave's accumulator set of at most 8 tiles (32 registers; measured: with 16 tiles,
   // config #5, the fused kernel drops to one wave per SIMD and loses to the separate launch)
@@ -105,7 +114,7 @@ struct Cfg {
 
 // Host-side mirror of Cfg (runtime values, same arithmetic).
 struct ModelShape {
-  int K, M, DS, G, NT, JT, POOL;
+  int K, M, DS, G, NT, JT, POOL, NPW;
   int NQ, KP, NW, NG, ROWS, TAB, NCH, DENSE, TV, WS, NGRP;
   int OFF_TF, OFF_TR, OFF_TV, OFF_TVR, OFF_C, TABLES, OFF_WS, END2, SP_TABLES, TABLES_ALL;
   int HIT_NI, FUSE_STATS;
@@ -114,7 +123,7 @@ inline ModelShape model_shape(int K, int M, int DS, int G, int POOL = 1) {
   ModelShape s;
   s.K = K; s.M = M; s.DS = DS; s.G = G; s.POOL = POOL;
   s.NQ = cdiv(K, 4); s.KP = 4 * s.NQ; s.NW = cdiv(K, 32);
-  s.NT = cdiv(K, 16); s.JT = cdiv(M, 16);
+  s.NT = cdiv(K, 16); s.JT = cdiv(M, 16); s.NPW = stats_npw(M);
   s.FUSE_STATS = 4 * s.JT * (1 + DS) * s.NT <= 8 && POOL == 1;
   s.NG = cdiv(M, G); s.ROWS = cpow4(G); s.TAB = s.NG * s.ROWS * s.KP;
   s.NCH = cdiv(K, 5);
@@ -181,8 +190,9 @@ inline GibbsLayout gibbs_layout(const ModelShape& ms, int Lf, int S, bool sparse
 // NR = NT / NTW roles), so that its accumulator set stays <= 32 tiles (128 registers);
 // a unit is processed by one wave of every role.
 //   LDS of a block:  [lut][slice of wave 0][slice of wave 1] ...   (+ gather tables)
-//   slice:           win [2][4] 64-bit letter windows: bit t of win[g][a] = [letter(32*gi + t) == a]
-//                    gw  [2][4] packed letter words of the two groups (stats_mfma_body only)
+//   slice:           win [2][4] letter windows of NPW 16-bit pieces (64 bits for M <= 32, 128 beyond):
+//                        bit t of win[g][a] = [letter(32*gi + t) == a]
+//                    gw  [2][NPW] packed letter words of the two groups (stats_mfma_body only)
 //                    Pt  [kinds*KW + 1 rows][68] floats: row kind*KW + i = motif 16*nt0 + i of the
 //                        kind, 64 positions + 4 pad (row stride 17 x 16 B: conflict-free b128 reads);
 //                        the last row is all zero (motifs beyond K)
@@ -221,9 +231,9 @@ inline StatsMfmaLayout stats_mfma_layout(const ModelShape& ms, int want_sparsity
   s.KW = 16 * s.NTW < K ? 16 * s.NTW : K;
   s.rows = s.kinds * s.KW + 1;
   s.GPC = cdiv(Lh, 32);
-  s.off_win = 0;                        // 8 windows x 2 floats
-  s.off_gw = 16;                        // 8 words
-  s.off_pt = 24;
+  s.off_win = 0;                        // 8 windows x NPW/2 words
+  s.off_gw = 4 * ms.NPW;                // 2 x NPW words
+  s.off_pt = 6 * ms.NPW;
   s.slice = (s.off_pt + s.rows * STATS_RS + 3) & ~3;
   s.off_slices = byte_lut ? 1024 : 32;      // 256 x 16 B (stand-alone kernel) or 16 x 8 B (fused tail of the Gibbs kernel)
   s.threads = threads > 0 ? threads : stats_mfma_threads(s.NR);

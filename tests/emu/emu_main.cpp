@@ -71,6 +71,9 @@ RngView make_rng(uint64_t seed, uint32_t step, uint32_t off) {
     case 8: { using C = Cfg<64, 32, 1, 1>; __VA_ARGS__; break; }        \
     case 9: { using C = Cfg<4, 5, 1, 2, 2>; __VA_ARGS__; break; }       \
     case 10: { using C = Cfg<10, 15, 0, 3, 3>; __VA_ARGS__; break; }    \
+    case 11: { using C = Cfg<100, 15, 0, 1>; __VA_ARGS__; break; }      \
+    case 12: { using C = Cfg<20, 40, 1, 2>; __VA_ARGS__; break; }       \
+    case 13: { using C = Cfg<70, 33, 1, 1>; __VA_ARGS__; break; }       \
     default: return -1;                                          \
   }
 

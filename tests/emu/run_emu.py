@@ -99,6 +99,9 @@ def make_oracle(K, M, ds, seed=0, batch=4, Lf=20, cd_k=2, wscale=1.0, **kw):
 # 5 (50,25,ss,G2: two mask words) 6 (7,32,ds,G3: sparse, 96-bit letter window) 7 (10,15,ss,G3: config #2)
 # 8 (64,32,ds,G1: the largest model the kernels take; statistics only -- three column roles)
 # 9 (4,5,ds,G2,pooling 2) 10 (10,15,ss,G3,pooling 3): pooled hidden units (convRBM.py:245-267)
+# 11 (100,15,ss,G1: four mask words) 12 (20,40,ds,G2: two-word letter windows, three filter-column tiles)
+# 13 (70,33,ds,G1: three mask words -- 4-byte aligned masks -- and two-word windows)
+LARGE_CASES = [11, 12, 13]
 ALL_CASES = list(range(8))
 POOLED_CASES = [9, 10]
 # One OS thread per GPU thread makes barrier-heavy kernels slow on 8 cores: the
@@ -156,8 +159,8 @@ def test_encode_pack():
     print("encode/pack/reduce ok")
 
 
-def test_hgv():
-    for cid in CASES:
+def test_hgv(cases=None):
+    for cid in (cases or CASES):
         info, o = oracle_for(cid)
         K, M, ds = info["K"], info["M"], info["ds"]
         tables = build_tables(cid, o)
@@ -243,8 +246,8 @@ def run_gibbs(cid, o, tables, S, steps, grid, threads, sparse=1, ones=None):
     return unpack_hidden(hm, K), (unpack_hidden(hmp, K) if ds else None), v, vout, lws
 
 
-def test_gibbs():
-    for cid in GIBBS_CASES:
+def test_gibbs(cases=None):
+    for cid in (cases or GIBBS_CASES):
         info = case_info(cid)
         for sparse in ((1, 0) if info["DENSE"] else (1,)):     # both top-down variants where both exist
             for (B, Lf, S, steps, grid, threads) in ((5, 21, 2, 3, 2, 128), (3, 40, 4, 1, 1, 64)):
@@ -267,11 +270,11 @@ def test_gibbs():
         print("gibbs ok", cid, info)
 
 
-def test_train_step():
+def test_train_step(cases=None):
     """One PCD-k update through the kernels of the product path: data half = stats_mfma_body (SP),
     model half = the fused tail of the Gibbs kernel where the model has one (else Gibbs kernel +
     stand-alone stats_mfma_body on its visible sample), then apply_update; all against the oracle."""
-    for cid in TRAIN_CASES:
+    for cid in (cases or TRAIN_CASES):
         info = case_info(cid)
         K, M, ds, NW = info["K"], info["M"], info["ds"], info["NW"]
         B, Lf, n, L = 4, 18 if cid != 1 else 40, 5, M + 20
@@ -469,18 +472,18 @@ def stats_sums(cid, tables, letters, n, L, want_sparsity, threads, gx, skip=(-1,
     return sums
 
 
-def test_stats_mfma():
+def test_stats_mfma(cases=None):
     """The MFMA statistics kernel against the oracle's raw sums: units that span chains, chains
     shorter than a group, a ragged last group, an odd number of groups, several blocks, one to
     four waves per role."""
-    cases = (ALL_CASES if FULL else [1, 3, 5]) + [8]
+    cases = cases or ((ALL_CASES if FULL else [1, 3, 5]) + [8])
     for cid in cases:
         info = case_info(cid)
         K, M, ds = info["K"], info["M"], info["ds"]
         KAM = K * 4 * M
         # (n, L, waves per role, blocks); NR roles -> 64 * NR * waves threads
         shapes = ((5, M + 20, 2, 3), (3, M + 69, 4, 2), (3, M + 3, 1, 1))
-        if cid == 8:
+        if cid == 8 or cid in LARGE_CASES:
             shapes = ((2, M + 40, 0, 2),)              # default geometry
         for (n, L, wpr, gx) in shapes:
             o = make_oracle(K, M, ds, seed=3, batch=2, Lf=10, rho=0.05)
@@ -611,8 +614,8 @@ def test_pooling():
         print("pooling ok", cid, (K, M, ds, pool))
 
 
-def test_free_energy():
-    for cid in CASES:
+def test_free_energy(cases=None):
+    for cid in (cases or CASES):
         info, o = oracle_for(cid)
         K, M, ds = info["K"], info["M"], info["ds"]
         tables = build_tables(cid, o)
@@ -645,6 +648,16 @@ def test_hit_summary():
             np.testing.assert_allclose(hsum / Lh, P.mean(axis=(2, 3)), rtol=1e-5, atol=1e-7)
             np.testing.assert_allclose(pos / n, P.mean(axis=(0, 2)), rtol=1e-5, atol=1e-7)
         print("hit summary ok", (K, M, ds))
+
+
+def test_large_models():
+    """Models beyond 64 motifs (masks of more than two words) and beyond 32-letter motifs (two-word letter
+    windows, 128-bit statistics windows): every kernel of a training step, the free energy and the chain."""
+    test_hgv([12, 13])
+    test_gibbs([11, 13])
+    test_stats_mfma([12, 13])
+    test_train_step([11, 12])
+    test_free_energy([13])
 
 
 if __name__ == "__main__":

@@ -268,7 +268,7 @@ def test_hitprobs_free_energy_pfms(ds, tmp_path):
 
 # ---- persistent chain (convRBM.py:397-408) -----------------------------------
 @pytest.mark.parametrize("K,M,ds,Lf", [(10, 15, False, 186), (10, 15, True, 200), (20, 15, True, 120),
-                                       (50, 25, False, 100), (3, 4, True, 17)])
+                                       (50, 25, False, 100), (3, 4, True, 17), (100, 15, False, 90), (20, 40, True, 70)])
 def test_gibbs_chain_matches_oracle(K, M, ds, Lf):
     B = 24
     model, o = make_pair(K, M, ds=ds, batchsize=B, Lf=Lf, wscale=1.5, bshift=5.0)
@@ -350,7 +350,8 @@ def test_gibbs_rejects_bad_state():
 
 
 # ---- the PCD-k update (convRBM.py:373-438) -------------------------------------
-@pytest.mark.parametrize("K,M,ds", [(10, 15, True), (10, 15, False), (4, 5, True), (20, 15, True), (50, 25, False)])
+@pytest.mark.parametrize("K,M,ds", [(10, 15, True), (10, 15, False), (4, 5, True), (20, 15, True), (50, 25, False),
+                                    (100, 15, True), (20, 40, False)])
 def test_train_step_trace(K, M, ds):
     B, Lf, n, L = 16, 40, 13, M + 57          # data batch != fantasy batch, lengths differ
     model, o = make_pair(K, M, ds=ds, batchsize=B, Lf=Lf, cd_k=2, bshift=4.0, rho=0.02)
@@ -823,10 +824,14 @@ def test_inference_streams_in_slabs(monkeypatch):
 
 
 @pytest.mark.parametrize("K,M,ds,L,n", [(1, 1, False, 7, 3), (1, 1, True, 1, 2), (5, 8, True, 8, 4),
-                                        (64, 32, True, 45, 3), (33, 17, False, 300, 5), (16, 16, True, 64, 6)])
+                                        (64, 32, True, 45, 3), (33, 17, False, 300, 5), (16, 16, True, 64, 6),
+                                        # beyond 64 motifs (masks of 3..8 words) and beyond 32-letter motifs (two-word
+                                        # letter windows): the reference takes any positive K, M (convRBM.py:72-108)
+                                        (100, 15, False, 120, 4), (20, 40, True, 150, 4), (70, 33, True, 90, 3),
+                                        (130, 7, True, 60, 3), (256, 4, False, 40, 2), (4, 64, True, 100, 3)])
 def test_edge_shapes(K, M, ds, L, n):
     """Smallest and largest supported models, L == M (a single hidden position),
-    mask-word and 64-bit-window boundaries: activations, hit probabilities,
+    mask-word and letter-window boundaries: activations, hit probabilities,
     free energy, a Gibbs chain and a training step against the oracle."""
     Lf = max(1, L - M + 1)
     model, o = make_pair(K, M, ds=ds, batchsize=4, Lf=Lf, cd_k=2, bshift=3.0, wscale=0.7)

@@ -168,13 +168,18 @@ def test_codes_detection():
 
 
 def test_limits_are_refused_at_construction():
-    """K > 64 and M > 32 must not wait for the middle of fit()."""
+    """what the kernels cannot take must not wait for the middle of fit().  Round 3 lifted the
+    K <= 64 / M <= 32 bounds of the mask and window words (the reference accepts any positive K, M,
+    convRBM.py:72-108): what remains is 256 motifs (statistics block size) and 64-letter motifs (two-word
+    letter windows); beyond that the bound is the LDS, reported when the device handle is created."""
     from crbm_amd import CRBM
-    with pytest.raises(Exception, match="num_motifs > 64"):
-        CRBM(65, 5)
-    with pytest.raises(Exception, match="motif_length > 32"):
-        CRBM(4, 33)
-    CRBM(64, 32, pooling=4)                   # the largest model, pooled: fine until a GPU is needed
+    with pytest.raises(Exception, match="num_motifs > 256"):
+        CRBM(257, 5)
+    with pytest.raises(Exception, match="motif_length > 64"):
+        CRBM(4, 65)
+    CRBM(256, 64, pooling=4)                  # fine until a GPU is needed (this one exceeds the LDS there)
+    CRBM(100, 15)
+    CRBM(20, 40)
 
 
 def test_shape_checks_before_the_c_side_reads(monkeypatch):

@@ -20,8 +20,8 @@ if __name__ == "__main__":
     bad = 0
     for case in range(n_cases):
         big = case % 4 == 3                              # every fourth case: large model / long sequences
-        K = int(rng.integers(1, 65 if big else 41))
-        M = int(rng.integers(1, 33 if big else 29))
+        K = int(rng.integers(1, 161 if big else 41))
+        M = int(rng.integers(1, 65 if big else 29))
         ds = bool(rng.integers(0, 2))
         Lf = int(rng.integers(1, 400 if big else 120))
         B = int(rng.integers(1, 40))
