@@ -433,9 +433,7 @@ int launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool d
   return CRBM_OK;
 }
 
-// update + rebuild of the table images in one launch (update_tables_body)
-int launch_update(crbm_handle* h, int L_data) {
-  UpdateTablesArgs a;
+void fill_update_args(crbm_handle* h, int L_data, UpdateTablesArgs& a) {
   UpdateArgs& u = a.u;
   u.sums = h->d_sums;
   u.W = h->dW; u.b = h->db; u.c = h->dc; u.vW = h->dvW; u.vb = h->dvb; u.vc = h->dvc;
@@ -445,19 +443,25 @@ int launch_update(crbm_handle* h, int L_data) {
   u.data_off = h->sl.data_off; u.n_d = h->sl.n_d; u.model_off = h->sl.model_off; u.n_m = h->sl.n_m;
   u.lr = h->cfg.learning_rate; u.momentum = h->cfg.momentum; u.rho = h->cfg.rho; u.lambda_rate = h->cfg.lambda_rate;
   a.tables = h->d_tables;
-  const unsigned grid = (unsigned)std::max(1, std::min((h->ms.TABLES_ALL + 1023) / 1024, 32));
-  HIPCHK(jit_launch(h->jk.update_tables, a, grid, 1, 256, (unsigned)((h->KAM + h->K + 4) * 4), h->stream));
+}
+
+// the update wrote the other set of buffers: it is the current one from now on
+void swap_param_sets(crbm_handle* h) {
   std::swap(h->dW, h->dW2); std::swap(h->db, h->db2); std::swap(h->dc, h->dc2);
   std::swap(h->dvW, h->dvW2); std::swap(h->dvb, h->dvb2); std::swap(h->dvc, h->dvc2);
   h->tables_dirty = false;
+}
+
+// update + rebuild of the table images in one launch (update_tables_body)
+int launch_update(crbm_handle* h, int L_data) {
+  UpdateTablesArgs a;
+  fill_update_args(h, L_data, a);
+  const unsigned grid = (unsigned)std::max(1, std::min((h->ms.TABLES_ALL + 4095) / 4096, 32));
+  HIPCHK(jit_launch(h->jk.update_tables, a, grid, 1, UPDATE_THREADS, (unsigned)((h->KAM + h->K + 4) * 4), h->stream));
+  swap_param_sets(h);
   return CRBM_OK;
 }
 
-// data statistics + k Gibbs steps + model statistics -> d_sums (local).  The two
-// halves are independent given (W,b,c): with CRBM_OVERLAP=1 the model half (chain
-// + its statistics) runs on a second stream beside the data half and is joined
-// before the update (off by default: each kernel fills the chip on its own and the
-// cross-stream events cost ~10 us per step).
 int train_local_dev(crbm_handle* h, const uint32_t* d_letters, int n, int L) {
   int rc = ensure_tables(h);
   if (rc) return rc;

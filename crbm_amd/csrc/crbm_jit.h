@@ -77,14 +77,14 @@ inline std::string jit_stub(int K, int M, int DS, int G, int POOL, int gibbs_wpe
   // kernel's geometry (4 blocks of 4 waves per CU for small models): cap it at 128 registers there
   if (gibbs_wpe > 0) snprintf(sattr, sizeof(sattr), "__attribute__((amdgpu_waves_per_eu(1, %d)))", gibbs_wpe);
   else snprintf(sattr, sizeof(sattr), "__attribute__((amdgpu_waves_per_eu(4)))");
-  char buf[12288];
+  char buf[16384];
   snprintf(buf, sizeof(buf),
            "#include \"crbm_kernels.h\"\n"
            "#ifndef CRBM_GIBBS_ATTR\n#define CRBM_GIBBS_ATTR %s\n#endif\n"
            "#ifndef CRBM_GIBBS_STATS_ATTR\n#define CRBM_GIBBS_STATS_ATTR %s\n#endif\n"
            "using ModelCfg = crbm::Cfg<%d, %d, %d, %d, %d>;\n"
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_build_tables(crbm::TablesArgs a) { crbm::build_tables_body<ModelCfg>(a); }\n"
-           "extern \"C\" __global__ void __launch_bounds__(256) crbm_update_tables(crbm::UpdateTablesArgs a) { crbm::update_tables_body<ModelCfg>(a); }\n"
+           "extern \"C\" __global__ void __launch_bounds__(1024) crbm_update_tables(crbm::UpdateTablesArgs a) { crbm::update_tables_body<ModelCfg>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_hgv(crbm::HgvArgs a) { crbm::hgv_body<ModelCfg>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(%d) CRBM_GIBBS_ATTR crbm_gibbs_sparse(crbm::GibbsArgs a) { crbm::gibbs_body<ModelCfg, true>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) CRBM_GIBBS_STATS_ATTR crbm_gibbs_sparse_stats(crbm::GibbsArgs a) { if constexpr (ModelCfg::FUSE_STATS) crbm::gibbs_body<ModelCfg, true, true>(a); }\n"

@@ -521,10 +521,11 @@ struct TablesArgs {
   float* out;       // Cfg::TABLES_ALL floats
 };
 
+// entries first, first + stride, ... of the table images
 template <class C>
-__device__ void build_tables_body(const TablesArgs& a) {
+__device__ void build_tables_range(const TablesArgs& a, int first, int stride) {
   constexpr int K = C::K, M = C::M;
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < C::TABLES_ALL; idx += gridDim.x * blockDim.x) {
+  for (int idx = first; idx < C::TABLES_ALL; idx += stride) {
     float val = 0.f;
     const bool fwd = idx < C::TAB, rcg = idx >= C::OFF_TR && idx < C::OFF_TR + C::TAB;
     if (fwd || rcg) {                                        // gather tables
@@ -565,6 +566,11 @@ __device__ void build_tables_body(const TablesArgs& a) {
     }
     a.out[idx] = val;
   }
+}
+
+template <class C>
+__device__ void build_tables_body(const TablesArgs& a) {
+  build_tables_range<C>(a, (int)(blockIdx.x * blockDim.x + threadIdx.x), (int)(gridDim.x * blockDim.x));
 }
 
 // ---------------------------------------------------------------------------
@@ -690,7 +696,7 @@ struct StatsRole {
   static constexpr int NR = C::NT / NTW;
   static constexpr int KW = 16 * NTW < C::K ? 16 * NTW : C::K;
   static constexpr int ROWS = KINDS * KW + 1;
-  static constexpr int NACC = 4 * C::JT * KINDS * NTW;
+  static constexpr int NACC = C::NL * C::JT * KINDS * NTW;
   static constexpr int THREADS = stats_mfma_threads(NR);
   static constexpr int NQW = 4 * NTW;            // float4 quads of motifs a wave gathers
 };
@@ -770,7 +776,7 @@ __device__ __forceinline__ void conv_gather_quads(const float* T, const LetterWi
 //   win : the group's four letter windows (NPW/2 words each)
 template <class C, int KINDS, int NTW, bool BYTE_LUT>
 __device__ __forceinline__ void stats_mfma_group(const float* Pt, const uint32_t* win, const uint32_t* lut, int nt0, int slot,
-                                                 floatx4 (&acc)[4 * C::JT * KINDS * NTW]) {
+                                                 floatx4 (&acc)[C::NL * C::JT * KINDS * NTW]) {
   constexpr int KW = 16 * NTW < C::K ? 16 * NTW : C::K, ZROW = KINDS * KW;
   const int lane = threadIdx.x & 63, i16 = lane & 15, g = lane >> 4;
   HalfFrag bhi[KINDS * NTW], blo[KINDS * NTW];
@@ -785,8 +791,10 @@ __device__ __forceinline__ void stats_mfma_group(const float* Pt, const uint32_t
       const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
       split_f16(x, bhi[kind * NTW + t], blo[kind * NTW + t]);
     }
+  // the spare row (filter column M of letter 0, NL == 3): all ones -> sum over positions of P, i.e. H (crbm_layout.h, NL)
+  const uint32_t ones_row = (C::NL == 3 && i16 == C::M % 16) ? 0x04000400u : 0u;
 #pragma unroll
-  for (int a = 0; a < 4; ++a) {
+  for (int a = 0; a < C::NL; ++a) {
     unsigned long long bits = 0ull;
     if constexpr (C::NPW == 4) {
       const uint2 w = reinterpret_cast<const uint2*>(win)[a];
@@ -811,6 +819,10 @@ __device__ __forceinline__ void stats_mfma_group(const float* Pt, const uint32_t
         const uint2 f0 = reinterpret_cast<const uint2*>(lut)[byte & 15u], f1 = reinterpret_cast<const uint2*>(lut)[(byte >> 4) & 15u];
         af.r[0] = f0.x; af.r[1] = f0.y; af.r[2] = f1.x; af.r[3] = f1.y;
       }
+      if (C::NL == 3 && a == 0 && jt == C::JT - 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) af.r[e] |= ones_row;
+      }
 #pragma unroll
       for (int c = 0; c < KINDS * NTW; ++c) {
         floatx4& d = acc[(a * C::JT + jt) * KINDS * NTW + c];
@@ -823,7 +835,8 @@ __device__ __forceinline__ void stats_mfma_group(const float* Pt, const uint32_t
 
 // Combines the waves of a block and writes the block's partial row: vh / vh' / sw blocks, the H
 // and sparsity-bias sums (filter column 0 pairs every hidden position with exactly one letter:
-// sum_s P[k,s] = sum_a VH[k,a,0]) and the letter counts.  Kind by kind, every wave parks its
+// sum_s P[k,s] = sum_a VH[k,a,0]; with NL == 3 the all-ones row gives H directly and the fourth letter is
+// derived from it: crbm_layout.h) and the letter counts.  Kind by kind, every wave parks its
 // accumulator tiles of that kind in a buffer of its own (as many waves at a time as the LDS
 // holds: normally all), then every thread sums the copies of its output elements in wave order
 // -- a barrier pair per kind instead of one per wave, and the same result for every launch
@@ -850,7 +863,7 @@ __device__ __forceinline__ void stats_mfma_finish(const StatsGeom& sg, float* ld
       if (wave >= w0 && wave < w0 + cw) {
         float* mine = wbuf + (size_t)(wave - w0) * PW;
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < C::NL; ++a)
 #pragma unroll
           for (int jt = 0; jt < C::JT; ++jt)
 #pragma unroll
@@ -861,11 +874,13 @@ __device__ __forceinline__ void stats_mfma_finish(const StatsGeom& sg, float* ld
               for (int r = 0; r < 4; ++r) {
                 const int j = 16 * jt + 4 * g + r;
                 if (j < M && 16 * nt0 + kl < K) mine[(a * M + j) * KW + kl] = d[r];   // motif fastest: lanes of a tile row hit consecutive banks
+                // the all-ones row: H, parked in the (unused) slot of letter 3, column 0
+                if (C::NL == 3 && a == 0 && j == M && 16 * nt0 + kl < K) mine[(3 * M) * KW + kl] = d[r];
               }
             }
       }
       __syncthreads();
-      for (int e = threadIdx.x; e < KAM; e += nthr) {                     // e = (letter*M + column)*K + motif
+      for (int e = threadIdx.x; e < (C::NL == 3 ? (3 * M + 1) * K : KAM); e += nthr) {   // e = (letter*M + column)*K + motif
         const int aj = e / K, k = e - aj * K;
         const int role = (k >> 4) / NTW, kl = k - 16 * NTW * role;
         const int o = k * 4 * M + aj;                                     // its place in the (K,4,M) output block
@@ -879,9 +894,19 @@ __device__ __forceinline__ void stats_mfma_finish(const StatsGeom& sg, float* ld
     // kinds: 0 = P (vh, h), 1 = P' when doublestranded (vh', h'), last = Q when SP (sw, sb)
     const int off_w = kind == 0 ? sg.off_vh0 : (C::DS && kind == 1) ? sg.off_vh1 : sg.off_sw;
     const int off_k = kind == 0 ? sg.off_h0 : (C::DS && kind == 1) ? sg.off_h1 : sg.off_sb;
-    for (int i = threadIdx.x; i < KAM; i += nthr) out[off_w + i] = total[i];
-    for (int k = threadIdx.x; k < K; k += nthr)
-      out[off_k + k] = (total[(k * 4) * M] + total[(k * 4 + 1) * M]) + (total[(k * 4 + 2) * M] + total[(k * 4 + 3) * M]);
+    if constexpr (C::NL == 3) {
+      // letter 3 from H (in its column-0 slot) and the three contracted letters
+      for (int i = threadIdx.x; i < KAM; i += nthr) {
+        const int k = i / (4 * M), aj = i - k * 4 * M;
+        const float* tk = total + k * 4 * M;
+        out[off_w + i] = aj < 3 * M ? tk[aj] : tk[3 * M] - ((tk[aj - 3 * M] + tk[aj - 2 * M]) + tk[aj - M]);
+      }
+      for (int k = threadIdx.x; k < K; k += nthr) out[off_k + k] = total[k * 4 * M + 3 * M];
+    } else {
+      for (int i = threadIdx.x; i < KAM; i += nthr) out[off_w + i] = total[i];
+      for (int k = threadIdx.x; k < K; k += nthr)
+        out[off_k + k] = (total[(k * 4) * M] + total[(k * 4 + 1) * M]) + (total[(k * 4 + 2) * M] + total[(k * 4 + 3) * M]);
+    }
     // (the next kind's first barrier orders these reads before `total` is rewritten)
   }
   // letter counts: lane l counted letter (l & 3); lanes of one class -> wave -> block, fixed order
@@ -1794,7 +1819,12 @@ struct UpdateArgs {
 };
 
 // `nw`: when not null, the new W, b, c are also left there ([KAM][K][4], LDS of the caller);
-// `store`: whether this block writes the new parameters and velocities to global memory
+// `store`: whether this block writes the new parameters and velocities to global memory.
+// NE: filter weights a thread may have to take (a compile-time bound on ceil(KAM / blockDim), 0 = run-time loop).
+// The kernel is a chain of memory round trips (sums, parameters, velocities -> a few hundred numbers): with
+// NE known the loads of all of a thread's weights are issued before the first is used -- a run-time loop
+// paid one round trip per iteration (three at config #2 with 256 threads: 7.3 us for the launch).
+template <int NE = 0>
 __device__ __forceinline__ void apply_update_body(const UpdateArgs& a, float* nw, bool store) {
   const int K = a.K, M = a.M, KAM = K * 4 * M;
   const float n_d = a.sums[a.n_d], n_m = a.sums[a.n_m];
@@ -1806,21 +1836,45 @@ __device__ __forceinline__ void apply_update_body(const UpdateArgs& a, float* nw
   const float* d_sw = d + 2 * KAM + 2 * K, *d_sb = d_sw + KAM, *d_v = d_sb + K;
   const float* m_vh = m, *m_vhp = m + KAM, *m_h = m + 2 * KAM, *m_hp = m_h + K, *m_v = m_hp + K;
   const float q = a.rho;
-  for (int idx = threadIdx.x; idx < KAM; idx += blockDim.x) {
+  struct WeightIn { float dvh, mvh, dvhp, mvhp, dh, dsw, vw, w; };
+  auto load_weight = [&](int idx) {
     const int k = idx / (4 * M), al = (idx / M) & 3, j = idx % M;
     const int ridx = (k * 4 + (3 - al)) * M + (M - 1 - j);
-    float gd = d_vh[idx] / cnt_d, gm = m_vh[idx] / cnt_m;
+    WeightIn in;
+    in.dvh = d_vh[idx]; in.mvh = m_vh[idx];
+    in.dvhp = a.ds ? d_vhp[ridx] : 0.f; in.mvhp = a.ds ? m_vhp[ridx] : 0.f;
+    in.dh = d_h[k]; in.dsw = d_sw[idx]; in.vw = a.vW[idx]; in.w = a.W[idx];
+    return in;
+  };
+  auto finish_weight = [&](int idx, const WeightIn& in) {
+    float gd = in.dvh / cnt_d, gm = in.mvh / cnt_m;
     if (a.ds) {
-      gd = 0.5f * (gd + d_vhp[ridx] / cnt_d);
-      gm = 0.5f * (gm + m_vhp[ridx] / cnt_m);
+      gd = 0.5f * (gd + in.dvhp / cnt_d);
+      gm = 0.5f * (gm + in.mvhp / cnt_m);
     }
-    const float p = d_h[k] / cnt_d;
+    const float p = in.dh / cnt_d;
     const float g = (q / p - (1.f - q) / (1.f - p)) / (float)K;
-    const float reg = -g * d_sw[idx] / cnt_d;
-    const float v = a.momentum * a.vW[idx] + a.lr * (gd - gm - a.lambda_rate * reg);
-    const float w = a.W[idx] + v;
+    const float reg = -g * in.dsw / cnt_d;
+    const float v = a.momentum * in.vw + a.lr * (gd - gm - a.lambda_rate * reg);
+    const float w = in.w + v;
     if (store) { a.ovW[idx] = v; a.oW[idx] = w; }
     if (nw) nw[idx] = w;
+  };
+  if constexpr (NE > 0) {
+    WeightIn in[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int idx = (int)threadIdx.x + e * (int)blockDim.x;
+      if (idx < KAM) in[e] = load_weight(idx);
+    }
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int idx = (int)threadIdx.x + e * (int)blockDim.x;
+      if (idx < KAM) finish_weight(idx, in[e]);
+    }
+    for (int idx = (int)threadIdx.x + NE * (int)blockDim.x; idx < KAM; idx += blockDim.x) finish_weight(idx, load_weight(idx));   // smaller blocks than assumed
+  } else {
+    for (int idx = threadIdx.x; idx < KAM; idx += blockDim.x) finish_weight(idx, load_weight(idx));
   }
   for (int k = threadIdx.x; k < K; k += blockDim.x) {
     float gd = d_h[k] / cnt_d, gm = m_h[k] / cnt_m;
@@ -1854,6 +1908,7 @@ __device__ __forceinline__ void apply_update_body(const UpdateArgs& a, float* nw
 // tables from there; block 0 also stores the new parameters and velocities -- into the OTHER set of
 // buffers (the host swaps the two sets after the launch), because the remaining blocks may still be
 // reading the old ones.
+constexpr int UPDATE_THREADS = 1024;   // block size of the update launches of the product (the emulator uses smaller ones)
 struct UpdateTablesArgs {
   UpdateArgs u;
   float* tables;     // Cfg::TABLES_ALL floats
@@ -1863,12 +1918,77 @@ template <class C>
 __device__ void update_tables_body(const UpdateTablesArgs& a) {
   HIP_DYNAMIC_SHARED(float, smem);
   constexpr int KAM = C::K * 4 * C::M;
-  apply_update_body(a.u, smem, blockIdx.x == 0);
+  apply_update_body<cdiv(KAM, UPDATE_THREADS) <= 8 ? cdiv(KAM, UPDATE_THREADS) : 0>(a.u, smem, blockIdx.x == 0);
   __syncthreads();
   TablesArgs t;
   t.W = smem; t.b = smem + KAM; t.c = smem + KAM + C::K; t.out = a.tables;
   build_tables_body<C>(t);
 }
+
+// sums[dst(r)] = sum over partial rows of column r in a fixed order.  Block =
+// 32 columns x (blockDim / 32) row groups: each thread adds the rows of its group (128-byte
+// segments per row), the 32 groups are combined through LDS.  The partial
+// buffer is never cleared: the kernel knows which column classes a statistics
+// launch wrote and yields 0 for the classes that launch did not compute.
+struct ReduceArgs {
+  const float* partials;
+  float* sums;
+  int32_t nrows, row;
+  int32_t K, KAM, ds, want_sparsity;
+  int32_t skip_begin, skip_len;   // columns [skip_begin, skip_begin+skip_len) are dropped
+  float n_value;                  // written after the last kept column
+};
+
+__device__ __forceinline__ void reduce_partials_body(const ReduceArgs& a) {
+  __shared__ float part[32][33];
+  const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int ngrp = (int)(blockDim.x >> 5);          // 32 row groups in the 1024-thread launches of the product
+  const int r = blockIdx.x * 32 + col;
+  float tsum = 0.f;
+  if (r < a.row) {
+    // column classes of a partial row: [vh KAM][vh' KAM][h K][h' K][sw KAM][sb K][v 4]
+    const int K = a.K, KAM = a.KAM;
+    bool valid;
+    if (r < KAM) valid = true;
+    else if (r < 2 * KAM) valid = a.ds != 0;
+    else if (r < 2 * KAM + K) valid = true;
+    else if (r < 2 * KAM + 2 * K) valid = a.ds != 0;
+    else if (r < 3 * KAM + 3 * K) valid = a.want_sparsity != 0;
+    else valid = true;
+    if (valid) {
+      // eight rows in flight per thread (the kernel is a chain of memory round trips: ~2 000 rows of a few KB;
+      // sixteen in flight measured slower, 5.1 -> 5.7 us); fixed order
+      float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f, t4 = 0.f, t5 = 0.f, t6 = 0.f, t7 = 0.f;
+      int i = grp;
+      for (; i + 7 * ngrp < a.nrows; i += 8 * ngrp) {
+        const float v0 = a.partials[(size_t)i * a.row + r], v1 = a.partials[(size_t)(i + ngrp) * a.row + r];
+        const float v2 = a.partials[(size_t)(i + 2 * ngrp) * a.row + r], v3 = a.partials[(size_t)(i + 3 * ngrp) * a.row + r];
+        const float v4 = a.partials[(size_t)(i + 4 * ngrp) * a.row + r], v5 = a.partials[(size_t)(i + 5 * ngrp) * a.row + r];
+        const float v6 = a.partials[(size_t)(i + 6 * ngrp) * a.row + r], v7 = a.partials[(size_t)(i + 7 * ngrp) * a.row + r];
+        t0 += v0; t1 += v1; t2 += v2; t3 += v3; t4 += v4; t5 += v5; t6 += v6; t7 += v7;
+      }
+      for (; i < a.nrows; i += ngrp) t0 += a.partials[(size_t)i * a.row + r];
+      tsum = ((t0 + t1) + (t2 + t3)) + ((t4 + t5) + (t6 + t7));
+    }
+  }
+  part[grp][col] = tsum;
+  __syncthreads();
+  if (grp == 0 && r < a.row) {
+    const bool skipped = r >= a.skip_begin && r < a.skip_begin + a.skip_len;
+    if (!skipped) {
+      float s = 0.f;
+      for (int g = 0; g < ngrp; ++g) s += part[g][col];
+      a.sums[r < a.skip_begin ? r : r - a.skip_len] = s;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.sums[a.row - a.skip_len] = a.n_value;
+}
+
+
+// both halves of a training step in one launch (blockIdx.y = 0: data, 1: model)
+struct ReducePair {
+  ReduceArgs half[2];
+};
 
 #ifdef CRBM_DEFINE_MISC_KERNELS
 // ===========================================================================
@@ -2091,74 +2211,13 @@ __global__ void __launch_bounds__(256) vgh_dense_kernel(VghArgs a) {
   }
 }
 
-// sums[dst(r)] = sum over partial rows of column r in a fixed order.  Block =
-// 32 columns x 32 row groups: each thread adds the rows of its group (128-byte
-// segments per row), the 32 groups are combined through LDS.  The partial
-// buffer is never cleared: the kernel knows which column classes a statistics
-// launch wrote and yields 0 for the classes that launch did not compute.
-struct ReduceArgs {
-  const float* partials;
-  float* sums;
-  int32_t nrows, row;
-  int32_t K, KAM, ds, want_sparsity;
-  int32_t skip_begin, skip_len;   // columns [skip_begin, skip_begin+skip_len) are dropped
-  float n_value;                  // written after the last kept column
-};
-
-__device__ __forceinline__ void reduce_partials_body(const ReduceArgs& a) {
-  __shared__ float part[32][33];
-  const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  const int r = blockIdx.x * 32 + col;
-  float t = 0.f;
-  if (r < a.row) {
-    // column classes of a partial row: [vh KAM][vh' KAM][h K][h' K][sw KAM][sb K][v 4]
-    const int K = a.K, KAM = a.KAM;
-    bool valid;
-    if (r < KAM) valid = true;
-    else if (r < 2 * KAM) valid = a.ds != 0;
-    else if (r < 2 * KAM + K) valid = true;
-    else if (r < 2 * KAM + 2 * K) valid = a.ds != 0;
-    else if (r < 3 * KAM + 3 * K) valid = a.want_sparsity != 0;
-    else valid = true;
-    if (valid) {
-      // eight rows in flight per thread (the kernel is a chain of memory round trips: ~2 000 rows of a few KB); fixed order
-      float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f, t4 = 0.f, t5 = 0.f, t6 = 0.f, t7 = 0.f;
-      int i = grp;
-      for (; i + 224 < a.nrows; i += 256) {
-        const float v0 = a.partials[(size_t)i * a.row + r], v1 = a.partials[(size_t)(i + 32) * a.row + r];
-        const float v2 = a.partials[(size_t)(i + 64) * a.row + r], v3 = a.partials[(size_t)(i + 96) * a.row + r];
-        const float v4 = a.partials[(size_t)(i + 128) * a.row + r], v5 = a.partials[(size_t)(i + 160) * a.row + r];
-        const float v6 = a.partials[(size_t)(i + 192) * a.row + r], v7 = a.partials[(size_t)(i + 224) * a.row + r];
-        t0 += v0; t1 += v1; t2 += v2; t3 += v3; t4 += v4; t5 += v5; t6 += v6; t7 += v7;
-      }
-      for (; i < a.nrows; i += 32) t0 += a.partials[(size_t)i * a.row + r];
-      t = ((t0 + t1) + (t2 + t3)) + ((t4 + t5) + (t6 + t7));
-    }
-  }
-  part[grp][col] = t;
-  __syncthreads();
-  if (grp == 0 && r < a.row) {
-    const bool skipped = r >= a.skip_begin && r < a.skip_begin + a.skip_len;
-    if (!skipped) {
-      float s = 0.f;
-      for (int g = 0; g < 32; ++g) s += part[g][col];
-      a.sums[r < a.skip_begin ? r : r - a.skip_len] = s;
-    }
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) a.sums[a.row - a.skip_len] = a.n_value;
-}
-
 __global__ void __launch_bounds__(1024) reduce_partials_kernel(ReduceArgs a) { reduce_partials_body(a); }
 
-// both halves of a training step in one launch (blockIdx.y = 0: data, 1: model)
-struct ReducePair {
-  ReduceArgs half[2];
-};
 __global__ void __launch_bounds__(1024) reduce_partials_pair_kernel(ReducePair p) {
   reduce_partials_body(p.half[blockIdx.y]);
 }
 
-__global__ void apply_update_kernel(UpdateArgs a) { apply_update_body(a, nullptr, true); }   // one block, in place
+__global__ void apply_update_kernel(UpdateArgs a) { apply_update_body<0>(a, nullptr, true); }   // one block, in place
 #endif  // CRBM_DEFINE_MISC_KERNELS
 
 }  // namespace crbm

@@ -101,6 +101,11 @@ struct Cfg {
   static constexpr int NT = cdiv(K, 16);                  // motif tiles per column kind
   static constexpr int JT = cdiv(M, 16);                  // filter-column tiles per letter
   static constexpr int NPW = stats_npw(M);                // 16-bit pieces per letter window (64 or 128 bits)
+  // Letters contracted on the matrix cores.  Every visible position carries exactly one letter, so
+  // sum_a VH[k,a,j] = sum_s P[k,s] = H[k] for every filter column j: with a spare row in the last
+  // filter-column tile (M not a multiple of 16) that row is fed all ones and yields H, and the fourth
+  // letter follows as H - (the other three) -- a quarter fewer MFMAs and A fragments.
+  static constexpr int NL = (M % 16 != 0) ? 3 : 4;
   static_assert(M <= MAX_MOTIF_LENGTH && K <= MAX_MOTIFS, "model beyond the kernels' limits");
   // the model half of the statistics rides in the Gibbs kernel's last h|v pass when all motifs of
   // a position fit one wave's accumulator set of at most 8 tiles (32 registers; measured: with 16 tiles,

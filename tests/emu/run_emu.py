@@ -85,6 +85,14 @@ def check_samples(name, got, prob, u):
     return int(bad.sum())
 
 
+def close_vh(got, want, rtol=2e-5):
+    """A (K,4,M) block of raw VH sums against the oracle's.  Where the fourth letter is derived as
+    H - (the other three) (models whose motif length is not a multiple of 16: crbm_layout.h, NL) its absolute
+    error follows the scale of H = sum_a VH[k,a,j], not its own: 4e-7 of the largest H is allowed."""
+    want = np.asarray(want, dtype=np.float64).ravel()
+    np.testing.assert_allclose(got, want, rtol=rtol, atol=1e-6 + 4e-7 * 4 * float(np.abs(want).max()))
+
+
 def make_oracle(K, M, ds, seed=0, batch=4, Lf=20, cd_k=2, wscale=1.0, **kw):
     rng = np.random.default_rng(100 + K * 31 + M)
     o = OracleCRBM(K, M, doublestranded=ds, batchsize=batch, cd_k=cd_k, fantasy_hidden_len=Lf, seed=seed,
@@ -340,17 +348,17 @@ def test_train_step(cases=None):
         o.gibbs_step -= o.cd_k
         s = o.local_sums(D, P_m, P_mp, v_m)
         KAM = K * 4 * M
-        np.testing.assert_allclose(sums[0:KAM], s['vh_d'].ravel(), rtol=2e-5, atol=1e-6)
+        close_vh(sums[0:KAM], s['vh_d'])
         np.testing.assert_allclose(sums[2 * KAM:2 * KAM + K], s['h_d'], rtol=2e-5)
-        np.testing.assert_allclose(sums[2 * KAM + 2 * K:3 * KAM + 2 * K], s['sw'].ravel(), rtol=2e-5, atol=1e-6)
+        close_vh(sums[2 * KAM + 2 * K:3 * KAM + 2 * K], s['sw'])
         np.testing.assert_allclose(sums[3 * KAM + 2 * K:3 * KAM + 3 * K], s['sb'], rtol=2e-5)
         np.testing.assert_allclose(sums[3 * KAM + 3 * K:3 * KAM + 3 * K + 4], s['v_d'])
-        np.testing.assert_allclose(sums[model_off:model_off + KAM], s['vh_m'].ravel(), rtol=2e-5, atol=1e-6)
+        close_vh(sums[model_off:model_off + KAM], s['vh_m'])
         np.testing.assert_allclose(sums[model_off + 2 * KAM:model_off + 2 * KAM + K], s['h_m'], rtol=2e-5)
         np.testing.assert_allclose(sums[n_m - 4:n_m], s['v_m'])
         if ds:
-            np.testing.assert_allclose(sums[KAM:2 * KAM], s['vh_dp'].ravel(), rtol=2e-5, atol=1e-6)
-            np.testing.assert_allclose(sums[model_off + KAM:model_off + 2 * KAM], s['vh_mp'].ravel(), rtol=2e-5, atol=1e-6)
+            close_vh(sums[KAM:2 * KAM], s['vh_dp'])
+            close_vh(sums[model_off + KAM:model_off + 2 * KAM], s['vh_mp'])
             np.testing.assert_allclose(sums[model_off + 2 * KAM + K:model_off + 2 * KAM + 2 * K], s['h_mp'], rtol=2e-5)
         new_tables = np.zeros(info["TABLES"], dtype=np.float32)
         old = [x.copy() for x in (W, b, c, vW, vb, vc)]
@@ -508,14 +516,14 @@ def test_stats_mfma(cases=None):
                     ntw -= 1
                 threads = 64 * (NT // ntw) * wpr
                 s = stats_sums(cid, tables, letters, n, L, want, threads, gx)
-                np.testing.assert_allclose(s[0:KAM], vh(P).ravel(), rtol=2e-5, atol=1e-6)
+                close_vh(s[0:KAM], vh(P))
                 np.testing.assert_allclose(s[2 * KAM:2 * KAM + K], P.sum(axis=(0, 2, 3)), rtol=2e-5)
                 if ds:
-                    np.testing.assert_allclose(s[KAM:2 * KAM], vh(Pp).ravel(), rtol=2e-5, atol=1e-6)
+                    close_vh(s[KAM:2 * KAM], vh(Pp))
                     np.testing.assert_allclose(s[2 * KAM + K:2 * KAM + 2 * K], Pp.sum(axis=(0, 2, 3)), rtol=2e-5)
                 if want:
                     Q = P * (1 - P)
-                    np.testing.assert_allclose(s[2 * KAM + 2 * K:3 * KAM + 2 * K], vh(Q).ravel(), rtol=2e-5, atol=1e-6)
+                    close_vh(s[2 * KAM + 2 * K:3 * KAM + 2 * K], vh(Q))
                     np.testing.assert_allclose(s[3 * KAM + 2 * K:3 * KAM + 3 * K], Q.sum(axis=(0, 2, 3)), rtol=2e-5)
                 np.testing.assert_array_equal(s[3 * KAM + 3 * K:3 * KAM + 3 * K + 4], Dv.sum(axis=(0, 2)))
                 assert s[3 * KAM + 3 * K + 4] == n
@@ -605,12 +613,12 @@ def test_pooling():
                                   fp(partials), partials.size, fp(sums[model_off:]), skipb, skipl) == row
         s = o.local_sums(d, P_m, P_mp, v_m)
         KAM = K * 4 * M
-        np.testing.assert_allclose(sums[0:KAM], s['vh_d'].ravel(), rtol=2e-5, atol=1e-6)
-        np.testing.assert_allclose(sums[2 * KAM + 2 * K:3 * KAM + 2 * K], s['sw'].ravel(), rtol=5e-5, atol=1e-6)
+        close_vh(sums[0:KAM], s['vh_d'])
+        close_vh(sums[2 * KAM + 2 * K:3 * KAM + 2 * K], s['sw'], rtol=5e-5)
         np.testing.assert_allclose(sums[3 * KAM + 2 * K:3 * KAM + 3 * K], s['sb'], rtol=5e-5, atol=1e-6)
-        np.testing.assert_allclose(sums[model_off:model_off + KAM], s['vh_m'].ravel(), rtol=2e-5, atol=1e-6)
+        close_vh(sums[model_off:model_off + KAM], s['vh_m'])
         if ds:
-            np.testing.assert_allclose(sums[model_off + KAM:model_off + 2 * KAM], s['vh_mp'].ravel(), rtol=2e-5, atol=1e-6)
+            close_vh(sums[model_off + KAM:model_off + 2 * KAM], s['vh_mp'])
         print("pooling ok", cid, (K, M, ds, pool))
 
 

@@ -663,7 +663,10 @@ def test_baseline_config_full_batch(K, M, ds, L, cd_k):
         ref = o2.local_sums(D, P_m, P_mp, v_m)
         got = _unpack_sums(buf, K, M)
         for key in ("vh_d", "h_d", "sw", "sb", "v_d", "vh_m", "h_m", "v_m") + (("vh_dp", "h_dp", "vh_mp", "h_mp") if ds else ()):
-            np.testing.assert_allclose(got[key], np.ravel(ref[key]), rtol=RTOL, atol=1e-5, err_msg=key)
+            # (K,4,M) blocks: the fourth letter is derived as H - (the other three) when M is not a multiple of 16
+            # (crbm_layout.h, NL), so its absolute error follows H = sum_a VH[k,a,j] -- 4e-7 of the largest H
+            atol = 1e-5 + (1.6e-6 * float(np.abs(ref[key]).max()) if key.startswith(("vh", "sw")) else 0.0)
+            np.testing.assert_allclose(got[key], np.ravel(ref[key]), rtol=RTOL, atol=atol, err_msg=key)
         assert got["n_d"] == 64 and got["n_m"] == 8
     else:                                   # a tie flipped a unit: the step-by-step test above vouches for the chain
         assert (h2 != o2.fantasy_h).mean() < 1e-4
