@@ -17,8 +17,9 @@ chain applied to one batch of 8192 chains per GPU -- the PCD-1 Gibbs step of
 BASELINE.json's metric, config #2 (10 motifs of length 15, visible 4x200,
 single-stranded); chains are sharded over ranks with no data-path collective
 (weak scaling), so `value` = N_gpus * K / T in "8192-chain batch Gibbs steps
-per second", T = the HOST clock around the K launches, bracketed by a barrier
-and a stream synchronisation on both sides, max over ranks (metric_version 3;
+per second", T = the HOST clock of each rank from the opening barrier (every
+stream idle) until its own K launches have completed, max over ranks, then a
+closing barrier (metric_version 3;
 round 2 quoted the HIP-event time, which is still reported as
 `device_ms_per_step` and is what the roofline object prices the kernel with).
 Inputs (chain state, parameters) are resident in HBM when the timed region
@@ -322,9 +323,9 @@ def main():
     total_ms = ctypes.c_float()
     barrier()
     t0 = time.perf_counter()
-    model._call("crbm_time_gibbs", k, args.steps, ctypes.byref(total_ms))
-    barrier()
-    wall = time.perf_counter() - t0
+    model._call("crbm_time_gibbs", k, args.steps, ctypes.byref(total_ms))     # returns once its last launch has completed
+    wall = time.perf_counter() - t0          # this rank's K steps, start barrier -> own stream idle; the closing barrier
+    barrier()                                # (TCP round trips, a blocking read-back of the activity monitor) is not step time
     wall, kernel_s = control.allreduce_max([wall, total_ms.value / 1e3])
     launches = args.steps
     steps_done = args.steps * k                  # Gibbs steps per rank in the timed region
@@ -417,8 +418,8 @@ def main():
                        "hidden": "%dx%d" % (cfg["K"], cfg["L"] - cfg["M"] + 1),
                        "parallelism": "chains sharded over %d GPU(s), no collective in the Gibbs step" % world,
                        "hidden_activity": activity},
-            "timing": "value and ms_per_step: host clock around the K launches, barrier + stream synchronise on both sides, "
-                      "max over ranks (metric_version 3; version 2 = round 2 quoted the HIP-event time, now device_ms_per_step / "
+            "timing": "value and ms_per_step: host clock of each rank from the opening barrier (all streams idle) until its own K "
+                      "launches have completed (event synchronise), max over ranks, closing barrier behind it (metric_version 3; version 2 = round 2 quoted the HIP-event time, now device_ms_per_step / "
                       "value_device; version 1 = round 1, host clock).  warmup_effective counts the chain burn-in launches "
                       "(chains start at h = 0) together with the --warmup launches",
             "chain_steps_per_s": value * cfg["chains"],
@@ -468,8 +469,9 @@ def main():
                 barrier()
                 t1 = time.perf_counter()
                 model._call("crbm_time_train", 0, n, tsteps, ctypes.byref(tms))
+                dt = time.perf_counter() - t1
                 barrier()
-                return control.allreduce_max([time.perf_counter() - t1, tms.value / 1e3])
+                return control.allreduce_max([dt, tms.value / 1e3])
 
             local_dev = rccl_init_s = allreduce_us = None
             if rccl:
