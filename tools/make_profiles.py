@@ -30,15 +30,23 @@ cp("gibbs_steps_per_launch_scan.txt", "gibbs_steps_per_launch_scan.txt")
 cp("pmc_summary.txt", "pmc_summary.txt")
 cp("pytest.log", "gpu_tests.log")
 
-# Gibbs traffic per config from the FETCH_SIZE / WRITE_SIZE / instruction passes of tools/prof_gibbs.py
+cp("bench_driver.json", "bench_cfg2_driver_style_20_steps.json")
+cp("bench_6rank_one_gpu_rehearsal.json", "bench_cfg2_6rank_one_gpu_rehearsal.json")
+cp("bench_cfg5_4rank_one_gpu_rehearsal.json", "bench_cfg5_4rank_one_gpu_rehearsal.json")
+cp("floor_scan.txt", "gibbs_launch_floor_scan.txt")
+cp("lds_conflict_phases.txt", "stats_lds_conflicts_by_phase.txt")
+cp("trace_train.txt", "train_step_kernel_trace.txt")
+
+# Counters of the chain kernel per config (what bench.py quotes when it cannot collect them itself): mean per launch
+# of every counter of the passes of tools/prof_gibbs.py (FETCH_SIZE and WRITE_SIZE in passes of their own)
 out = {}
 for cfg in ("cfg2", "cfg4", "cfg5"):
     vals = {}
-    for p, names in (("f", ["FETCH_SIZE"]), ("w", ["WRITE_SIZE"]), ("a", ["SQ_INSTS_VALU", "SQ_INSTS_LDS"])):
+    for p in "abfw":
         for f in glob.glob(os.path.join(src, "pmc_gibbs_%s_%s" % (cfg, p), "**", "*counter_collection.csv"), recursive=True):
             acc = defaultdict(lambda: defaultdict(float))
             for r in csv.DictReader(open(f)):
-                if r["Kernel_Name"].startswith("crbm_gibbs") and r["Counter_Name"] in names:
+                if r["Kernel_Name"].startswith("crbm_gibbs"):
                     acc[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
             for name in acc:
                 ids = sorted(acc[name], key=int)
@@ -46,12 +54,11 @@ for cfg in ("cfg2", "cfg4", "cfg5"):
                 vals[name] = sum(acc[name][i] for i in ids) / len(ids)
     if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
         out[cfg] = {
+            "counters": vals,
             "hbm_bytes_per_launch": int((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024),
-            "fetch_size_kb_raw": vals["FETCH_SIZE"], "write_size_kb": vals["WRITE_SIZE"],
             "correction": "gfx950 FETCH_SIZE reports 1/2 of a wide coalesced streaming read (MI355X_MICROARCH.md, HBM): doubled",
-            "valu_wave_insts_per_launch": vals.get("SQ_INSTS_VALU"), "lds_wave_insts_per_launch": vals.get("SQ_INSTS_LDS"),
-            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / SQ_INSTS_* (separate passes) of python3 tools/prof_gibbs.py %s "
-                      "(tools/runs/evidence.sh; profiles/%s_pmc_summary.txt)" % (cfg, rnd),
+            "source": "rocprofv3 --pmc passes of python3 tools/prof_gibbs.py %s on another box (tools/runs/evidence.sh; "
+                      "profiles/%s_pmc_summary.txt)" % (cfg, rnd),
         }
 json.dump(out, open(os.path.join(dst, "gibbs_traffic.json"), "w"), indent=1)
 print("profiles/gibbs_traffic.json", sorted(out))
