@@ -257,7 +257,7 @@ int launch_hgv(crbm_handle* h, const uint32_t* d_letters, int n, int L, int mode
   a.kind = kind;
   const int ntiles = (n + a.TS - 1) / a.TS;
   const unsigned gx = (unsigned)std::max(1, std::min(ntiles, h->num_cu * 8));
-  HIPCHK(jit_launch(h->jk.hgv, a, gx, 1, 256, (unsigned)((mode == 2 ? 2 : 1) * tab_bytes(h)), h->stream));
+  HIPCHK(jit_launch(h->jk.hgv, a, gx, 1, 256, (unsigned)tab_bytes(h), h->stream));
   return CRBM_OK;
 }
 
@@ -369,7 +369,7 @@ int prepare_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool 
   DevBuf<float>& pbuf = data_half ? h->partials : h->partials2;
   const int want_sp = data_half ? 1 : 0;
   const int Lh = L - h->M + 1;
-  const int tabs = (1 + h->ds) * tab_bytes(h);
+  const int tabs = tab_bytes(h);
   const bool own = threads <= 0;
   // CRBM_STATS_MAX_TILES is an experiment knob: it must come with CRBM_JIT_DEFINES=-DCRBM_STATS_MAX_TILES=<same>
   const StatsMfmaLayout st = stats_mfma_layout(h->ms, want_sp, Lh, own ? env_int("CRBM_STATS_THREADS", 0) : threads, tabs, own,
@@ -665,7 +665,7 @@ int crbm_precompile(const crbm_config* cfg) {
   if (rc) return rc;
   const int ds = cfg->doublestranded ? 1 : 0;
   int G = env_int("CRBM_GROUP", 0);
-  if (G < 1 || G > 4) G = choose_group(cfg->num_motifs, cfg->motif_length, ds, env_int("CRBM_TABLE_BUDGET", 24 * 1024));
+  if (G < 1 || G > 4) G = choose_group(cfg->num_motifs, cfg->motif_length, ds, env_int("CRBM_TABLE_BUDGET", 26 * 1024));
   const ModelShape ms = model_shape(cfg->num_motifs, cfg->motif_length, ds, G, cfg->pooling);
   std::vector<char> code;
   bool cached = false;
@@ -703,7 +703,7 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
   hh->sl = sums_layout(hh->K, hh->M);
   // gather-table group size, derived shapes
   hh->G = env_int("CRBM_GROUP", 0);
-  if (hh->G < 1 || hh->G > 4) hh->G = choose_group(hh->K, hh->M, hh->ds, env_int("CRBM_TABLE_BUDGET", 24 * 1024));
+  if (hh->G < 1 || hh->G > 4) hh->G = choose_group(hh->K, hh->M, hh->ds, env_int("CRBM_TABLE_BUDGET", 26 * 1024));
   hh->ms = model_shape(hh->K, hh->M, hh->ds, hh->G, cfg->pooling);
   hh->NW = hh->ms.NW;
   auto bail = [&](int code) { crbm_destroy(hh); return code; };
@@ -1333,7 +1333,7 @@ int launch_free_energy(crbm_handle* h, const uint32_t* rows, int n, int L, const
   a.n = n; a.L = L; a.Lh = L - h->M + 1; a.LW = letter_words(L);
   a.fe = set.oa->p; a.fem = set.ob->p;
   const unsigned gx = (unsigned)std::max(1, std::min((n + 3) / 4, h->num_cu * 8));
-  HIPCHK(jit_launch(h->jk.free_energy, a, gx, 1, 256, (unsigned)((1 + h->ds) * tab_bytes(h)), set.st));
+  HIPCHK(jit_launch(h->jk.free_energy, a, gx, 1, 256, (unsigned)tab_bytes(h), set.st));
   return CRBM_OK;
 }
 
@@ -1406,7 +1406,7 @@ int hit_summary_any(crbm_handle* h, const RowSource& src, float* hmax, float* hm
   int rc = check_data_shape(h, src.n, src.L);
   if (rc) return rc;
   const int n = src.n, L = src.L, Lh = L - h->M + 1, K = h->K;
-  const int tabs = (h->ds ? 1 : 2) * tab_bytes(h);
+  const int tabs = tab_bytes(h);
   // a block covers one chunk of 64*HIT_NI positions; its (PC,K) sums share the LDS with the tables
   const int PC = 64 * h->ms.HIT_NI;
   const int nchunks = (Lh + PC - 1) / PC;
@@ -1702,7 +1702,7 @@ int crbm_time_allreduce(crbm_handle* h, int32_t launches, float* total_ms) {
 int crbm_get_launch_info(const crbm_handle* h, crbm_launch_info* out) {
   if (!h || !out) return CRBM_ERR_INVALID;
   // the data-half statistics kernel at the chains' shape (stats_mfma_body)
-  const int tabs = (1 + h->ds) * h->ms.TAB * 4;
+  const int tabs = h->ms.TAB * 4;
   const StatsMfmaLayout st = stats_mfma_layout(h->ms, 1, h->Lf, 0, tabs);
   const int lds = std::max(st.region_floats * 4 + tabs, st.combine_bytes);
   out->nq = h->ms.NQ; out->group = h->G;

@@ -82,6 +82,7 @@ inline std::string jit_stub(int K, int M, int DS, int G, int POOL, int gibbs_wpe
            "#include \"crbm_kernels.h\"\n"
            "#ifndef CRBM_GIBBS_ATTR\n#define CRBM_GIBBS_ATTR %s\n#endif\n"
            "#ifndef CRBM_GIBBS_STATS_ATTR\n#define CRBM_GIBBS_STATS_ATTR %s\n#endif\n"
+           "#ifndef CRBM_STATS_BYTE_LUT\n#define CRBM_STATS_BYTE_LUT true\n#endif\n"
            "using ModelCfg = crbm::Cfg<%d, %d, %d, %d, %d>;\n"
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_build_tables(crbm::TablesArgs a) { crbm::build_tables_body<ModelCfg>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(1024) crbm_update_tables(crbm::UpdateTablesArgs a) { crbm::update_tables_body<ModelCfg>(a); }\n"
@@ -91,8 +92,8 @@ inline std::string jit_stub(int K, int M, int DS, int G, int POOL, int gibbs_wpe
            "extern \"C\" __global__ void __launch_bounds__(256) CRBM_GIBBS_STATS_ATTR crbm_train_local(crbm::TrainLocalArgs a) { crbm::train_local_body<ModelCfg>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(%d) crbm_gibbs(crbm::GibbsArgs a) { if constexpr (ModelCfg::DENSE) crbm::gibbs_body<ModelCfg, ModelCfg::DENSE ? false : true>(a); }\n"
            "using RoleData = crbm::StatsRole<ModelCfg, true>;\nusing RoleModel = crbm::StatsRole<ModelCfg, false>;\n"
-           "extern \"C\" __global__ void __launch_bounds__(RoleData::THREADS) crbm_stats_mfma_data(crbm::StatsMfmaArgs a) { crbm::stats_mfma_body<ModelCfg, true>(a); }\n"
-           "extern \"C\" __global__ void __launch_bounds__(RoleModel::THREADS) crbm_stats_mfma_model(crbm::StatsMfmaArgs a) { crbm::stats_mfma_body<ModelCfg, false>(a); }\n"
+           "extern \"C\" __global__ void __launch_bounds__(RoleData::THREADS) crbm_stats_mfma_data(crbm::StatsMfmaArgs a) { crbm::stats_mfma_body<ModelCfg, true, CRBM_STATS_BYTE_LUT>(a); }\n"
+           "extern \"C\" __global__ void __launch_bounds__(RoleModel::THREADS) crbm_stats_mfma_model(crbm::StatsMfmaArgs a) { crbm::stats_mfma_body<ModelCfg, false, CRBM_STATS_BYTE_LUT>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_free_energy(crbm::FeArgs a) { crbm::free_energy_body<ModelCfg>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_hit_summary(crbm::HitArgs a) { crbm::hit_summary_body<ModelCfg>(a); }\n",
            attr, sattr, K, M, DS, G, POOL, gibbs_tb, gibbs_tb);

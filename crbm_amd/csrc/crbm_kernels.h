@@ -53,6 +53,7 @@ struct HalfFrag {     // eight f16 = one A or B fragment of v_mfma_f32_16x16x32_
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 // a ^ b ^ c in one instruction (v_bitop3_b32, truth table 0x96); the compiler does not fuse it itself
 __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+__device__ __forceinline__ uint32_t bitrev32(uint32_t x) { return __builtin_bitreverse32(x); }   // v_bfrev_b32
 // 16-byte store that does not linger in the caches (the chain state is written once
 // per launch and next read by another launch: measured 0.45 us per launch at config #2)
 __device__ __forceinline__ void store4_streaming(uint32_t* dst, uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
@@ -94,6 +95,13 @@ typedef float floatx2 __attribute__((vector_size(8)));
 __device__ __forceinline__ floatx2 fma2(floatx2 a, floatx2 b, floatx2 c) { return floatx2{fmaf(a[0], b[0], c[0]), fmaf(a[1], b[1], c[1])}; }
 __device__ __forceinline__ floatx2 opaque(floatx2 v) { return v; }
 __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return a ^ b ^ c; }
+__device__ __forceinline__ uint32_t bitrev32(uint32_t x) {
+  x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+  x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+  x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+  x = ((x >> 8) & 0x00FF00FFu) | ((x & 0x00FF00FFu) << 8);
+  return (x >> 16) | (x << 16);
+}
 __device__ __forceinline__ void store4_streaming(uint32_t* dst, uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
   *reinterpret_cast<uint4*>(dst) = make_uint4(x, y, z, w);
 }
@@ -350,6 +358,34 @@ __device__ __forceinline__ uint32_t window_bits(const LetterWin<M>& win, int off
   }
 }
 
+// The window of the reverse-complement strand: letter o of the result is the complement of letter M-1-o.
+// The reference flips the FILTER for that strand (rc(W)[k,a,j] = W[k,3-a,M-1-j], convRBM.py:241); flipping the
+// data instead gives the same activation -- sum_j W[k, 3 - l(s+j), M-1-j] = sum_j' W[k, rc_window[j'], j'] -- as
+// the FORWARD gather of the one table Tf (bias and pad columns of group 0 included exactly once, as they
+// should be: both strands share the bias, :242).  No second gather table exists anywhere.
+__device__ __forceinline__ uint32_t revcomp_word(uint32_t x) {   // 16 letters: order reversed, each complemented
+  x = bitrev32(x);                                                // reverses the two bits inside every letter as well ...
+  x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);        // ... swap them back
+  return ~x;
+}
+
+template <int M>
+__device__ __forceinline__ LetterWin<M> revcomp_window(const LetterWin<M>& w) {
+  LetterWin<M> out;
+  out.hi = 0ull;
+  // reversing a 64-bit word of 32 letters: both halves reversed, then swapped
+  const uint64_t rlo = ((uint64_t)revcomp_word((uint32_t)w.lo) << 32) | revcomp_word((uint32_t)(w.lo >> 32));
+  if constexpr (M <= 32) {
+    out.lo = M < 32 ? rlo >> (64 - 2 * M) : rlo;        // the M letters sit at the top (the complemented padding below them leaves)
+  } else {
+    const uint64_t rhi = ((uint64_t)revcomp_word((uint32_t)w.hi) << 32) | revcomp_word((uint32_t)(w.hi >> 32));
+    constexpr int sh = 128 - 2 * M;                     // the 128-bit value rlo:rhi (rlo on top), shifted down
+    out.lo = sh > 0 ? (rhi >> sh) | (rlo << (64 - sh)) : rhi;
+    out.hi = sh > 0 ? rlo >> sh : rlo;
+  }
+  return out;
+}
+
 // z[k] (+)= sum over letter groups of T[g][tuple][k]  (z = -log2(e) * activation).  The sums are kept
 // as pairs of floats: one v_pk_add_f32 per two motifs (the compiler leaves scalar adds otherwise).
 template <class C, bool ACCUMULATE = false>
@@ -527,17 +563,15 @@ __device__ void build_tables_range(const TablesArgs& a, int first, int stride) {
   constexpr int K = C::K, M = C::M;
   for (int idx = first; idx < C::TABLES_ALL; idx += stride) {
     float val = 0.f;
-    const bool fwd = idx < C::TAB, rcg = idx >= C::OFF_TR && idx < C::OFF_TR + C::TAB;
-    if (fwd || rcg) {                                        // gather tables
-      const bool rc = rcg;
-      const int t0 = rc ? idx - C::OFF_TR : idx;
+    if (idx < C::TAB) {                                      // gather table
+      const int t0 = idx;
       const int k = t0 % C::KP, r = (t0 / C::KP) % C::ROWS, g = t0 / (C::KP * C::ROWS);
       if (k < K) {
         for (int t = 0; t < C::G; ++t) {
           const int j = g * C::G + t;
           if (j < M) {
             const int al = (r >> (2 * t)) & 3;
-            val += rc ? a.W[(k * 4 + (3 - al)) * M + (M - 1 - j)] : a.W[(k * 4 + al) * M + j];
+            val += a.W[(k * 4 + al) * M + j];
           }
         }
         if (g == 0) val += a.b[k];
@@ -598,9 +632,7 @@ __device__ void hgv_body(const HgvArgs& a) {
   constexpr int KP = C::KP, K = C::K, M = C::M;
   HIP_DYNAMIC_SHARED(float, smem);
   float* T0 = smem;
-  float* T1 = smem + C::TAB;
-  copy_tables<C::TAB>(T0, a.tables + (a.mode == 1 ? C::OFF_TR : C::OFF_TF));
-  if (a.mode == 2) copy_tables<C::TAB>(T1, a.tables + C::OFF_TR);
+  copy_tables<C::TAB>(T0, a.tables + C::OFF_TF);
   __syncthreads();
   const bool want_sample = (a.sample != nullptr) || (a.ones != nullptr);
   const uint32_t strand = a.mode == 1 ? 1u : 0u;
@@ -617,8 +649,8 @@ __device__ void hgv_body(const HgvArgs& a) {
       const uint32_t* lrow = a.letters + (size_t)nn * a.LW;
       auto zfun = [&](int pos, float (&z)[KP]) {
         const LetterWin<M> w = letter_window<M>(lrow, pos);
-        conv_gather<C>(T0, w, z);
-        if (a.mode == 2) conv_gather<C, true>(T1, w, z);
+        conv_gather<C>(T0, a.mode == 1 ? revcomp_window<M>(w) : w, z);
+        if (a.mode == 2) conv_gather<C, true>(T0, revcomp_window<M>(w), z);
       };
       float x[KP];
       zfun(s, x);
@@ -950,10 +982,8 @@ __device__ void stats_mfma_body(const StatsMfmaArgs& a, int bid = -1) {   // bid
   uint32_t* gw = reinterpret_cast<uint32_t*>(slice + sg.off_gw);
   float* Pt = slice + sg.off_pt;
   float* Tf = smem + a.off_tab;
-  float* Tr = Tf + C::TAB;
   if (!(a.debug & 16)) {
     copy_tables<C::TAB>(Tf, a.tables + C::OFF_TF);
-    if (C::DS) copy_tables<C::TAB>(Tr, a.tables + C::OFF_TR);
     stats_build_lut<BYTE_LUT>(lut);
     for (int i = lane; i < R::ROWS * STATS_RS; i += 64) Pt[i] = 0.f;   // the zero row (and the pad columns) stay zero
   }
@@ -1020,7 +1050,10 @@ __device__ void stats_mfma_body(const StatsMfmaArgs& a, int bid = -1) {   // bid
           float p[NV], cb[NV], S[NV];
 #pragma unroll
           for (int strand = 0; strand <= C::DS; ++strand) {
-            auto zfun = [&](int pos, float (&z)[NV]) { conv_gather_quads<C, R::NQW>(strand ? Tr : Tf, letter_window<M>(lrow, pos), 4 * nt0, z); };
+            auto zfun = [&](int pos, float (&z)[NV]) {
+              const LetterWin<M> w = letter_window<M>(lrow, pos);
+              conv_gather_quads<C, R::NQW>(Tf, strand ? revcomp_window<M>(w) : w, 4 * nt0, z);
+            };
             pooled_probs<C::POOL, NV>(zfun, s, p, cb, S);
 #pragma unroll
             for (int kl = 0; kl < KW; ++kl)
@@ -1047,7 +1080,7 @@ __device__ void stats_mfma_body(const StatsMfmaArgs& a, int bid = -1) {   // bid
             if (SP) col[(size_t)((1 + C::DS) * KW + kl) * STATS_RS] = fmaf(-ps * STATS_PSCALE_INV, ps, ps);   // 2^14 * P(1-P)
           }
         if (C::DS) {
-          conv_gather_quads<C, R::NQW>(Tr, wl, 4 * nt0, z);
+          conv_gather_quads<C, R::NQW>(Tf, revcomp_window<M>(wl), 4 * nt0, z);
 #pragma unroll
           for (int kl = 0; kl < KW; ++kl)
             if (16 * nt0 + kl < K)
@@ -1152,7 +1185,6 @@ __device__ void gibbs_body(const GibbsArgs& a, int bid = -1) {   // bid: block o
   constexpr int LTAB = SPARSE ? C::SP_TABLES : C::TABLES;
   HIP_DYNAMIC_SHARED(float, smem);
   const float* Tf = smem;
-  const float* Tr = smem + C::TAB;
   const float* cv = smem + (SPARSE ? C::SP_C : C::OFF_C);
   uint32_t* hm = reinterpret_cast<uint32_t*>(smem + LTAB);
   uint32_t* hmp = hm + (size_t)a.S * a.Lrow * NW;
@@ -1171,7 +1203,7 @@ __device__ void gibbs_body(const GibbsArgs& a, int bid = -1) {   // bid: block o
   bool tables_done = (a.debug & 1) != 0;
   auto copy_all_tables = [&]() {
     if (SPARSE) {
-      copy_tables<C::TAB * (1 + C::DS)>(smem, a.tables);
+      copy_tables<C::TAB>(smem, a.tables);
       copy_tables<C::WS * (1 + C::DS) + 4>(smem + C::SP_WS, a.tables + C::OFF_WS);
     } else {
       copy_tables<C::TABLES>(smem, a.tables);
@@ -1298,8 +1330,9 @@ __device__ void gibbs_body(const GibbsArgs& a, int bid = -1) {   // bid: block o
       const uint32_t nl = fastdiv_tile(it, a.divHB);
       const int s = (int)(it - nl * (uint32_t)a.nhb);
       const uint32_t gn = a.rng.seq_offset + (uint32_t)(n0 + nl);
-      const LetterWin<M> win = letter_window<M>(let + nl * (uint32_t)a.LWs, s);
-      const float* T = (strand ? Tr : Tf) + k;
+      LetterWin<M> win = letter_window<M>(let + nl * (uint32_t)a.LWs, s);
+      if (strand) win = revcomp_window<M>(win);
+      const float* T = Tf + k;
       float z = 0.f;
 #pragma unroll
       for (int g = 0; g < C::NG; ++g) {
@@ -1488,7 +1521,7 @@ __device__ void gibbs_body(const GibbsArgs& a, int bid = -1) {   // bid: block o
 #pragma unroll
               for (int strand = 0; strand <= C::DS; ++strand) {
                 float x[KP], p[KP];
-                conv_gather<C>(strand ? Tr : Tf, win, x);
+                conv_gather<C>(Tf, strand ? revcomp_window<M>(win) : win, x);
                 uint32_t mask[NW];
                 uint32_t pend[C::NGRP];
                 sample_hidden<C, 2, DEFER>(x, gn, (uint32_t)s, KIND_CHAIN_H, (uint32_t)strand, a.rng,
@@ -1533,13 +1566,16 @@ __device__ void gibbs_body(const GibbsArgs& a, int bid = -1) {   // bid: block o
           float x[KP], p[KP];
           uint32_t mask[NW], pend[C::NGRP];
           if constexpr (C::POOL > 1) {
-            auto zfun = [&](int pos, float (&z)[KP]) { conv_gather<C>(strand ? Tr : Tf, letter_window<M>(lrow, pos), z); };
+            auto zfun = [&](int pos, float (&z)[KP]) {
+              const LetterWin<M> w = letter_window<M>(lrow, pos);
+              conv_gather<C>(Tf, strand ? revcomp_window<M>(w) : w, z);
+            };
             float cb[KP], S[KP], u[KP];
             pooled_probs<C::POOL, KP>(zfun, s, p, cb, S);
             hidden_uniforms24<C>(gn, (uint32_t)(s - s % C::POOL), KIND_CHAIN_H, (uint32_t)strand, a.rng, a.rng.step + (uint32_t)st, u);
             pooled_sample<C>(p, cb, u, mask);
           } else {
-          conv_gather<C>(strand ? Tr : Tf, win, x);
+          conv_gather<C>(Tf, strand ? revcomp_window<M>(win) : win, x);
           sample_hidden<C, 0, DEFER>(x, gn, (uint32_t)s, KIND_CHAIN_H, (uint32_t)strand, a.rng,
                                      a.rng.step + (uint32_t)st, mask, p, pend);
           }
@@ -1652,9 +1688,7 @@ __device__ void free_energy_body(const FeArgs& a) {
   constexpr int KP = C::KP, K = C::K, M = C::M;
   HIP_DYNAMIC_SHARED(float, smem);
   float* Tf = smem;
-  float* Tr = Tf + C::TAB;
   copy_tables<C::TAB>(Tf, a.tables + C::OFF_TF);
-  if (C::DS) copy_tables<C::TAB>(Tr, a.tables + C::OFF_TR);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const float* cg = a.tables + C::OFF_C;
@@ -1669,7 +1703,10 @@ __device__ void free_energy_body(const FeArgs& a) {
       for (int g0 = lane * C::POOL; g0 < a.Lh; g0 += 64 * C::POOL)
 #pragma unroll
         for (int strand = 0; strand <= C::DS; ++strand) {
-          auto zfun = [&](int pos, float (&z)[KP]) { conv_gather<C>(strand ? Tr : Tf, letter_window<M>(row, pos), z); };
+          auto zfun = [&](int pos, float (&z)[KP]) {
+            const LetterWin<M> w = letter_window<M>(row, pos);
+            conv_gather<C>(Tf, strand ? revcomp_window<M>(w) : w, z);
+          };
           pooled_softplus<C::POOL, KP>(zfun, g0, acc, K);
         }
     } else
@@ -1680,7 +1717,7 @@ __device__ void free_energy_body(const FeArgs& a) {
 #pragma unroll
       for (int q = 0; q < K; ++q) acc[q] += softplus_of_z(x[q]);
       if (C::DS) {
-        conv_gather<C>(Tr, win, x);
+        conv_gather<C>(Tf, revcomp_window<M>(win), x);
 #pragma unroll
         for (int q = 0; q < K; ++q) acc[q] += softplus_of_z(x[q]);
       }
@@ -1728,10 +1765,8 @@ __device__ void hit_summary_body(const HitArgs& a) {
   constexpr bool BOTH = !C::DS;   // single-stranded models report sigma(x + x'), convRBM.py:511-514
   HIP_DYNAMIC_SHARED(float, smem);
   float* Tf = smem;
-  float* Tr = Tf + C::TAB;
-  float* acc = Tf + (BOTH ? 2 : 1) * C::TAB;   // [PC][K], block total of the waves' register sums
+  float* acc = Tf + C::TAB;                    // [PC][K], block total of the waves' register sums
   copy_tables<C::TAB>(Tf, a.tables + C::OFF_TF);
-  if (BOTH) copy_tables<C::TAB>(Tr, a.tables + C::OFF_TR);
   const int s0 = blockIdx.y * PC;
   if (a.pos)
     for (int i = threadIdx.x; i < PC * K; i += blockDim.x) acc[i] = 0.f;
@@ -1754,7 +1789,7 @@ __device__ void hit_summary_body(const HitArgs& a) {
         auto zfun = [&](int pos, float (&zz)[KP]) {
           const LetterWin<M> w = letter_window<M>(row, pos);
           conv_gather<C>(Tf, w, zz);
-          if (BOTH) conv_gather<C, true>(Tr, w, zz);
+          if (BOTH) conv_gather<C, true>(Tf, revcomp_window<M>(w), zz);
         };
         float z[KP], pp[KP];
         if constexpr (C::POOL > 1) {

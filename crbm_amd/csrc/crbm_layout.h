@@ -76,13 +76,12 @@ struct Cfg {
   static constexpr int WS = WSROWS * K * 4;               // floats per sparse table
   static constexpr int NGRP = cdiv(K, 10);                // sampler groups of 10 hidden units
   // Precomputed tables buffer (floats), global memory:
-  //   [Tf][Tr*][Tv][Tvr*][c]   TABLES floats = LDS image of the dense Gibbs variant
-  //   [Ws][Wsr*][c]            with [Tf][Tr*] the LDS image of the sparse variant (SP_TABLES floats)
-  //   [Tr]                     single-stranded models only: Tr is still needed for flip=True
-  //                            calls and for motifHitProbs (convRBM.py:511-514), global only
-  // (* = doublestranded only)
+  //   [Tf][Tv][Tvr*][c]        TABLES floats = LDS image of the dense Gibbs variant
+  //   [Ws][Wsr*][c]            with [Tf] the LDS image of the sparse variant (SP_TABLES floats)
+  // (* = doublestranded only.  There is ONE gather table: the reverse-complement strand gathers from it
+  //  with the reverse-complemented letter window, crbm_kernels.h revcomp_window)
   static constexpr int OFF_TF = 0;
-  static constexpr int OFF_TV = TAB * (1 + DS);
+  static constexpr int OFF_TV = TAB;
   static constexpr int OFF_TVR = OFF_TV + TV;
   static constexpr int OFF_C = OFF_TV + TV * (1 + DS);
   static constexpr int TABLES = OFF_C + 4;                // multiple of 4 floats
@@ -91,7 +90,7 @@ struct Cfg {
   static constexpr int OFF_C2 = OFF_WS + WS * (1 + DS);
   static constexpr int END2 = OFF_C2 + 4;
   // sparse variant, offsets inside LDS
-  static constexpr int SP_WS = TAB * (1 + DS);
+  static constexpr int SP_WS = TAB;
   static constexpr int SP_WSR = SP_WS + WS;
   static constexpr int SP_C = SP_WS + WS * (1 + DS);
   static constexpr int SP_TABLES = SP_C + 4;
@@ -111,8 +110,7 @@ struct Cfg {
   // a position fit one wave's accumulator set of at most 8 tiles (32 registers; measured: with 16 tiles,
   // config #5, the fused kernel drops to one wave per SIMD and loses to the separate launch)
   static constexpr bool FUSE_STATS = 4 * JT * (1 + DS) * NT <= 8 && POOL == 1;
-  static constexpr int OFF_TR = DS ? TAB : END2;
-  static constexpr int TABLES_ALL = DS ? END2 : END2 + TAB;
+  static constexpr int TABLES_ALL = END2;
   // hit-summary kernel: a lane keeps the position sums of HIT_NI positions in registers
   static constexpr int HIT_NI = (48 / KP) < 1 ? 1 : ((48 / KP) > 4 ? 4 : (48 / KP));
 };
@@ -121,7 +119,7 @@ struct Cfg {
 struct ModelShape {
   int K, M, DS, G, NT, JT, POOL, NPW;
   int NQ, KP, NW, NG, ROWS, TAB, NCH, DENSE, TV, WS, NGRP;
-  int OFF_TF, OFF_TR, OFF_TV, OFF_TVR, OFF_C, TABLES, OFF_WS, END2, SP_TABLES, TABLES_ALL;
+  int OFF_TF, OFF_TV, OFF_TVR, OFF_C, TABLES, OFF_WS, END2, SP_TABLES, TABLES_ALL;
   int HIT_NI, FUSE_STATS;
 };
 inline ModelShape model_shape(int K, int M, int DS, int G, int POOL = 1) {
@@ -136,21 +134,21 @@ inline ModelShape model_shape(int K, int M, int DS, int G, int POOL = 1) {
   s.TV = s.DENSE ? M * s.NCH * 32 * 4 : 0;
   s.WS = (M + 7) * K * 4;
   s.NGRP = cdiv(K, 10);
-  s.OFF_TF = 0; s.OFF_TV = s.TAB * (1 + DS); s.OFF_TVR = s.OFF_TV + s.TV;
+  s.OFF_TF = 0; s.OFF_TV = s.TAB; s.OFF_TVR = s.OFF_TV + s.TV;
   s.OFF_C = s.OFF_TV + s.TV * (1 + DS); s.TABLES = s.OFF_C + 4;
   s.OFF_WS = s.TABLES; s.END2 = s.OFF_WS + s.WS * (1 + DS) + 4;
-  s.SP_TABLES = s.TAB * (1 + DS) + s.WS * (1 + DS) + 4;
-  s.OFF_TR = DS ? s.TAB : s.END2; s.TABLES_ALL = DS ? s.END2 : s.END2 + s.TAB;
+  s.SP_TABLES = s.TAB + s.WS * (1 + DS) + 4;
+  s.TABLES_ALL = s.END2;
   s.HIT_NI = (48 / s.KP) < 1 ? 1 : ((48 / s.KP) > 4 ? 4 : (48 / s.KP));
   return s;
 }
 
-// Letters per gather-table group: the largest G whose table(s) stay small
+// Letters per gather-table group: the largest G whose table stays small
 // enough (budget) to leave the CU several resident blocks; failing that G = 2
-// if it fits twice the budget, else G = 1.
-inline int choose_group(int K, int M, int ds, int budget_bytes) {
+// if it fits twice the budget, else G = 1.  (One table serves both strands.)
+inline int choose_group(int K, int M, int /*ds*/, int budget_bytes) {
   const int KP = 4 * cdiv(K, 4);
-  auto bytes = [&](int G) { return (1 + ds) * cdiv(M, G) * cpow4(G) * KP * 4; };
+  auto bytes = [&](int G) { return cdiv(M, G) * cpow4(G) * KP * 4; };
   for (int G = 4; G >= 2; --G)
     if (bytes(G) <= budget_bytes) return G;
   return bytes(2) <= 2 * budget_bytes ? 2 : 1;

@@ -124,7 +124,7 @@ int emu_hgv(int id, const float* tables, const uint32_t* letters, int n, int L, 
   a.rng = make_rng(seed, step, off); a.kind = kind;
   CFG_DISPATCH(id, (a.Lh = L - C::M + 1, a.divLh = make_fastdiv((uint32_t)a.Lh),
                     emu::launch([&] { hgv_body<C>(a); }, dim3(grid), dim3(threads),
-                                (size_t)(mode == 2 ? 2 : 1) * C::TAB * 4)));
+                                (size_t)C::TAB * 4)));
   return 0;
 }
 
@@ -213,7 +213,7 @@ int emu_stats_mfma(int id, const float* tables, const uint32_t* letters, int n, 
     const ModelShape ms = shape_of<C>();
     const int Lh = L - C::M + 1;
     a.Lh = Lh;
-    const StatsMfmaLayout st = stats_mfma_layout(ms, want_sparsity, Lh, threads, (1 + C::DS) * C::TAB * 4);
+    const StatsMfmaLayout st = stats_mfma_layout(ms, want_sparsity, Lh, threads, C::TAB * 4);
     if ((st.threads / 64) % st.NR != 0) return -3;
     const long ngroups = (long)n * st.GPC;
     const long nunits = (ngroups + 1) / 2;
@@ -224,7 +224,7 @@ int emu_stats_mfma(int id, const float* tables, const uint32_t* letters, int n, 
     a.off_tab = st.region_floats;
     a.debug = 0;
     a.nblocks = 0;
-    const size_t lds = std::max((size_t)st.region_floats * 4 + (size_t)(1 + C::DS) * C::TAB * 4, (size_t)st.combine_bytes);
+    const size_t lds = std::max((size_t)st.region_floats * 4 + (size_t)C::TAB * 4, (size_t)st.combine_bytes);
     a.sg = geom_of(st, partials, ngroups, lds);
     if (want_sparsity) emu::launch([&] { stats_mfma_body<C, true>(a); }, dim3(gx), dim3(st.threads), lds);
     else emu::launch([&] { stats_mfma_body<C, false>(a); }, dim3(gx), dim3(st.threads), lds);
@@ -277,7 +277,7 @@ static int run_train_local(GibbsArgs g, int Lf, int S, int ggrid, int dgrid, int
     g.divRow = make_fastdiv((uint32_t)(gl.Lrow * ms.NW)); g.divLfw = make_fastdiv((uint32_t)(Lf * ms.NW));
     if (!C::DS) g.hmp = nullptr;
     const StatsMfmaLayout sm = stats_mfma_layout(ms, 0, Lf, threads, 0, false);
-    const int tabs = (1 + C::DS) * C::TAB * 4, Lh = L - C::M + 1;
+    const int tabs = C::TAB * 4, Lh = L - C::M + 1;
     const StatsMfmaLayout sd = stats_mfma_layout(ms, 1, Lh, threads, tabs, false);
     const long ngroups = (long)n * sd.GPC;
     const int wpr = (sd.threads / 64) / sd.NR;
@@ -373,7 +373,7 @@ int emu_free_energy(int id, const float* tables, const uint32_t* letters, int n,
   a.fe = fe; a.fem = fem;
   CFG_DISPATCH(id, (a.Lh = L - C::M + 1,
                     emu::launch([&] { free_energy_body<C>(a); }, dim3(grid), dim3(threads),
-                                (size_t)(1 + C::DS) * C::TAB * 4)));
+                                (size_t)C::TAB * 4)));
   return 0;
 }
 
@@ -384,7 +384,7 @@ int emu_hit_summary(int id, const float* tables, const uint32_t* letters, int n,
   a.hmax = hmax; a.hsum = hsum; a.pos = pos; a.inv_Lh = 1.0f;   // the harness divides by Lh itself
   CFG_DISPATCH(id, (a.Lh = L - C::M + 1,
                     emu::launch([&] { hit_summary_body<C>(a); }, dim3(grid, (a.Lh + 64 * C::HIT_NI - 1) / (64 * C::HIT_NI)),
-                                dim3(threads), (size_t)(C::DS ? 1 : 2) * C::TAB * 4 + (size_t)64 * C::HIT_NI * C::K * 4)));
+                                dim3(threads), (size_t)C::TAB * 4 + (size_t)64 * C::HIT_NI * C::K * 4)));
   return 0;
 }
 

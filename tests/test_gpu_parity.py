@@ -830,7 +830,7 @@ def test_inference_streams_in_slabs(monkeypatch):
                                         (64, 32, True, 45, 3), (33, 17, False, 300, 5), (16, 16, True, 64, 6),
                                         # beyond 64 motifs (masks of 3..8 words) and beyond 32-letter motifs (two-word
                                         # letter windows): the reference takes any positive K, M (convRBM.py:72-108)
-                                        (100, 15, False, 120, 4), (20, 40, True, 150, 4), (70, 33, False, 90, 3),
+                                        (100, 15, False, 120, 4), (20, 40, True, 150, 4), (70, 33, True, 90, 3),
                                         (130, 7, True, 60, 3), (192, 4, False, 40, 2), (4, 64, True, 100, 3)])
 def test_edge_shapes(K, M, ds, L, n):
     """Smallest and largest supported models, L == M (a single hidden position),
@@ -912,7 +912,7 @@ def test_pooling(K, M, ds, pool, capsys):
 def test_models_beyond_the_lds_are_refused_with_a_reason():
     """Within K <= 256, M <= 64 the bound is the LDS: tables of both strands plus one chain must fit 160 KB."""
     from crbm_amd import CRBM
-    m = CRBM(70, 33, doublestranded=True)              # 76 KB of gather tables + 90 KB of top-down tables
+    m = CRBM(120, 40, doublestranded=True)             # 77 KB of gather table + 180 KB of top-down tables
     with pytest.raises(Exception, match="too large for the LDS"):
         m.gibbsSteps(1)
     m = CRBM(256, 4, doublestranded=False, batchsize=2, fantasy_hidden_len=20)
