@@ -474,11 +474,12 @@ def main():
                 return control.allreduce_max([dt, tms.value / 1e3])
 
             local_dev = rccl_init_s = allreduce_us = None
-            if rccl:
-                # the same steps first WITHOUT the communicator (every rank for itself: no collective, replicas drift
-                # apart, the broadcast below makes them one model again): the difference to the steps with it is
-                # what the all-reduce adds to the critical path of a step
+            if world > 1:
+                # the same steps first WITHOUT any all-reduce (every rank for itself; the replicas drift apart and are
+                # made one model again below): the difference to the steps with it is what the all-reduce adds to the
+                # critical path of a step
                 _, local_dev = timed_steps()
+            if rccl:
                 # the 128-byte RCCL id travels over the control plane
                 t2 = time.perf_counter()
                 uid = cdist.exchange_unique_id(rank, world, control=control)
@@ -486,12 +487,13 @@ def main():
                 model._call("crbm_comm_init", buf, world, rank)
                 model._call("crbm_comm_broadcast_state", 0)
                 rccl_init_s = control.allreduce_max([time.perf_counter() - t2])[0]
-            twall, tdev = timed_steps()
-            train = {"train_steps_per_s": tsteps / tdev, "global_batch": n * world, "cd_k": k,
-                     "all_reduce": "rccl" if rccl else "none", "ms_per_train_step": 1e3 * tdev / tsteps,
-                     "wall_ms_per_train_step": 1e3 * twall / tsteps, "steps": tsteps,
-                     "statistics_dtype": "P enters the MFMA contraction as two f16 halves (22 significant bits; fp32 has 24), "
-                                         "accumulation in fp32; the chain itself computes in f32"}
+            stats_note = ("P enters the MFMA contraction as two f16 halves (22 significant bits; fp32 has 24), "
+                          "accumulation in fp32; the chain itself computes in f32")
+            if world == 1 or rccl:
+                twall, tdev = timed_steps()
+                train = {"train_steps_per_s": tsteps / tdev, "global_batch": n * world, "cd_k": k,
+                         "all_reduce": "rccl" if rccl else "none", "ms_per_train_step": 1e3 * tdev / tsteps,
+                         "wall_ms_per_train_step": 1e3 * twall / tsteps, "steps": tsteps, "statistics_dtype": stats_note}
             if rccl:
                 ams = ctypes.c_float()
                 model._call("crbm_time_allreduce", 10, ctypes.byref(ams))
@@ -508,6 +510,41 @@ def main():
                 sums = control.gather(cdist.replica_checksum(model))
                 train["replicas_identical"] = len(set(sums)) == 1
                 failed = failed or not train["replicas_identical"]
+                model._call("crbm_comm_destroy")
+            if world > 1 and os.environ.get("CRBM_BENCH_IPC", "1") != "0":
+                # the all-reduce through mapped buffers (crbm_ipc_*): the ranks map each other's sums buffers and the update
+                # launch adds them -- no collective launch.  Works with all ranks on one GPU too (the rehearsal), where RCCL
+                # refuses; on a real node it is timed beside RCCL so that the two can be compared.
+                ipc = {}
+                try:
+                    # identical replicas again: the filters every rank was built with, velocities at zero
+                    model.motifs.set_value(np.random.default_rng(42).standard_normal((cfg["K"], 1, 4, cfg["M"])).astype(np.float32))
+                    model.bias.set_value(model._host["bias"])
+                    model.c.set_value(np.zeros((1, 4), dtype=np.float32))
+                    model.set_velocities(np.zeros((cfg["K"], 1, 4, cfg["M"]), np.float32), np.zeros((1, cfg["K"]), np.float32),
+                                         np.zeros((1, 4), np.float32))
+                    t3 = time.perf_counter()
+                    cdist.attach_ipc(model, control)
+                    ipc["init_s"] = control.allreduce_max([time.perf_counter() - t3])[0]
+                    iwall, idev = timed_steps()
+                    ipc.update({"ms_per_train_step": 1e3 * idev / tsteps, "wall_ms_per_train_step": 1e3 * iwall / tsteps,
+                                "all_reduce_us": 1e6 * (idev - local_dev) / tsteps,
+                                "timed_out": bool(max(control.gather(int(cdist.ipc_timed_out(model)))))})
+                    sums = control.gather(cdist.replica_checksum(model))
+                    ipc["replicas_identical"] = len(set(sums)) == 1
+                    failed = failed or ipc["timed_out"] or not ipc["replicas_identical"]
+                except Exception as e:
+                    ipc["error"] = str(e)[:300]
+                    failed = True
+                if train is None:               # all ranks on one GPU: the IPC form is the only all-reduce that can run
+                    train = {"train_steps_per_s": (tsteps / idev) if "ms_per_train_step" in ipc else None, "global_batch": n * world,
+                             "cd_k": k, "all_reduce": "ipc (mapped buffers, no collective launch)",
+                             "ms_per_train_step": ipc.get("ms_per_train_step"), "wall_ms_per_train_step": ipc.get("wall_ms_per_train_step"),
+                             "ms_per_train_step_without_all_reduce": 1e3 * local_dev / tsteps, "steps": tsteps,
+                             "statistics_dtype": stats_note}
+                train["ipc_all_reduce"] = ipc
+            if train is None:
+                train = {"error": "no all-reduce available (CRBM_BENCH_SHARE_GPU with CRBM_BENCH_IPC=0)", "global_batch": n * world}
         except Exception as e:                      # report, never hide: the headline is the Gibbs metric
             train = {"error": str(e)[:300]}
             failed = True

@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libcrbm_hip.so")
 
 UNIQUE_ID_BYTES = 128
+IPC_HANDLE_BYTES = 64
 ABI_VERSION = 2          # CRBM_AMD_ABI_VERSION of include/crbm_amd.h
 
 CRBM_OK = 0
@@ -102,6 +103,10 @@ SIGNATURES = {
     "crbm_comm_init": (_I32, [_H, _U8P, _I32, _I32]),
     "crbm_comm_destroy": (_I32, [_H]),
     "crbm_comm_broadcast_state": (_I32, [_H, _I32]),
+    "crbm_ipc_export": (_I32, [_H, _U8P]),
+    "crbm_ipc_attach": (_I32, [_H, _U8P, _I32, _I32]),
+    "crbm_ipc_detach": (_I32, [_H]),
+    "crbm_ipc_status": (_I32, [_H, ctypes.POINTER(_I32)]),
     "crbm_sums_count": (_I32, [_H]),
     "crbm_train_local": (_I32, [_H, _F, _I32, _I32, _F]),
     "crbm_train_apply": (_I32, [_H, _F, _I32]),

@@ -149,6 +149,12 @@ struct crbm_handle {
   // data parallel
   ncclComm_t comm = nullptr;
   int nranks = 1, rank = 0;
+  // ... without a collective launch: every rank's sums buffer mapped into every rank (crbm_ipc_*)
+  float* ipc_buf = nullptr;            // own: [2 parities][ipc_stride floats], then 2 flag words and a status word
+  void* ipc_peer[IPC_MAX_RANKS] = {};  // all ranks' buffers as this process sees them (own included)
+  int ipc_stride = 0;                  // floats per parity (sums count rounded up to a 128-byte line)
+  bool ipc_on = false;
+  uint32_t ipc_step = 0;               // steps published so far (the flag value of the next one is ipc_step + 1)
   std::string err;
 };
 
@@ -525,9 +531,61 @@ int train_local_dev(crbm_handle* h, const uint32_t* d_letters, int n, int L) {
   return CRBM_OK;
 }
 
+// ---- IPC all-reduce (update_tables_ipc_body) -------------------------------------------------
+size_t ipc_bytes(const crbm_handle* h) { return ((size_t)2 * h->ipc_stride + 64) * sizeof(float); }
+float* ipc_sums_of(void* base, const crbm_handle* h, int parity) { return static_cast<float*>(base) + (size_t)parity * h->ipc_stride; }
+uint32_t* ipc_flag_of(void* base, const crbm_handle* h, int parity) {
+  return reinterpret_cast<uint32_t*>(static_cast<float*>(base) + (size_t)2 * h->ipc_stride) + 16 * parity;   // one flag per 64-byte line
+}
+uint32_t* ipc_status_of(void* base, const crbm_handle* h) {
+  return reinterpret_cast<uint32_t*>(static_cast<float*>(base) + (size_t)2 * h->ipc_stride) + 32;
+}
+
+int ipc_allocate(crbm_handle* h) {
+  if (h->ipc_buf) return CRBM_OK;
+  h->ipc_stride = (h->sl.count + 31) & ~31;
+  // fine-grained device memory (coherent between agents) where the runtime exports it; plain device memory otherwise --
+  // every access of a peer is a system-scope load or store either way
+  void* p = nullptr;
+  if (hipExtMallocWithFlags(&p, ipc_bytes(h), hipDeviceMallocFinegrained) != hipSuccess) {
+    (void)hipGetLastError();
+    HIPCHK(hipMalloc(&p, ipc_bytes(h)));
+  }
+  HIPCHK(hipMemset(p, 0, ipc_bytes(h)));
+  h->ipc_buf = static_cast<float*>(p);
+  return CRBM_OK;
+}
+
+// this rank's sums of the step -> its published buffer + flag; then the update that sums all ranks' buffers
+int launch_ipc_allreduce_update(crbm_handle* h, int L_data) {
+  const int parity = (int)(h->ipc_step & 1u);
+  const uint32_t value = h->ipc_step + 1u;
+  PublishArgs pa;
+  pa.src = h->d_sums; pa.dst = ipc_sums_of(h->ipc_buf, h, parity); pa.flag = ipc_flag_of(h->ipc_buf, h, parity);
+  pa.value = value; pa.count = h->sl.count;
+  hipLaunchKernelGGL(publish_sums_kernel, dim3(1), dim3(1024), 0, h->stream, pa);
+  HIPCHK(hipGetLastError());
+  UpdateIpcArgs a;
+  fill_update_args(h, L_data, a.ut);
+  for (int r = 0; r < IPC_MAX_RANKS; ++r) {
+    void* base = r < h->nranks ? h->ipc_peer[r] : h->ipc_buf;
+    a.ipc.sums[r] = ipc_sums_of(base, h, parity);
+    a.ipc.flags[r] = ipc_flag_of(base, h, parity);
+  }
+  a.ipc.status = ipc_status_of(h->ipc_buf, h);
+  a.ipc.expect = value; a.ipc.nranks = h->nranks; a.ipc.count = h->sl.count;
+  const unsigned grid = (unsigned)std::max(1, std::min((h->ms.TABLES_ALL + 4095) / 4096, 32));
+  const unsigned lds = (unsigned)((((h->sl.count + 3) & ~3) + h->KAM + h->K + 4) * 4);
+  HIPCHK(jit_launch(h->jk.update_tables_ipc, a, grid, 1, UPDATE_THREADS, lds, h->stream));
+  swap_param_sets(h);
+  h->ipc_step += 1;
+  return CRBM_OK;
+}
+
 int train_core(crbm_handle* h, const uint32_t* d_letters, int n, int L) {
   int rc = train_local_dev(h, d_letters, n, L);
   if (rc) return rc;
+  if (h->ipc_on) return launch_ipc_allreduce_update(h, L);
   if (h->comm) {
     ncclResult_t r = g_rccl.AllReduce(h->d_sums, h->d_sums, (size_t)h->sl.count, ncclFloat, ncclSum, h->comm, h->stream);
     if (r != ncclSuccess) return fail(h, CRBM_ERR_RCCL, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r));
@@ -807,6 +865,9 @@ int crbm_destroy(crbm_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->stream2) (void)hipStreamSynchronize(h->stream2);
   if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+  for (int r = 0; r < IPC_MAX_RANKS; ++r)
+    if (h->ipc_peer[r] && h->ipc_peer[r] != h->ipc_buf) (void)hipIpcCloseMemHandle(h->ipc_peer[r]);
+  if (h->ipc_buf) (void)hipFree(h->ipc_buf);
   void* ptrs[] = {h->dW2, h->db2, h->dc2, h->dvW2, h->dvb2, h->dvc2, h->dW, h->db, h->dc, h->dvW, h->dvb, h->dvc, h->d_hm, h->d_hmp, h->d_vf, h->d_flags, h->d_ones, h->d_nset, h->d_sums, h->d_tables};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -1010,7 +1071,7 @@ int crbm_train_step_resident(crbm_handle* h, int32_t start, int32_t end) {
   const int slot = h->slot;
   ARGCHK(h->dataset_n[slot] > 0, "no resident data set (call crbm_dataset_upload)");
   ARGCHK(start >= 0 && end >= start && end <= h->dataset_n[slot], "row range out of bounds");
-  ARGCHK(end > start || h->comm, "empty row range");
+  ARGCHK(end > start || h->comm || h->ipc_on, "empty row range");
   const int LW = letter_words(h->dataset_L[slot]);
   int rc = train_core(h, h->dataset[slot].p + (size_t)start * LW, end - start, h->dataset_L[slot]);
   if (rc) return rc;
@@ -1060,7 +1121,7 @@ int crbm_train_epoch_sharded(crbm_handle* h, int32_t batchsize, int32_t total_ro
   }
   ARGCHK(have == h->dataset_n[slot], "resident rows do not match this rank's share of total_rows");
   ARGCHK(have == 0 || h->dataset_L[slot] == L, "resident rows have another sequence length than L");
-  ARGCHK(have > 0 || h->comm, "no resident data set (call crbm_dataset_upload)");
+  ARGCHK(have > 0 || h->comm || h->ipc_on, "no resident data set (call crbm_dataset_upload)");
   size_t off = 0;
   for (int start = 0; start < total_rows; start += batchsize) {
     const long n = std::min(total_rows, start + batchsize) - start;
@@ -1649,6 +1710,64 @@ int crbm_comm_broadcast_state(crbm_handle* h, int32_t root) {
   }
   HIPCHK(hipStreamSynchronize(h->stream));
   h->tables_dirty = true;
+  return CRBM_OK;
+}
+
+// ---- all-reduce through mapped buffers (no collective launch) -------------------------------------
+int crbm_ipc_export(crbm_handle* h, uint8_t handle[CRBM_IPC_HANDLE_BYTES]) {
+  ENTER();
+  ARGCHK(handle, "null argument");
+  static_assert(sizeof(hipIpcMemHandle_t) == CRBM_IPC_HANDLE_BYTES, "hipIpcMemHandle_t size");
+  int rc = ipc_allocate(h);
+  if (rc) return rc;
+  hipIpcMemHandle_t mh;
+  HIPCHK(hipIpcGetMemHandle(&mh, h->ipc_buf));
+  memcpy(handle, &mh, sizeof(mh));
+  return CRBM_OK;
+}
+
+int crbm_ipc_attach(crbm_handle* h, const uint8_t* handles, int32_t nranks, int32_t rank) {
+  ENTER();
+  ARGCHK(handles && nranks >= 1 && nranks <= IPC_MAX_RANKS && rank >= 0 && rank < nranks, "bad argument (at most 8 ranks: one node)");
+  ARGCHK(!h->comm, "the handle already has an RCCL communicator");
+  int rc = ipc_allocate(h);
+  if (rc) return rc;
+  for (int r = 0; r < nranks; ++r) {
+    if (r == rank) { h->ipc_peer[r] = h->ipc_buf; continue; }
+    hipIpcMemHandle_t mh;
+    memcpy(&mh, handles + (size_t)r * CRBM_IPC_HANDLE_BYTES, sizeof(mh));
+    void* p = nullptr;
+    hipError_t e = hipIpcOpenMemHandle(&p, mh, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) return fail(h, CRBM_ERR_HIP, std::string("hipIpcOpenMemHandle (rank ") + std::to_string(r) + "): " + hipGetErrorString(e));
+    h->ipc_peer[r] = p;
+  }
+  h->nranks = nranks; h->rank = rank;
+  h->ipc_on = true;
+  h->ipc_step = 0;
+  return CRBM_OK;
+}
+
+int crbm_ipc_detach(crbm_handle* h) {
+  ENTER();
+  HIPCHK(hipStreamSynchronize(h->stream));
+  for (int r = 0; r < IPC_MAX_RANKS; ++r) {
+    if (h->ipc_peer[r] && h->ipc_peer[r] != h->ipc_buf) (void)hipIpcCloseMemHandle(h->ipc_peer[r]);
+    h->ipc_peer[r] = nullptr;
+  }
+  h->ipc_on = false;
+  h->nranks = 1; h->rank = 0;
+  return CRBM_OK;
+}
+
+int crbm_ipc_status(crbm_handle* h, int32_t* timed_out) {
+  ENTER();
+  ARGCHK(timed_out, "null argument");
+  *timed_out = 0;
+  if (!h->ipc_buf) return CRBM_OK;
+  uint32_t st = 0;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpy(&st, ipc_status_of(h->ipc_buf, h), sizeof(st), hipMemcpyDeviceToHost));
+  *timed_out = (int32_t)st;
   return CRBM_OK;
 }
 

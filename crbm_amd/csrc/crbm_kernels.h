@@ -64,6 +64,14 @@ __device__ __forceinline__ void store4_streaming(uint32_t* dst, uint32_t x, uint
 __device__ __forceinline__ void store1_streaming(uint32_t* dst, uint32_t x) { __builtin_nontemporal_store(x, dst); }
 // all vector-memory operations of this wave have completed (gfx9 encoding: vmcnt = 0, expcnt and lgkmcnt untouched)
 __device__ __forceinline__ void wait_vector_memory() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+// System-scope accesses for memory another process / another GPU reads and writes (the mapped sums buffers of the
+// IPC all-reduce): loads and stores that bypass this GPU's caches, and the fence that orders them.
+__device__ __forceinline__ float load_system(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ uint32_t load_system(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void store_system(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void store_system(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void fence_system() { __threadfence_system(); }
+__device__ __forceinline__ void short_sleep() { __builtin_amdgcn_s_sleep(8); }
 // x = hi + lo with both halves f16 (round to nearest): 22 significant bits, v_cvt_pk_f16_f32 +
 // v_cvt_f32_f16 + v_pk_add_f32 per pair
 __device__ __forceinline__ void split_f16(const float (&x)[8], HalfFrag& hi, HalfFrag& lo) {
@@ -107,6 +115,12 @@ __device__ __forceinline__ void store4_streaming(uint32_t* dst, uint32_t x, uint
 }
 __device__ __forceinline__ void store1_streaming(uint32_t* dst, uint32_t x) { *dst = x; }
 __device__ __forceinline__ void wait_vector_memory() {}
+__device__ __forceinline__ float load_system(const float* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
+__device__ __forceinline__ uint32_t load_system(const uint32_t* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
+__device__ __forceinline__ void store_system(float* p, float v) { __atomic_store_n(p, v, __ATOMIC_RELAXED); }
+__device__ __forceinline__ void store_system(uint32_t* p, uint32_t v) { __atomic_store_n(p, v, __ATOMIC_RELAXED); }
+__device__ __forceinline__ void fence_system() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+__device__ __forceinline__ void short_sleep() {}
 __device__ __forceinline__ void split_f16(const float (&x)[8], HalfFrag& hi, HalfFrag& lo) { emu::split_f16(x, hi.r, lo.r); }
 __device__ __forceinline__ floatx4 mfma_16x16x32_f16(const HalfFrag& a, const HalfFrag& b, floatx4 c) {
   float d[4] = {c[0], c[1], c[2], c[3]};
@@ -1960,6 +1974,67 @@ __device__ void update_tables_body(const UpdateTablesArgs& a) {
   build_tables_body<C>(t);
 }
 
+// ---------------------------------------------------------------------------
+// The all-reduce of a data-parallel training step WITHOUT a collective launch (an alternative to
+// ncclAllReduce for the few-KB sums buffer, whose cost is pure latency).  Every rank publishes its packed
+// sums in a buffer that all ranks of the node have mapped (hipIpcOpenMemHandle; double-buffered by step
+// parity) and then raises that buffer's flag to the step number (publish_sums_kernel).  The update launch of
+// every rank waits for the flags of all ranks, adds the R copies IN RANK ORDER (so every rank forms the
+// bit-identical sum, and with it the bit-identical update) and goes on as update_tables_body does: no
+// collective launch, no extra kernel boundary on the critical path.
+// Buffer reuse: a rank overwrites parity p only after its own update of the step before, which waited for
+// every peer's flag of that step -- raised after the peer's update two steps back had read parity p.
+// The wait is bounded (a peer that died must not hang this GPU): on a time-out the kernel raises
+// `status[0]`, later launches do not wait at all, and the host reports it (crbm_ipc_status).
+// ---------------------------------------------------------------------------
+constexpr int IPC_MAX_RANKS = 8;
+struct IpcArgs {
+  const float* sums[IPC_MAX_RANKS];       // every rank's published sums of this step's parity (this rank's own included)
+  const uint32_t* flags[IPC_MAX_RANKS];   // ... and their flag words: == expect once the sums are complete
+  uint32_t* status;                       // [0] != 0: a wait timed out (sticky)
+  uint32_t expect;
+  int32_t nranks, count;
+};
+struct UpdateIpcArgs {
+  UpdateTablesArgs ut;
+  IpcArgs ipc;
+};
+
+template <class C>
+__device__ void update_tables_ipc_body(const UpdateIpcArgs& a) {
+  HIP_DYNAMIC_SHARED(float, smem);
+  constexpr int KAM = C::K * 4 * C::M;
+  const IpcArgs& ipc = a.ipc;
+  float* ssum = smem;                                // [count], then the new W, b, c
+  float* nw = smem + ((ipc.count + 3) & ~3);
+  if ((int)threadIdx.x < ipc.nranks && load_system(ipc.status) == 0u) {
+    const uint32_t* f = ipc.flags[threadIdx.x];
+    int spins = 0;
+    while ((int32_t)(load_system(f) - ipc.expect) < 0) {       // flags only grow (step numbers)
+      if (++spins > (1 << 18)) { store_system(ipc.status, 1u); break; }
+      short_sleep();
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < ipc.count; i += blockDim.x) {
+    float v[IPC_MAX_RANKS];
+#pragma unroll
+    for (int r = 0; r < IPC_MAX_RANKS; ++r) v[r] = r < ipc.nranks ? load_system(ipc.sums[r] + i) : 0.f;   // all in flight
+    float t = v[0];
+#pragma unroll
+    for (int r = 1; r < IPC_MAX_RANKS; ++r) t += v[r];          // rank order; the zeros of absent ranks change nothing
+    ssum[i] = t;
+  }
+  __syncthreads();
+  UpdateArgs u = a.ut.u;
+  u.sums = ssum;
+  apply_update_body<cdiv(KAM, UPDATE_THREADS) <= 8 ? cdiv(KAM, UPDATE_THREADS) : 0>(u, nw, blockIdx.x == 0);
+  __syncthreads();
+  TablesArgs t;
+  t.W = nw; t.b = nw + KAM; t.c = nw + KAM + C::K; t.out = a.ut.tables;
+  build_tables_body<C>(t);
+}
+
 // sums[dst(r)] = sum over partial rows of column r in a fixed order.  Block =
 // 32 columns x (blockDim / 32) row groups: each thread adds the rows of its group (128-byte
 // segments per row), the 32 groups are combined through LDS.  The partial
@@ -2253,6 +2328,21 @@ __global__ void __launch_bounds__(1024) reduce_partials_pair_kernel(ReducePair p
 }
 
 __global__ void apply_update_kernel(UpdateArgs a) { apply_update_body<0>(a, nullptr, true); }   // one block, in place
+
+// IPC all-reduce: this rank's sums of the step -> its published buffer, then the flag (one block)
+struct PublishArgs {
+  const float* src;
+  float* dst;
+  uint32_t* flag;
+  uint32_t value;
+  int32_t count;
+};
+__global__ void __launch_bounds__(1024) publish_sums_kernel(PublishArgs a) {
+  for (int i = threadIdx.x; i < a.count; i += blockDim.x) store_system(a.dst + i, a.src[i]);
+  fence_system();                                   // this thread's stores are visible system-wide ...
+  __syncthreads();                                  // ... and so are everybody's
+  if (threadIdx.x == 0) store_system(a.flag, a.value);
+}
 #endif  // CRBM_DEFINE_MISC_KERNELS
 
 }  // namespace crbm

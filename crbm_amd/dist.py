@@ -423,11 +423,35 @@ def replica_checksum(model):
     return tot & 0xFFFFFFFFFFFFFFFF
 
 
-def attach(model, rank=None, world=None, uid=None, control=None):
+def attach_ipc(model, control):
+    """The all-reduce through mapped buffers (include/crbm_amd.h, crbm_ipc_*): every rank exports a handle of
+    its sums buffer, the control plane carries the handles to everybody, every rank maps them."""
+    h = model._h()
+    mine = (ctypes.c_uint8 * _lib.IPC_HANDLE_BYTES)()
+    model._check(model._lib.crbm_ipc_export(h, mine))
+    handles = control.gather(bytes(mine))
+    blob = b"".join(handles)
+    buf = (ctypes.c_uint8 * len(blob)).from_buffer_copy(blob)
+    model._check(model._lib.crbm_ipc_attach(h, buf, control.world, control.rank))
+    control.barrier()                    # nobody publishes before everybody has mapped
+
+
+def ipc_timed_out(model):
+    """True if a wait for a peer's sums ever ran out (crbm_ipc_status): the run is invalid from then on."""
+    flag = ctypes.c_int32()
+    model._check(model._lib.crbm_ipc_status(model._h(), ctypes.byref(flag)))
+    return flag.value != 0
+
+
+def attach(model, rank=None, world=None, uid=None, control=None, allreduce=None):
     """Make `model` (a CRBM) one rank of a data-parallel job.  Must be called
     before the model touches the GPU.  batchsize stays the GLOBAL number of
     persistent chains; each rank owns batchsize/world of them.  All ranks leave
-    with rank 0's parameters, velocities and seed."""
+    with rank 0's parameters, velocities and seed.
+
+    allreduce: "rccl" (default; CRBM_ALLREDUCE overrides) -- ncclAllReduce of the packed sums per step; or
+    "ipc" -- the ranks of ONE node map each other's sums buffers and the update launch adds them itself
+    (no collective launch; at most 8 ranks)."""
     if rank is None or world is None:
         rank, world = env_rank_world()
     if model._handle is not None:
@@ -435,17 +459,23 @@ def attach(model, rank=None, world=None, uid=None, control=None):
     model.rank, model.world_size = rank, world
     if world == 1:
         return model
+    allreduce = (allreduce or os.environ.get("CRBM_ALLREDUCE", "rccl")).lower()
+    if allreduce not in ("rccl", "ipc"):
+        raise Exception("allreduce must be 'rccl' or 'ipc', got %r" % allreduce)
     own = control is None
     cp = ControlPlane(rank, world) if own else control
     model._control = cp
     sync_replicas(model, cp)
-    if uid is None:
-        uid = exchange_unique_id(rank, world, control=cp)
-    h = model._h()
-    buf = (ctypes.c_uint8 * _lib.UNIQUE_ID_BYTES).from_buffer_copy(uid)
-    model._check(model._lib.crbm_comm_init(h, buf, world, rank))
-    # belt and braces on the device side: rank 0's W, b, c and velocities over RCCL
-    model._check(model._lib.crbm_comm_broadcast_state(h, 0))
+    if allreduce == "ipc":
+        attach_ipc(model, cp)
+    else:
+        if uid is None:
+            uid = exchange_unique_id(rank, world, control=cp)
+        h = model._h()
+        buf = (ctypes.c_uint8 * _lib.UNIQUE_ID_BYTES).from_buffer_copy(uid)
+        model._check(model._lib.crbm_comm_init(h, buf, world, rank))
+        # belt and braces on the device side: rank 0's W, b, c and velocities over RCCL
+        model._check(model._lib.crbm_comm_broadcast_state(h, 0))
     sums = cp.gather(replica_checksum(model))
     if len(set(sums)) != 1:
         raise Exception("data-parallel replicas differ after attach(): %s" % (sums,))

@@ -209,6 +209,19 @@ int crbm_comm_destroy(crbm_handle* h);
  * reference's randn initialisation, convRBM.py:127-131, differs per process).
  * No-op without a communicator. */
 int crbm_comm_broadcast_state(crbm_handle* h, int32_t root);
+/* The same all-reduce WITHOUT a collective launch, for the ranks of one node (at most 8): every rank exports a
+ * handle of its sums buffer (crbm_ipc_export, hipIpcGetMemHandle), the host ships the handles to all ranks by
+ * any channel, every rank maps them (crbm_ipc_attach, `handles` = nranks x CRBM_IPC_HANDLE_BYTES in rank
+ * order).  A training step then publishes its packed sums in the rank's buffer and raises a flag; the update
+ * launch of every rank waits for all flags and adds the copies in rank order (bit-identical on all ranks):
+ * one small launch instead of ncclAllReduce on the critical path.  Alternative to crbm_comm_init, not to be
+ * combined with it; replicas must start identical (crbm_amd.dist.attach ships rank 0's parameters first).
+ * crbm_ipc_status: *timed_out != 0 if a wait for a peer ever ran out (results are invalid from then on). */
+#define CRBM_IPC_HANDLE_BYTES 64
+int crbm_ipc_export(crbm_handle* h, uint8_t handle[CRBM_IPC_HANDLE_BYTES]);
+int crbm_ipc_attach(crbm_handle* h, const uint8_t* handles, int32_t nranks, int32_t rank);
+int crbm_ipc_detach(crbm_handle* h);
+int crbm_ipc_status(crbm_handle* h, int32_t* timed_out);
 int crbm_sums_count(const crbm_handle* h);
 /* Split form of crbm_train_step for hosts that reduce the sums themselves:
  * local phase -> sums in `sums_out` (host, crbm_sums_count floats);

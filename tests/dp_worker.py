@@ -7,6 +7,8 @@ replicas identical.
 
 mode "rccl": crbm_amd.dist.attach() + CRBM.fit() (sharded upload, RCCL all-reduce inside the library;
              needs one GPU per rank).
+mode "ipc":  crbm_amd.dist.attach(allreduce="ipc") + CRBM.fit(): the ranks map each other's sums buffers
+             (hipIpcOpenMemHandle) and the update launch adds them; all ranks may share GPU 0.
 mode "host": all ranks share GPU 0; the packed sums of crbm_train_local are summed over the control
              plane and applied with crbm_train_apply (same kernels, same sharding, no communicator).
 """
@@ -39,10 +41,12 @@ def main():
                  seed=9000 + rank,                    # ... and a different sampler seed
                  device=rank if mode == "rccl" else 0)
     D = data()
-    if mode == "rccl":
-        dist.attach(model, rank, world)
+    if mode in ("rccl", "ipc"):
+        dist.attach(model, rank, world, allreduce=mode)
         W0, seed0 = model.motifs.get_value(), model.seed
         model.fit(D)
+        if mode == "ipc":
+            assert not dist.ipc_timed_out(model), "a wait for a peer's sums timed out"
     else:
         cp = dist.ControlPlane(rank, world)
         dist.sync_replicas(model, cp)

@@ -101,6 +101,17 @@ def test_two_processes_host_reduced_equal_single_rank(tmp_path):
     _check_against_single(res, tmp_path)
 
 
+def test_two_processes_ipc_allreduce_equal_single_rank(tmp_path):
+    """The all-reduce through mapped buffers (crbm_ipc_*: hipIpcGetMemHandle / hipIpcOpenMemHandle, publish kernel,
+    update launch that waits for both flags and adds both copies in rank order) with two REAL processes --
+    both on GPU 0, which RCCL cannot do: dist.attach(allreduce="ipc") + CRBM.fit (sharded upload,
+    crbm_train_epoch_sharded, a last mini-batch of which rank 0 owns nothing) equals the one-rank run, the
+    replicas are bit-identical, the chains identical, and the checkpoint resumes on one rank."""
+    res, logs = _run_ranks("ipc", tmp_path)
+    assert "Epoch 1: FE=" in logs[0] and "Epoch" not in logs[1]        # rank 0 alone evaluates and prints
+    _check_against_single(res, tmp_path)
+
+
 def test_two_gpu_rccl_fit_equals_single_rank(tmp_path):
     from crbm_amd import _lib
     if _lib.load().crbm_device_count() < 2:
@@ -118,7 +129,7 @@ def test_bench_spawns_its_own_ranks(tmp_path):
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
     if not two:
-        env["CRBM_BENCH_SHARE_GPU"] = "1"          # plumbing rehearsal on one GPU (no communicator)
+        env["CRBM_BENCH_SHARE_GPU"] = "1"          # plumbing rehearsal on one GPU (no RCCL communicator: it refuses two ranks on one device)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "3",
                         "--no-cpu-baseline"], env=env, capture_output=True, timeout=600)
     assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
@@ -126,6 +137,10 @@ def test_bench_spawns_its_own_ranks(tmp_path):
     line = json.loads(p.stdout.decode().strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["steps"] == 20
     assert line["train"]["global_batch"] == 2 * 8192
-    assert line["train"]["all_reduce"] == ("rccl" if two else "none")
+    assert line["train"]["all_reduce"].startswith("rccl" if two else "ipc")
     if two:
         assert line["train"]["replicas_identical"] is True
+    # the all-reduce through mapped buffers runs in both cases (beside RCCL on two GPUs, alone on one)
+    ipc = line["train"]["ipc_all_reduce"]
+    assert "error" not in ipc and ipc["replicas_identical"] is True and ipc["timed_out"] is False, ipc
+    assert line["secondary_ok"] is True
