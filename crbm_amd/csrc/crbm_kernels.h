@@ -115,9 +115,9 @@ __device__ __forceinline__ void store4_streaming(uint32_t* dst, uint32_t x, uint
 }
 __device__ __forceinline__ void store1_streaming(uint32_t* dst, uint32_t x) { *dst = x; }
 __device__ __forceinline__ void wait_vector_memory() {}
-__device__ __forceinline__ float load_system(const float* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
+__device__ __forceinline__ float load_system(const float* p) { float v; __atomic_load(p, &v, __ATOMIC_RELAXED); return v; }
 __device__ __forceinline__ uint32_t load_system(const uint32_t* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
-__device__ __forceinline__ void store_system(float* p, float v) { __atomic_store_n(p, v, __ATOMIC_RELAXED); }
+__device__ __forceinline__ void store_system(float* p, float v) { __atomic_store(p, &v, __ATOMIC_RELAXED); }
 __device__ __forceinline__ void store_system(uint32_t* p, uint32_t v) { __atomic_store_n(p, v, __ATOMIC_RELAXED); }
 __device__ __forceinline__ void fence_system() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 __device__ __forceinline__ void short_sleep() {}

@@ -366,6 +366,36 @@ int emu_update_tables(int id, const float* sums, const float* W, const float* b,
   return 0;
 }
 
+// The all-reduce through mapped buffers with `nranks` emulated ranks in one process: every rank's sums are
+// published into its own buffer (publish_sums_kernel: sums, fence, flag), then ONE rank's update launch waits
+// for all flags and adds the copies in rank order (update_tables_ipc_body).  bufs: nranks x stride floats,
+// flags: nranks words, status: one word.
+int emu_ipc_update(int id, int nranks, const float* rank_sums, int count, float* bufs, int stride, uint32_t* flags,
+                   uint32_t* status, uint32_t step_value, const float* W, const float* b, const float* c, const float* vW,
+                   const float* vb, const float* vc, float* oW, float* ob, float* oc, float* ovW, float* ovb, float* ovc,
+                   int L_data, int Lf, float lr, float momentum, float rho, float lambda_rate, float* tables, int grid, int threads) {
+  for (int r = 0; r < nranks; ++r) {
+    PublishArgs pa{rank_sums + (size_t)r * count, bufs + (size_t)r * stride, flags + r, step_value, count};
+    emu::launch([&] { publish_sums_kernel(pa); }, dim3(1), dim3(64), 0);
+  }
+  CFG_DISPATCH(id, {
+    const SumsLayout sl = sums_layout(C::K, C::M);
+    if (count != sl.count || nranks > IPC_MAX_RANKS) return -2;
+    UpdateIpcArgs a;
+    a.ut.u = UpdateArgs{nullptr, W, b, c, vW, vb, vc, oW, ob, oc, ovW, ovb, ovc, C::K, C::M, C::DS, L_data, Lf,
+                        sl.data_off, sl.n_d, sl.model_off, sl.n_m, lr, momentum, rho, lambda_rate};
+    a.ut.tables = tables;
+    for (int r = 0; r < IPC_MAX_RANKS; ++r) {
+      a.ipc.sums[r] = bufs + (size_t)(r < nranks ? r : 0) * stride;
+      a.ipc.flags[r] = flags + (r < nranks ? r : 0);
+    }
+    a.ipc.status = status; a.ipc.expect = step_value; a.ipc.nranks = nranks; a.ipc.count = count;
+    emu::launch([&] { update_tables_ipc_body<C>(a); }, dim3(grid), dim3(threads),
+                (size_t)(((count + 3) & ~3) + C::K * 4 * C::M + C::K + 4) * 4);
+  });
+  return 0;
+}
+
 int emu_free_energy(int id, const float* tables, const uint32_t* letters, int n, int L, float* fe, float* fem,
                     int grid, int threads) {
   FeArgs a;

@@ -429,8 +429,9 @@ def test_two_ranks():
     D = synthetic_onehot(6, L, seed=33)
     batches = [(0, 5), (5, 6)]
 
-    def run(world):
+    def run(world, ipc=False):
         o = make_oracle(K, M, ds, seed=5, batch=B, Lf=Lf, cd_k=2, rho=0.05)
+        step_no = 0
         W, b, c = model_arrays(o)
         vW, vb, vc = np.zeros_like(W), np.zeros_like(b), np.zeros_like(c)
         fh, fhp = o.fantasy_h.copy(), o.fantasy_h_prime.copy()
@@ -440,10 +441,12 @@ def test_two_ranks():
             tables = build_tables(cid, o)
             total = None
             new_h, new_hp = [], []
+            per_rank = []
             for r in range(world):
                 lo, hi = shard_range(s1 - s0, r, world)
                 clo, chi = shard_range(B, r, world)
                 sums, hm, hmp = rank_step(cid, o, tables, D[s0 + lo:s0 + hi], L, clo, chi)
+                per_rank.append(sums)
                 total = sums if total is None else (total + sums).astype(np.float32)
                 new_h.append(unpack_hidden(hm, K))
                 new_hp.append(unpack_hidden(hmp, K))
@@ -452,13 +455,29 @@ def test_two_ranks():
             old = [W, b, c, vW, vb, vc]
             nxt = [np.zeros_like(x) for x in old]
             new_tables = np.zeros(info["TABLES"], dtype=np.float32)
-            lib.emu_update_tables(cid, fp(total), *[fp(x) for x in old], *[fp(x) for x in nxt], L, Lf,
-                                  ctypes.c_float(o.learning_rate), ctypes.c_float(o.momentum), ctypes.c_float(o.rho),
-                                  ctypes.c_float(o.lambda_rate), fp(new_tables), 2, 128)
+            if ipc:
+                # the all-reduce through mapped buffers: every rank publishes, the update launch adds the copies in rank order
+                step_no += 1
+                count = per_rank[0].size
+                stride = (count + 31) & ~31
+                bufs = np.full(world * stride, np.nan, dtype=np.float32)
+                flags, status = np.zeros(world, dtype=np.uint32), np.zeros(1, dtype=np.uint32)
+                rc = lib.emu_ipc_update(cid, world, fp(np.concatenate(per_rank)), count, fp(bufs), stride, up(flags), up(status), step_no,
+                                        *[fp(x) for x in old], *[fp(x) for x in nxt], L, Lf,
+                                        ctypes.c_float(o.learning_rate), ctypes.c_float(o.momentum), ctypes.c_float(o.rho),
+                                        ctypes.c_float(o.lambda_rate), fp(new_tables), 2, 128)
+                assert rc == 0 and status[0] == 0 and np.all(flags == step_no)
+            else:
+                lib.emu_update_tables(cid, fp(total), *[fp(x) for x in old], *[fp(x) for x in nxt], L, Lf,
+                                      ctypes.c_float(o.learning_rate), ctypes.c_float(o.momentum), ctypes.c_float(o.rho),
+                                      ctypes.c_float(o.lambda_rate), fp(new_tables), 2, 128)
             W, b, c, vW, vb, vc = nxt
         return W, b, c, vW, fh, fhp
 
     one, two = run(1), run(2)
+    two_ipc = run(2, ipc=True)                          # ... and through publish + update_tables_ipc_body: bit for bit the same
+    for x, y in zip(two, two_ipc):
+        np.testing.assert_array_equal(x, y)
     np.testing.assert_array_equal(one[4], two[4])       # identical samples
     np.testing.assert_array_equal(one[5], two[5])
     for x, y in zip(one[:4], two[:4]):
