@@ -223,3 +223,29 @@ def test_load_state_defers_device_state(tmp_path):
     np.testing.assert_array_equal(f[1], fh[4:8].astype(np.float32))      # rank 1 of 2 takes chains 4..7
     np.testing.assert_array_equal(f[2], fh[::-1][4:8].astype(np.float32))
     assert [g for g in got if g[0] == "r"][0][1] == (77, 5, 1)
+
+
+def test_bench_line_contract_of_the_tracked_profile():
+    """The bench line the round's evidence holds (profiles/r03_bench_cfg2.json, written by `python bench.py` on an
+    MI355X): the driver's keys, BASELINE.json's metric and config, and a roofline object that names the resource
+    that binds (no `bound: hbm`, no fraction above 1 posing as a bandwidth utilisation)."""
+    import json
+    line = json.loads(open(os.path.join(ROOT, "profiles", "r03_bench_cfg2.json")).read().strip().splitlines()[-1])
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["metric"].split(";")[0].replace("x", "×") in base["metric"] and "cfg2" in line["config"]["workload"]
+    assert line["vs_baseline"] is None and base["published"] == {} and line["scaling"] == "weak" and line["dtype"] == "f32"
+    assert abs(line["value"] - line["n_gpus"] * 1e3 / line["ms_per_step"]) < 1e-6 * line["value"]   # value from the host clock
+    assert line["device_ms_per_step"] <= line["ms_per_step"] * 1.02 and line["metric_version"] == 3
+    assert line["warmup_effective"] == line["warmup"] + line["chain_burn_in_launches"]
+    r = line["roofline"]
+    assert r["bound"] == "valu_issue" and 0.0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["counters_source"].startswith("measured in this run")
+    assert 0.0 < r["hbm_actual_frac"] < 0.2 and abs(r["hbm_actual_frac"] - r["traffic"] / (r["avg_launch_us"] * 1e-6) / 8e12) < 1e-6
+    assert abs(r["algorithmic_frac"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 8e12) < 1e-6
+    assert r["algorithmic_bytes_per_launch"] == 8 * (10 * 186 + 4 * 200) * 8192                    # SURVEY 8(d)
+    c = line["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and 0 < c["parallel_efficiency"] <= 1.5
+    assert line["train"]["ms_per_train_step"] > 3 * line["device_ms_per_step"] / 2
