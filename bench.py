@@ -532,10 +532,13 @@ def main():
                                 "timed_out": bool(max(control.gather(int(cdist.ipc_timed_out(model)))))})
                     sums = control.gather(cdist.replica_checksum(model))
                     ipc["replicas_identical"] = len(set(sums)) == 1
-                    failed = failed or ipc["timed_out"] or not ipc["replicas_identical"]
+                    ipc["ok"] = ipc["replicas_identical"] and not ipc["timed_out"]
                 except Exception as e:
                     ipc["error"] = str(e)[:300]
-                    failed = True
+                    ipc["ok"] = False
+                # beside RCCL this form is a comparison, reported with its own flag; where it is the only all-reduce that
+                # can run (all ranks on one GPU) its failure is the training section's
+                failed = failed or (not rccl and not ipc["ok"])
                 if train is None:               # all ranks on one GPU: the IPC form is the only all-reduce that can run
                     train = {"train_steps_per_s": (tsteps / idev) if "ms_per_train_step" in ipc else None, "global_batch": n * world,
                              "cd_k": k, "all_reduce": "ipc (mapped buffers, no collective launch)",

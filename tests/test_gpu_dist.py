@@ -142,5 +142,5 @@ def test_bench_spawns_its_own_ranks(tmp_path):
         assert line["train"]["replicas_identical"] is True
     # the all-reduce through mapped buffers runs in both cases (beside RCCL on two GPUs, alone on one)
     ipc = line["train"]["ipc_all_reduce"]
-    assert "error" not in ipc and ipc["replicas_identical"] is True and ipc["timed_out"] is False, ipc
+    assert "error" not in ipc and ipc["ok"] is True and ipc["replicas_identical"] is True and ipc["timed_out"] is False, ipc
     assert line["secondary_ok"] is True
