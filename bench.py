@@ -462,10 +462,10 @@ def main():
             D = synthetic_onehot(n, cfg["L"], seed=1234 + rank)
             model._call("crbm_dataset_upload", fptr(D), n, cfg["L"])
             tms = ctypes.c_float()
-            tsteps = max(10, min(200, args.steps // 10))
+            tsteps = max(50, min(200, args.steps // 10))     # (a training step is 70 us: 50 of them keep the section at a few ms)
 
             def timed_steps():
-                model._call("crbm_time_train", 0, n, 5, ctypes.byref(tms))
+                model._call("crbm_time_train", 0, n, 10, ctypes.byref(tms))
                 barrier()
                 t1 = time.perf_counter()
                 model._call("crbm_time_train", 0, n, tsteps, ctypes.byref(tms))
