@@ -20,8 +20,12 @@
 //  * One workgroup owns whole chains and one thread owns 4 consecutive
 //    positions, so a k-step Gibbs chain runs entirely in LDS/registers; HBM
 //    sees the masks once in and once out per launch.
-//  * MFMA is not used: the transposed conv has output width 4 and the forward
-//    has one-hot operands (BASELINE.json north_star).
+//  * The convolution and its transpose do not use MFMA: the transposed conv has
+//    output width 4 and the forward has one-hot operands (BASELINE.json
+//    north_star).  The gradient statistics -- a K x 4M output contracted over
+//    all positions of the batch -- do (stats_mfma_*).
+//  * The reverse-complement strand needs no table of its own: its activation is
+//    the forward gather of the reverse-complemented letter window.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -555,7 +559,8 @@ __device__ __forceinline__ void copy_tables(float* dst, const float* src) {
 // ---------------------------------------------------------------------------
 // Tables, rebuilt whenever W, b or c change (set_params / apply_update):
 //  Tf[g][r][k]  = -log2(e) * ( sum_{t<G, j=gG+t<M} W[k][(r>>2t)&3][j]  (+ b[k] in group 0) )
-//  Tr           = same for rc(W) = W[k][3-a][M-1-j]       (convRBM.py:241,:285)
+//    (ONE table: the reverse-complement strand, rc(W) = W[k][3-a][M-1-j] of convRBM.py:241, gathers from it
+//     with the reverse-complemented letter window -- revcomp_window)
 //    The gather therefore yields z = -x*log2(e), so exp(-x) is one v_exp_f32
 //    (2^z) with no multiply; kernels that need x itself use x = -ln(2)*z.
 //    Pad columns k >= K get +1e30 in group 0: exp(-x) = inf, sigmoid -> 0.
