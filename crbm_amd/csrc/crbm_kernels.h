@@ -746,7 +746,13 @@ struct StatsRole {
   static constexpr int NTW = stats_ntw(C::NT, C::JT, KINDS);
   static constexpr int NR = C::NT / NTW;
   static constexpr int KW = 16 * NTW < C::K ? 16 * NTW : C::K;
-  static constexpr int ROWS = KINDS * KW + 1;
+  // The sparsity columns Q = P(1-P) are not parked: the wave that reads a P fragment derives the Q fragment from
+  // it in registers (same formula, same bits), so the column image holds the strands' P only -- half the rows
+  // of a single-stranded data half, a third fewer LDS instructions.  (Pooled units need the sum over their
+  // pooling group for Q: those are parked.)
+  static constexpr bool QDERIVE = SP && C::POOL == 1;
+  static constexpr int PARKED = KINDS - (QDERIVE ? 1 : 0);
+  static constexpr int ROWS = PARKED * KW + 1;
   static constexpr int NACC = C::NL * C::JT * KINDS * NTW;
   static constexpr int THREADS = stats_mfma_threads(NR);
   static constexpr int NQW = 4 * NTW;            // float4 quads of motifs a wave gathers
@@ -825,14 +831,16 @@ __device__ __forceinline__ void conv_gather_quads(const float* T, const LetterWi
 // One 32-position group (slot 0 or 1 of the wave's unit): all accumulator tiles of the wave.
 //   Pt  : the wave's column image (row kind*KW + i, stride STATS_RS, position slot*32 + t)
 //   win : the group's four letter windows (NPW/2 words each)
-template <class C, int KINDS, int NTW, bool BYTE_LUT>
+//   QDERIVE: the last kind (Q = P(1-P), sparsity) is not in the image but derived from the fragment of kind 0
+template <class C, int KINDS, int NTW, bool BYTE_LUT, bool QDERIVE = false>
 __device__ __forceinline__ void stats_mfma_group(const float* Pt, const uint32_t* win, const uint32_t* lut, int nt0, int slot,
                                                  floatx4 (&acc)[C::NL * C::JT * KINDS * NTW]) {
-  constexpr int KW = 16 * NTW < C::K ? 16 * NTW : C::K, ZROW = KINDS * KW;
+  constexpr int PARKED = KINDS - (QDERIVE ? 1 : 0);
+  constexpr int KW = 16 * NTW < C::K ? 16 * NTW : C::K, ZROW = PARKED * KW;
   const int lane = threadIdx.x & 63, i16 = lane & 15, g = lane >> 4;
   HalfFrag bhi[KINDS * NTW], blo[KINDS * NTW];
 #pragma unroll
-  for (int kind = 0; kind < KINDS; ++kind)
+  for (int kind = 0; kind < PARKED; ++kind)
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
       const int kl = 16 * t + i16;
@@ -841,6 +849,12 @@ __device__ __forceinline__ void stats_mfma_group(const float* Pt, const uint32_t
       const float4 x0 = src[0], x1 = src[1];
       const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
       split_f16(x, bhi[kind * NTW + t], blo[kind * NTW + t]);
+      if (QDERIVE && kind == 0) {
+        float q[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) q[e] = fmaf(-x[e] * STATS_PSCALE_INV, x[e], x[e]);   // 2^14 * P(1-P) from 2^14 * P
+        split_f16(q, bhi[(KINDS - 1) * NTW + t], blo[(KINDS - 1) * NTW + t]);
+      }
     }
   // the spare row (filter column M of letter 0, NL == 3): all ones -> sum over positions of P, i.e. H (crbm_layout.h, NL)
   const uint32_t ones_row = (C::NL == 3 && i16 == C::M % 16) ? 0x04000400u : 0u;
@@ -1084,7 +1098,7 @@ __device__ void stats_mfma_body(const StatsMfmaArgs& a, int bid = -1) {   // bid
           }
         } else {
 #pragma unroll
-          for (int r = 0; r < KINDS * KW; ++r) col[(size_t)r * STATS_RS] = 0.f;
+          for (int r = 0; r < R::PARKED * KW; ++r) col[(size_t)r * STATS_RS] = 0.f;
         }
       } else
       if (valid) {
@@ -1096,7 +1110,7 @@ __device__ void stats_mfma_body(const StatsMfmaArgs& a, int bid = -1) {   // bid
           if (16 * nt0 + kl < K) {                     // wave-uniform
             const float ps = fast_rcp(fmaf(exp_neg_x(z[kl]), STATS_PSCALE_INV, STATS_PSCALE_INV));   // 2^14 * sigma(x)
             col[(size_t)kl * STATS_RS] = ps;
-            if (SP) col[(size_t)((1 + C::DS) * KW + kl) * STATS_RS] = fmaf(-ps * STATS_PSCALE_INV, ps, ps);   // 2^14 * P(1-P)
+            if (SP && !R::QDERIVE) col[(size_t)((1 + C::DS) * KW + kl) * STATS_RS] = fmaf(-ps * STATS_PSCALE_INV, ps, ps);   // 2^14 * P(1-P)
           }
         if (C::DS) {
           conv_gather_quads<C, R::NQW>(Tf, revcomp_window<M>(wl), 4 * nt0, z);
@@ -1107,7 +1121,7 @@ __device__ void stats_mfma_body(const StatsMfmaArgs& a, int bid = -1) {   // bid
         }
       } else {
 #pragma unroll
-        for (int r = 0; r < KINDS * KW; ++r) col[(size_t)r * STATS_RS] = 0.f;
+        for (int r = 0; r < R::PARKED * KW; ++r) col[(size_t)r * STATS_RS] = 0.f;
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -1115,7 +1129,7 @@ __device__ void stats_mfma_body(const StatsMfmaArgs& a, int bid = -1) {   // bid
 #pragma unroll
     for (int slot = 0; slot < 2; ++slot)
       if (G0 + slot < ngroups && !(a.debug & 1))
-        stats_mfma_group<C, KINDS, NTW, BYTE_LUT>(Pt, win + 2 * NPW * slot, lut, nt0, slot, acc);
+        stats_mfma_group<C, KINDS, NTW, BYTE_LUT, R::QDERIVE>(Pt, win + 2 * NPW * slot, lut, nt0, slot, acc);
     __builtin_amdgcn_wave_barrier();                   // the slice is rewritten by the next unit
   }
   if (a.debug & 8) return;

@@ -232,7 +232,9 @@ inline StatsMfmaLayout stats_mfma_layout(const ModelShape& ms, int want_sparsity
   s.NTW = stats_ntw(ms.NT, ms.JT, s.kinds, max_tiles);
   s.NR = ms.NT / s.NTW;
   s.KW = 16 * s.NTW < K ? 16 * s.NTW : K;
-  s.rows = s.kinds * s.KW + 1;
+  // the sparsity columns are derived from the P fragments in registers, not parked (pooled units excepted): crbm_kernels.h, StatsRole
+  const int parked = s.kinds - ((want_sparsity && ms.POOL == 1) ? 1 : 0);
+  s.rows = parked * s.KW + 1;
   s.GPC = cdiv(Lh, 32);
   s.off_win = 0;                        // 8 windows x NPW/2 words
   s.off_gw = 4 * ms.NPW;                // 2 x NPW words
