@@ -131,6 +131,7 @@ class CRBM(object):
         self._host = {"motifs": W, "bias": b, "c": c}
         self._handle = None
         self._control = None          # crbm_amd.dist.ControlPlane of a data-parallel job
+        self._allreduce = None        # "rccl" or "ipc" once crbm_amd.dist.attach has made this model a rank
         self._pending_state = None    # velocities / chains / counters to install when the handle is created
         self.motifs = _DeviceShared(self, "motifs", W.shape)
         self.bias = _DeviceShared(self, "bias", b.shape)
@@ -521,6 +522,13 @@ class CRBM(object):
             # enqueued back to back, with one host synchronisation per epoch
             if sharded:
                 self._call("crbm_train_epoch_sharded", self.batchsize, ntrain, int(training_data.shape[-1]))
+                if self._allreduce == "ipc":
+                    # the update launches wait for their peers' sums with a bound: a peer that never delivered must not
+                    # hang the GPU -- and must not go unnoticed either
+                    from . import dist
+                    if dist.ipc_timed_out(self):
+                        raise Exception("data-parallel training: rank %d waited in vain for a peer's statistic sums "
+                                        "(a rank died or fell out of step); the model is invalid from this epoch on" % self.rank)
             else:
                 self._call("crbm_train_epoch_resident", self.batchsize)
             if not evaluates:

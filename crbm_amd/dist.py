@@ -466,6 +466,7 @@ def attach(model, rank=None, world=None, uid=None, control=None, allreduce=None)
     cp = ControlPlane(rank, world) if own else control
     model._control = cp
     sync_replicas(model, cp)
+    model._allreduce = allreduce
     if allreduce == "ipc":
         attach_ipc(model, cp)
     else:
