@@ -444,9 +444,12 @@ def main():
             print(json.dumps(out), flush=True)
 
     watchdog = None
+    progress = {}
     if world > 1 and not args.no_train:
         def bail():
-            emit({"error": "training section did not finish within %d s" % TRAIN_WATCHDOG_S})
+            # what the section had measured when it stopped making progress is kept (e.g. the RCCL steps when the
+            # comparison run of the mapped-buffer all-reduce behind them hangs)
+            emit(dict(progress, error="training section did not finish within %d s" % TRAIN_WATCHDOG_S))
             os._exit(3)
         watchdog = threading.Timer(TRAIN_WATCHDOG_S, bail)
         watchdog.daemon = True
@@ -510,6 +513,7 @@ def main():
                 sums = control.gather(cdist.replica_checksum(model))
                 train["replicas_identical"] = len(set(sums)) == 1
                 failed = failed or not train["replicas_identical"]
+                progress.update(train)
                 model._call("crbm_comm_destroy")
             if world > 1 and os.environ.get("CRBM_BENCH_IPC", "1") != "0":
                 # the all-reduce through mapped buffers (crbm_ipc_*): the ranks map each other's sums buffers and the update

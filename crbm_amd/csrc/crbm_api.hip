@@ -1152,6 +1152,15 @@ int crbm_gibbs_steps(crbm_handle* h, int32_t k) {
   return crbm_sync(h);
 }
 
+// waits for an event by polling it: the timed entry points return microseconds after their last launch has completed
+// (a blocking wait wakes up tens of microseconds late, which a 20-launch benchmark run would see in its host clock)
+static hipError_t spin_until(hipEvent_t ev) {
+  for (;;) {
+    const hipError_t e = hipEventQuery(ev);
+    if (e != hipErrorNotReady) return e;
+  }
+}
+
 int crbm_time_gibbs(crbm_handle* h, int32_t k, int32_t launches, float* total_ms) {
   ENTER();
   ARGCHK(k >= 0 && launches >= 1 && total_ms, "bad argument");   // k = 0: state load/store only (profiling)
@@ -1161,7 +1170,7 @@ int crbm_time_gibbs(crbm_handle* h, int32_t k, int32_t launches, float* total_ms
     if (rc) return rc;
   }
   HIPCHK(hipEventRecord(h->ev1, h->stream));
-  HIPCHK(hipEventSynchronize(h->ev1));
+  HIPCHK(spin_until(h->ev1));
   HIPCHK(hipEventElapsedTime(total_ms, h->ev0, h->ev1));
   return CRBM_OK;
 }
@@ -1178,7 +1187,7 @@ int crbm_time_train(crbm_handle* h, int32_t start, int32_t end, int32_t launches
     if (rc) return rc;
   }
   HIPCHK(hipEventRecord(h->ev1, h->stream));
-  HIPCHK(hipEventSynchronize(h->ev1));
+  HIPCHK(spin_until(h->ev1));
   HIPCHK(hipEventElapsedTime(total_ms, h->ev0, h->ev1));
   return CRBM_OK;
 }
@@ -1813,7 +1822,7 @@ int crbm_time_allreduce(crbm_handle* h, int32_t launches, float* total_ms) {
     if (r != ncclSuccess) return fail(h, CRBM_ERR_RCCL, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r));
   }
   HIPCHK(hipEventRecord(h->ev1, h->stream));
-  HIPCHK(hipEventSynchronize(h->ev1));
+  HIPCHK(spin_until(h->ev1));
   HIPCHK(hipEventElapsedTime(total_ms, h->ev0, h->ev1));
   return CRBM_OK;
 }
