@@ -373,8 +373,10 @@ int emu_update_tables(int id, const float* sums, const float* W, const float* b,
 int emu_ipc_update(int id, int nranks, const float* rank_sums, int count, float* bufs, int stride, uint32_t* flags,
                    uint32_t* status, uint32_t step_value, const float* W, const float* b, const float* c, const float* vW,
                    const float* vb, const float* vc, float* oW, float* ob, float* oc, float* ovW, float* ovb, float* ovc,
-                   int L_data, int Lf, float lr, float momentum, float rho, float lambda_rate, float* tables, int grid, int threads) {
+                   int L_data, int Lf, float lr, float momentum, float rho, float lambda_rate, float* tables, int grid, int threads,
+                   int silent_rank) {   // silent_rank >= 0: that rank never publishes (the update must time out, not hang)
   for (int r = 0; r < nranks; ++r) {
+    if (r == silent_rank) continue;
     PublishArgs pa{rank_sums + (size_t)r * count, bufs + (size_t)r * stride, flags + r, step_value, count};
     emu::launch([&] { publish_sums_kernel(pa); }, dim3(1), dim3(64), 0);
   }

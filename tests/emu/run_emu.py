@@ -465,8 +465,17 @@ def test_two_ranks():
                 rc = lib.emu_ipc_update(cid, world, fp(np.concatenate(per_rank)), count, fp(bufs), stride, up(flags), up(status), step_no,
                                         *[fp(x) for x in old], *[fp(x) for x in nxt], L, Lf,
                                         ctypes.c_float(o.learning_rate), ctypes.c_float(o.momentum), ctypes.c_float(o.rho),
-                                        ctypes.c_float(o.lambda_rate), fp(new_tables), 2, 128)
+                                        ctypes.c_float(o.lambda_rate), fp(new_tables), 2, 128, -1)
                 assert rc == 0 and status[0] == 0 and np.all(flags == step_no)
+                if step_no == 1:
+                    # a peer that never publishes: the wait runs out, the sticky status word says so, nothing hangs
+                    flags2, status2 = np.zeros(world, dtype=np.uint32), np.zeros(1, dtype=np.uint32)
+                    scratch = [np.zeros_like(x) for x in old]
+                    rc = lib.emu_ipc_update(cid, world, fp(np.concatenate(per_rank)), count, fp(bufs.copy()), stride, up(flags2), up(status2),
+                                            step_no, *[fp(x) for x in old], *[fp(x) for x in scratch], L, Lf,
+                                            ctypes.c_float(o.learning_rate), ctypes.c_float(o.momentum), ctypes.c_float(o.rho),
+                                            ctypes.c_float(o.lambda_rate), fp(np.zeros_like(new_tables)), 1, 64, 1)
+                    assert rc == 0 and status2[0] == 1 and flags2[1] == 0
             else:
                 lib.emu_update_tables(cid, fp(total), *[fp(x) for x in old], *[fp(x) for x in nxt], L, Lf,
                                       ctypes.c_float(o.learning_rate), ctypes.c_float(o.momentum), ctypes.c_float(o.rho),
