@@ -425,15 +425,26 @@ def replica_checksum(model):
 
 def attach_ipc(model, control):
     """The all-reduce through mapped buffers (include/crbm_amd.h, crbm_ipc_*): every rank exports a handle of
-    its sums buffer, the control plane carries the handles to everybody, every rank maps them."""
+    its sums buffer, the control plane carries the handles to everybody, every rank maps them.  Collective and
+    all-or-nothing: if any rank cannot export or map, EVERY rank raises (after the same number of collective
+    calls), so no rank is left waiting for a peer that gave up."""
     h = model._h()
     mine = (ctypes.c_uint8 * _lib.IPC_HANDLE_BYTES)()
-    model._check(model._lib.crbm_ipc_export(h, mine))
-    handles = control.gather(bytes(mine))
-    blob = b"".join(handles)
-    buf = (ctypes.c_uint8 * len(blob)).from_buffer_copy(blob)
-    model._check(model._lib.crbm_ipc_attach(h, buf, control.world, control.rank))
-    control.barrier()                    # nobody publishes before everybody has mapped
+    rc = model._lib.crbm_ipc_export(h, mine)
+    err = None if rc == 0 else "rank %d: crbm_ipc_export failed (%d): %s" % (control.rank, rc, model._lib.crbm_last_error(h).decode())
+    handles = control.gather(bytes(mine) if err is None else None)
+    if err is None and all(x is not None for x in handles):
+        blob = b"".join(handles)
+        buf = (ctypes.c_uint8 * len(blob)).from_buffer_copy(blob)
+        rc = model._lib.crbm_ipc_attach(h, buf, control.world, control.rank)
+        if rc != 0:
+            err = "rank %d: crbm_ipc_attach failed (%d): %s" % (control.rank, rc, model._lib.crbm_last_error(h).decode())
+    elif err is None:
+        err = "a peer could not export its buffer"
+    errors = [e for e in control.gather(err) if e]       # also the barrier: nobody publishes before everybody has mapped
+    if errors:
+        model._lib.crbm_ipc_detach(h)
+        raise Exception("mapped-buffer all-reduce not available: " + "; ".join(errors))
 
 
 def ipc_timed_out(model):
