@@ -553,6 +553,16 @@ def main():
                 train["ipc_all_reduce"] = ipc
             if train is None:
                 train = {"error": "no all-reduce available (CRBM_BENCH_SHARE_GPU with CRBM_BENCH_IPC=0)", "global_batch": n * world}
+            if train.get("ms_per_train_step"):
+                # SURVEY 8(d), train-step bytes in the reference's dense fp32 layout: the data batch read once, k Gibbs
+                # steps, the model statistics fused (no extra traffic) -- per GPU
+                S = 2 if cfg["ds"] else 1
+                tb = n * (4 * 4 * cfg["L"] + k * algorithmic_bytes_per_seq(cfg["K"], cfg["M"], cfg["L"], cfg["ds"]))
+                train["algorithmic_bytes_per_step_per_gpu"] = tb
+                train["algorithmic_frac"] = tb / (train["ms_per_train_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                train["bound_note"] = ("equivalent-dense rate like roofline.algorithmic_frac, not a bandwidth utilisation: the step moves "
+                                       "about 21 MB of HBM and is bound by vector-instruction issue (crbm_train_local keeps a SIMD's "
+                                       "vector issue busy for 0.77 of its launch at config #2: profiles/r03_pmc_summary.txt)")
         except Exception as e:                      # report, never hide: the headline is the Gibbs metric
             train = {"error": str(e)[:300]}
             failed = True
