@@ -831,7 +831,7 @@ def test_inference_streams_in_slabs(monkeypatch):
                                         # beyond 64 motifs (masks of 3..8 words) and beyond 32-letter motifs (two-word
                                         # letter windows): the reference takes any positive K, M (convRBM.py:72-108)
                                         (100, 15, False, 120, 4), (20, 40, True, 150, 4), (70, 33, True, 90, 3),
-                                        (130, 7, True, 60, 3), (192, 4, False, 40, 2), (4, 64, True, 100, 3)])
+                                        (130, 7, True, 60, 3), (192, 4, False, 40, 2), (256, 4, False, 40, 2), (4, 64, True, 100, 3)])
 def test_edge_shapes(K, M, ds, L, n):
     """Smallest and largest supported models, L == M (a single hidden position),
     mask-word and letter-window boundaries: activations, hit probabilities,
@@ -915,7 +915,7 @@ def test_models_beyond_the_lds_are_refused_with_a_reason():
     m = CRBM(120, 40, doublestranded=True)             # 77 KB of gather table + 180 KB of top-down tables
     with pytest.raises(Exception, match="too large for the LDS"):
         m.gibbsSteps(1)
-    m = CRBM(256, 4, doublestranded=False, batchsize=2, fantasy_hidden_len=20)
+    m = CRBM(256, 4, doublestranded=True, batchsize=2, fantasy_hidden_len=20)
     m.gibbsSteps(1)                                    # the chain fits ...
     with pytest.raises(Exception, match="too large for the statistics kernel"):
         m._trainingFct(synthetic_onehot(2, 30, seed=1))   # ... the 16 column roles of the statistics block do not
