@@ -2358,9 +2358,12 @@ struct PublishArgs {
 };
 __global__ void __launch_bounds__(1024) publish_sums_kernel(PublishArgs a) {
   for (int i = threadIdx.x; i < a.count; i += blockDim.x) store_system(a.dst + i, a.src[i]);
-  fence_system();                                   // this thread's stores are visible system-wide ...
-  __syncthreads();                                  // ... and so are everybody's
-  if (threadIdx.x == 0) store_system(a.flag, a.value);
+  wait_vector_memory();                             // this wave's (write-through) stores have left ...
+  __syncthreads();                                  // ... and so have everybody's
+  if (threadIdx.x == 0) {
+    fence_system();                                 // one release for the block (a fence per thread costs microseconds)
+    store_system(a.flag, a.value);
+  }
 }
 #endif  // CRBM_DEFINE_MISC_KERNELS
 
