@@ -155,6 +155,8 @@ struct crbm_handle {
   int ipc_stride = 0;                  // floats per parity (sums count rounded up to a 128-byte line)
   bool ipc_on = false;
   uint32_t ipc_step = 0;               // steps published so far (the flag value of the next one is ipc_step + 1)
+  bool ipc_published = false;          // the column reduction of the running step has written and flagged the published buffer itself
+  uint32_t* d_ticket = nullptr;        // arrival counter of that launch (zero between launches)
   std::string err;
 };
 
@@ -468,7 +470,33 @@ int launch_update(crbm_handle* h, int L_data) {
   return CRBM_OK;
 }
 
-int train_local_dev(crbm_handle* h, const uint32_t* d_letters, int n, int L) {
+size_t ipc_bytes(const crbm_handle* h);
+float* ipc_sums_of(void* base, const crbm_handle* h, int parity);
+uint32_t* ipc_flag_of(void* base, const crbm_handle* h, int parity);
+
+// the column reductions of both halves in one launch; with the mapped-buffer all-reduce on, straight into this
+// rank's published buffer, flag included (reduce_publish_pair_kernel)
+int launch_reduce_pair(crbm_handle* h, ReducePair pair, bool publish) {
+  const dim3 grid((pair.half[0].row + 31) / 32, 2);
+  if (publish && h->ipc_on) {
+    const int parity = (int)(h->ipc_step & 1u);
+    float* base = ipc_sums_of(h->ipc_buf, h, parity);
+    for (auto& half : pair.half) half.sums = base + (half.sums - h->d_sums);
+    PublishTail t;
+    t.ticket = h->d_ticket; t.flag = ipc_flag_of(h->ipc_buf, h, parity); t.value = h->ipc_step + 1u;
+    hipLaunchKernelGGL(reduce_publish_pair_kernel, grid, dim3(1024), 0, h->stream, pair, t);
+    h->ipc_published = true;
+  } else {
+    hipLaunchKernelGGL(reduce_partials_pair_kernel, grid, dim3(1024), 0, h->stream, pair);
+  }
+  HIPCHK(hipGetLastError());
+  return CRBM_OK;
+}
+
+// data statistics + k Gibbs steps + model statistics -> d_sums (local)
+// publish: the caller runs the mapped-buffer all-reduce next (train_core), so the sums may go straight to the
+// published buffer; crbm_train_local wants them in d_sums
+int train_local_dev(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool publish = false) {
   int rc = ensure_tables(h);
   if (rc) return rc;
   hipStream_t sm = h->overlap ? h->stream2 : h->stream;
@@ -495,9 +523,7 @@ int train_local_dev(crbm_handle* h, const uint32_t* d_letters, int n, int L) {
     HIPCHK(jit_launch(h->jk.train_local, t, (unsigned)(h->gibbs_grid + dgrid), 1, (unsigned)h->gibbs_threads, lds, h->stream));
     h->gibbs_step += (uint32_t)h->cfg.cd_k;
     h->launches_since_read += 1;
-    hipLaunchKernelGGL(reduce_partials_pair_kernel, dim3((pair.half[0].row + 31) / 32, 2), dim3(1024), 0, h->stream, pair);
-    HIPCHK(hipGetLastError());
-    return CRBM_OK;
+    return launch_reduce_pair(h, pair, publish);
   }
   if (h->fuse_stats) {
     // the Gibbs launch itself leaves the model half of the statistics (last-step probabilities
@@ -521,8 +547,8 @@ int train_local_dev(crbm_handle* h, const uint32_t* d_letters, int n, int L) {
     rc = launch_stats(h, d_letters, n, L, true, nullptr, paired ? &pair.half[0] : nullptr);
     if (rc) return rc;
     if (paired) {
-      hipLaunchKernelGGL(reduce_partials_pair_kernel, dim3((pair.half[0].row + 31) / 32, 2), dim3(1024), 0, h->stream, pair);
-      HIPCHK(hipGetLastError());
+      rc = launch_reduce_pair(h, pair, publish);
+      if (rc) return rc;
     }
   } else {   // a rank may own no rows of a short last mini-batch: contribute zeros
     HIPCHK(hipMemsetAsync(h->d_sums + h->sl.data_off, 0, (size_t)(h->sl.n_d + 1 - h->sl.data_off) * sizeof(float), h->stream));
@@ -560,11 +586,16 @@ int ipc_allocate(crbm_handle* h) {
 int launch_ipc_allreduce_update(crbm_handle* h, int L_data) {
   const int parity = (int)(h->ipc_step & 1u);
   const uint32_t value = h->ipc_step + 1u;
-  PublishArgs pa;
-  pa.src = h->d_sums; pa.dst = ipc_sums_of(h->ipc_buf, h, parity); pa.flag = ipc_flag_of(h->ipc_buf, h, parity);
-  pa.value = value; pa.count = h->sl.count;
-  hipLaunchKernelGGL(publish_sums_kernel, dim3(1), dim3(1024), 0, h->stream, pa);
-  HIPCHK(hipGetLastError());
+  if (!h->ipc_published) {
+    // the sums of this step were formed in d_sums (separate reductions of the two halves, or a rank without data
+    // rows): copy them into the published buffer and raise its flag in a launch of its own
+    PublishArgs pa;
+    pa.src = h->d_sums; pa.dst = ipc_sums_of(h->ipc_buf, h, parity); pa.flag = ipc_flag_of(h->ipc_buf, h, parity);
+    pa.value = value; pa.count = h->sl.count;
+    hipLaunchKernelGGL(publish_sums_kernel, dim3(1), dim3(1024), 0, h->stream, pa);
+    HIPCHK(hipGetLastError());
+  }
+  h->ipc_published = false;
   UpdateIpcArgs a;
   fill_update_args(h, L_data, a.ut);
   for (int r = 0; r < IPC_MAX_RANKS; ++r) {
@@ -583,7 +614,7 @@ int launch_ipc_allreduce_update(crbm_handle* h, int L_data) {
 }
 
 int train_core(crbm_handle* h, const uint32_t* d_letters, int n, int L) {
-  int rc = train_local_dev(h, d_letters, n, L);
+  int rc = train_local_dev(h, d_letters, n, L, true);
   if (rc) return rc;
   if (h->ipc_on) return launch_ipc_allreduce_update(h, L);
   if (h->comm) {
@@ -842,6 +873,7 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
     TRY(hipMalloc((void**)&hh->d_nset, slots * 4)); TRY(hipMemset(hh->d_nset, 0, slots * 4));
   }
   TRY(hipMalloc((void**)&hh->d_sums, (size_t)hh->sl.count * 4)); TRY(hipMemset(hh->d_sums, 0, (size_t)hh->sl.count * 4));
+  TRY(hipMalloc((void**)&hh->d_ticket, 16)); TRY(hipMemset(hh->d_ticket, 0, 16));
 #undef TRY
   hh->tables_dirty = true;
   {
@@ -868,7 +900,7 @@ int crbm_destroy(crbm_handle* h) {
   for (int r = 0; r < IPC_MAX_RANKS; ++r)
     if (h->ipc_peer[r] && h->ipc_peer[r] != h->ipc_buf) (void)hipIpcCloseMemHandle(h->ipc_peer[r]);
   if (h->ipc_buf) (void)hipFree(h->ipc_buf);
-  void* ptrs[] = {h->dW2, h->db2, h->dc2, h->dvW2, h->dvb2, h->dvc2, h->dW, h->db, h->dc, h->dvW, h->dvb, h->dvc, h->d_hm, h->d_hmp, h->d_vf, h->d_flags, h->d_ones, h->d_nset, h->d_sums, h->d_tables};
+  void* ptrs[] = {h->dW2, h->db2, h->dc2, h->dvW2, h->dvb2, h->dvc2, h->dW, h->db, h->dc, h->dvW, h->dvb, h->dvc, h->d_hm, h->d_hmp, h->d_vf, h->d_flags, h->d_ones, h->d_nset, h->d_sums, h->d_ticket, h->d_tables};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   h->stage.release(); h->stage2.release(); h->out_a.release(); h->out_b.release(); h->out_c.release();

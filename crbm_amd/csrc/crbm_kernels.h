@@ -2068,6 +2068,9 @@ struct ReduceArgs {
   float n_value;                  // written after the last kept column
 };
 
+// SYSTEM: the sums go out with system-scope stores (into the buffer the other ranks of a node have mapped:
+// reduce_publish_pair_kernel)
+template <bool SYSTEM = false>
 __device__ __forceinline__ void reduce_partials_body(const ReduceArgs& a) {
   __shared__ float part[32][33];
   const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
@@ -2107,10 +2110,13 @@ __device__ __forceinline__ void reduce_partials_body(const ReduceArgs& a) {
     if (!skipped) {
       float s = 0.f;
       for (int g = 0; g < ngrp; ++g) s += part[g][col];
-      a.sums[r < a.skip_begin ? r : r - a.skip_len] = s;
+      float* dst = a.sums + (r < a.skip_begin ? r : r - a.skip_len);
+      if (SYSTEM) store_system(dst, s); else *dst = s;
     }
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) a.sums[a.row - a.skip_len] = a.n_value;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (SYSTEM) store_system(a.sums + (a.row - a.skip_len), a.n_value); else a.sums[a.row - a.skip_len] = a.n_value;
+  }
 }
 
 
@@ -2340,10 +2346,32 @@ __global__ void __launch_bounds__(256) vgh_dense_kernel(VghArgs a) {
   }
 }
 
-__global__ void __launch_bounds__(1024) reduce_partials_kernel(ReduceArgs a) { reduce_partials_body(a); }
+__global__ void __launch_bounds__(1024) reduce_partials_kernel(ReduceArgs a) { reduce_partials_body<false>(a); }
+
+// IPC all-reduce: the column reduction writes this rank's sums straight into its published buffer, and the block
+// that arrives last raises the buffer's flag -- the all-reduce then costs no launch of its own (the stores are
+// system-scope and drained before a block's ticket; the last block's fence orders them before the flag)
+struct PublishTail {
+  uint32_t* ticket;      // zero before the launch, left zero
+  uint32_t* flag;
+  uint32_t value;
+};
+__global__ void __launch_bounds__(1024) reduce_publish_pair_kernel(ReducePair p, PublishTail t) {
+  reduce_partials_body<true>(p.half[blockIdx.y]);
+  wait_vector_memory();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t prev = atomicAdd(t.ticket, 1u);
+    if (prev == gridDim.x * gridDim.y - 1u) {
+      atomicExch(t.ticket, 0u);
+      fence_system();
+      store_system(t.flag, t.value);
+    }
+  }
+}
 
 __global__ void __launch_bounds__(1024) reduce_partials_pair_kernel(ReducePair p) {
-  reduce_partials_body(p.half[blockIdx.y]);
+  reduce_partials_body<false>(p.half[blockIdx.y]);
 }
 
 __global__ void apply_update_kernel(UpdateArgs a) { apply_update_body<0>(a, nullptr, true); }   // one block, in place
