@@ -700,9 +700,11 @@ GibbsGeom choose_gibbs_geometry(const ModelShape& ms, int Lf, int B, int num_cu,
     // small blocks reach at most half the waves
     // Solo launches of single-stranded models take the large blocks whenever they score better (config #2:
     // one 1024-thread block of 32 chains per CU 22.7 us per launch against 23.8 with four 256-thread blocks:
-    // one table copy per CU, and the short last round of the v|h pass spreads over all SIMDs); double-stranded
-    // ones do not (config #5: 150 -> 153 / 156 us with 512 / 1024 threads -- the queue drain grows with the block).
-    const bool big_ok = solo ? !ms.DS : (!ms.FUSE_STATS && best_occupancy <= 0.5);
+    // one table copy per CU, and the short last round of the v|h pass spreads over all SIMDs).  Double-stranded
+    // models too since they gather from one table and their queue of undecided units holds 254 entries
+    // (config #5: 158 us per launch with three 256-thread blocks of 3 chains per CU, 145 with two 512-thread
+    // blocks of 8, 143.6 with one 1024-thread block of 16 -- 147 when the queue overflows at 62 entries).
+    const bool big_ok = solo ? true : (!ms.FUSE_STATS && best_occupancy <= 0.5);
     if (threads > 256 && (!big_ok || env_int("CRBM_GIBBS_MAX_THREADS", 1024) < threads)) continue;
     if (forceT > 0 && threads != forceT) continue;
     for (int S = 1; S <= std::min(B, 64); ++S) {

@@ -161,9 +161,9 @@ inline int choose_group(int K, int M, int /*ds*/, int budget_bytes) {
 // Behind the letter rows sits the block's queue of undecided hidden units (crbm_kernels.h, gibbs_body):
 // word 0 = count, words 2.. = entries (item | unit << 20 | strand << 26).
 #ifndef CRBM_FIXQ_CAP
-#define CRBM_FIXQ_CAP 62     // tests shrink it (CRBM_JIT_DEFINES) to drive the overflow path; never above FIXQ_WORDS - 2
+#define CRBM_FIXQ_CAP 254    // tests shrink it (CRBM_JIT_DEFINES) to drive the overflow path; never above FIXQ_WORDS - 2
 #endif
-constexpr int FIXQ_WORDS = 64, FIXQ_CAP = CRBM_FIXQ_CAP;
+constexpr int FIXQ_WORDS = 256, FIXQ_CAP = CRBM_FIXQ_CAP;
 static_assert(FIXQ_CAP >= 0 && FIXQ_CAP <= FIXQ_WORDS - 2, "queue capacity");
 struct GibbsLayout {
   int S, Lv, nvb, nhb, Lrow, LWs;
