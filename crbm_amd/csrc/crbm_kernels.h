@@ -1227,7 +1227,8 @@ __device__ void gibbs_body(const GibbsArgs& a, int bid = -1) {   // bid: block o
   constexpr bool DEFER = false;
 #else
   // Measured: double-stranded models gain (config #5: 180 -> 155 us per step), single-stranded
-  // ones lose to the extra barrier and the serial drain (config #2: 16.9 -> 17.5 us per step).  Pooled
+  // ones lose to the extra barrier and the serial drain (config #2: 16.9 -> 17.5 us per step; with the
+  // 1024-thread blocks of round 3 21.7 -> 22.1 us per one-step launch, config #4 2.273 -> 2.279 ms).  Pooled
   // models draw both fields for every group anyway.
   constexpr bool DEFER = C::POOL == 1 && C::DS;
 #endif
