@@ -466,10 +466,14 @@ def main():
             D = synthetic_onehot(n, cfg["L"], seed=1234 + rank)
             model._call("crbm_dataset_upload", fptr(D), n, cfg["L"])
             tms = ctypes.c_float()
-            tsteps = max(50, min(200, args.steps // 10))     # (a training step is 70 us: 50 of them keep the section at a few ms)
+            # 200 timed steps after 50: the hidden activity of the randomly initialised model settles within ~50 steps
+            # (config #2: 79 us per step over the first ten, 70.5 over steps 40-50), and a timed region of a few
+            # milliseconds still contains the GPU's ramp out of idle (tools/train_trajectory.py: 70 us per step in
+            # 10-step regions against 65.5 in a 400-step one)
+            tsteps, twarm = 200, 50
 
             def timed_steps():
-                model._call("crbm_time_train", 0, n, 10, ctypes.byref(tms))
+                model._call("crbm_time_train", 0, n, twarm, ctypes.byref(tms))
                 barrier()
                 t1 = time.perf_counter()
                 model._call("crbm_time_train", 0, n, tsteps, ctypes.byref(tms))
@@ -497,7 +501,8 @@ def main():
                 twall, tdev = timed_steps()
                 train = {"train_steps_per_s": tsteps / tdev, "global_batch": n * world, "cd_k": k,
                          "all_reduce": "rccl" if rccl else "none", "ms_per_train_step": 1e3 * tdev / tsteps,
-                         "wall_ms_per_train_step": 1e3 * twall / tsteps, "steps": tsteps, "statistics_dtype": stats_note}
+                         "wall_ms_per_train_step": 1e3 * twall / tsteps, "steps": tsteps, "warmup_steps": twarm,
+                         "statistics_dtype": stats_note}
             if rccl:
                 ams = ctypes.c_float()
                 model._call("crbm_time_allreduce", 10, ctypes.byref(ams))
