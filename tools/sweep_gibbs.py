@@ -19,6 +19,8 @@ def time_cfg(cfg, env, steps=300):
     try:
         model._h()
     except Exception as e:
+        for k in env:
+            os.environ.pop(k, None)
         return None, str(e)
     model._call("crbm_gibbs_steps", 10)
     ms = ctypes.c_float()
