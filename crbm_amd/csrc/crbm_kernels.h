@@ -753,7 +753,27 @@ struct StatsRole {
   static constexpr bool QDERIVE = SP && C::POOL == 1;
   static constexpr int PARKED = KINDS - (QDERIVE ? 1 : 0);
   static constexpr int ROWS = PARKED * KW + 1;
-  static constexpr int NACC = C::NL * C::JT * KINDS * NTW;
+  // Column tiles of the accumulators.  A wave that holds all motifs (NR == 1, so KW == K) has the parked kinds
+  // back to back in its image, rows kind * K + k: the tiles then cut that list every 16 rows regardless of
+  // where a kind ends (PACKED) -- 20 motifs on two strands are 40 columns = 3 tiles instead of 2 x 2.  The
+  // derived sparsity tiles follow; each comes from the P fragment of the same tile index (columns of that
+  // fragment that belong to the other strand give garbage nobody reads).
+  static constexpr int NPT_PACKED = cdiv(PARKED * C::K, 16);
+#ifdef CRBM_STATS_UNPACKED     // A/B knob (CRBM_JIT_DEFINES): whole tiles per kind everywhere
+  static constexpr bool PACKED = false;
+#else
+  static constexpr bool PACKED = NR == 1 && NPT_PACKED < PARKED * NTW;
+#endif
+  static constexpr int NPT = PACKED ? NPT_PACKED : PARKED * NTW;        // tiles read from the image
+  static constexpr int NCT = NPT + (QDERIVE ? NTW : 0);                 // + derived ones
+  static constexpr int NACC = C::NL * C::JT * NCT;
+  // tile and lane-in-tile of column `col` of kind `kind` (kind == KINDS - 1 with QDERIVE: the derived tiles)
+  static constexpr int tile_of(int kind, int col) {
+    return (QDERIVE && kind == KINDS - 1) ? NPT + col / 16 : PACKED ? (kind * C::K + col) / 16 : kind * NTW + col / 16;
+  }
+  static constexpr int lane_of(int kind, int col) {
+    return (QDERIVE && kind == KINDS - 1) ? col % 16 : PACKED ? (kind * C::K + col) % 16 : col % 16;
+  }
   static constexpr int THREADS = stats_mfma_threads(NR);
   static constexpr int NQW = 4 * NTW;            // float4 quads of motifs a wave gathers
 };
@@ -831,31 +851,35 @@ __device__ __forceinline__ void conv_gather_quads(const float* T, const LetterWi
 // One 32-position group (slot 0 or 1 of the wave's unit): all accumulator tiles of the wave.
 //   Pt  : the wave's column image (row kind*KW + i, stride STATS_RS, position slot*32 + t)
 //   win : the group's four letter windows (NPW/2 words each)
-//   QDERIVE: the last kind (Q = P(1-P), sparsity) is not in the image but derived from the fragment of kind 0
-template <class C, int KINDS, int NTW, bool BYTE_LUT, bool QDERIVE = false>
+//   R   : the wave's role (StatsRole): column tiles read from the image (per kind, or cut from the kinds back to
+//         back: PACKED) and, with QDERIVE, the tiles of the last kind (Q = P(1-P), sparsity), which are not in the
+//         image but derived from the fragments of kind 0
+template <class C, class R, bool BYTE_LUT>
 __device__ __forceinline__ void stats_mfma_group(const float* Pt, const uint32_t* win, const uint32_t* lut, int nt0, int slot,
-                                                 floatx4 (&acc)[C::NL * C::JT * KINDS * NTW]) {
-  constexpr int PARKED = KINDS - (QDERIVE ? 1 : 0);
-  constexpr int KW = 16 * NTW < C::K ? 16 * NTW : C::K, ZROW = PARKED * KW;
+                                                 floatx4 (&acc)[R::NACC]) {
+  constexpr int NTW = R::NTW, NCT = R::NCT, NPT = R::NPT, KW = R::KW, ZROW = R::PARKED * KW;
   const int lane = threadIdx.x & 63, i16 = lane & 15, g = lane >> 4;
-  HalfFrag bhi[KINDS * NTW], blo[KINDS * NTW];
+  HalfFrag bhi[NCT], blo[NCT];
 #pragma unroll
-  for (int kind = 0; kind < PARKED; ++kind)
-#pragma unroll
-    for (int t = 0; t < NTW; ++t) {
-      const int kl = 16 * t + i16;
-      const int row = (16 * (nt0 + t) + i16 < C::K) ? kind * KW + kl : ZROW;     // motifs beyond K: the all-zero row
-      const float4* src = reinterpret_cast<const float4*>(Pt + (size_t)row * STATS_RS + slot * 32 + 8 * g);
-      const float4 x0 = src[0], x1 = src[1];
-      const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-      split_f16(x, bhi[kind * NTW + t], blo[kind * NTW + t]);
-      if (QDERIVE && kind == 0) {
-        float q[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) q[e] = fmaf(-x[e] * STATS_PSCALE_INV, x[e], x[e]);   // 2^14 * P(1-P) from 2^14 * P
-        split_f16(q, bhi[(KINDS - 1) * NTW + t], blo[(KINDS - 1) * NTW + t]);
-      }
+  for (int c = 0; c < NPT; ++c) {
+    int row;
+    if constexpr (R::PACKED) {
+      row = 16 * c + i16 < R::PARKED * C::K ? 16 * c + i16 : ZROW;               // the kinds back to back; behind them the all-zero row
+    } else {
+      const int kind = c / NTW, t = c - kind * NTW, kl = 16 * t + i16;
+      row = (16 * (nt0 + t) + i16 < C::K) ? kind * KW + kl : ZROW;              // motifs beyond K: the all-zero row
     }
+    const float4* src = reinterpret_cast<const float4*>(Pt + (size_t)row * STATS_RS + slot * 32 + 8 * g);
+    const float4 x0 = src[0], x1 = src[1];
+    const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    split_f16(x, bhi[c], blo[c]);
+    if (R::QDERIVE && c < NTW) {          // kind 0 fills the first tiles in either layout
+      float q[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) q[e] = fmaf(-x[e] * STATS_PSCALE_INV, x[e], x[e]);   // 2^14 * P(1-P) from 2^14 * P
+      split_f16(q, bhi[NPT + c], blo[NPT + c]);
+    }
+  }
   // the spare row (filter column M of letter 0, NL == 3): all ones -> sum over positions of P, i.e. H (crbm_layout.h, NL)
   const uint32_t ones_row = (C::NL == 3 && i16 == C::M % 16) ? 0x04000400u : 0u;
 #pragma unroll
@@ -889,8 +913,8 @@ __device__ __forceinline__ void stats_mfma_group(const float* Pt, const uint32_t
         for (int e = 0; e < 4; ++e) af.r[e] |= ones_row;
       }
 #pragma unroll
-      for (int c = 0; c < KINDS * NTW; ++c) {
-        floatx4& d = acc[(a * C::JT + jt) * KINDS * NTW + c];
+      for (int c = 0; c < NCT; ++c) {
+        floatx4& d = acc[(a * C::JT + jt) * NCT + c];
         d = mfma_16x16x32_f16(af, bhi[c], d);
         d = mfma_16x16x32_f16(af, blo[c], d);
       }
@@ -932,15 +956,17 @@ __device__ __forceinline__ void stats_mfma_finish(const StatsGeom& sg, float* ld
 #pragma unroll
           for (int jt = 0; jt < C::JT; ++jt)
 #pragma unroll
-            for (int t = 0; t < NTW; ++t) {
-              const int kl = 16 * t + i16;
-              const floatx4 d = acc[((a * C::JT + jt) * KINDS + kind) * NTW + t];
+            for (int c = R::tile_of(kind, 0); c <= R::tile_of(kind, KW - 1); ++c) {   // the tiles that hold columns of this kind
+              // this lane's column of the tile, as a motif of the kind (negative or >= KW: another kind's or padding)
+              const int kl = 16 * (c - R::tile_of(kind, 0)) + i16 - R::lane_of(kind, 0);
+              const floatx4 d = acc[(a * C::JT + jt) * R::NCT + c];
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 const int j = 16 * jt + 4 * g + r;
-                if (j < M && 16 * nt0 + kl < K) mine[(a * M + j) * KW + kl] = d[r];   // motif fastest: lanes of a tile row hit consecutive banks
+                const bool mine_k = kl >= 0 && kl < KW && 16 * nt0 + kl < K;
+                if (j < M && mine_k) mine[(a * M + j) * KW + kl] = d[r];   // motif fastest: lanes of a tile row hit consecutive banks
                 // the all-ones row: H, parked in the (unused) slot of letter 3, column 0
-                if (C::NL == 3 && a == 0 && j == M && 16 * nt0 + kl < K) mine[(3 * M) * KW + kl] = d[r];
+                if (C::NL == 3 && a == 0 && j == M && mine_k) mine[(3 * M) * KW + kl] = d[r];
               }
             }
       }
@@ -1004,7 +1030,7 @@ struct StatsMfmaArgs {
 template <class C, bool SP, bool BYTE_LUT = true>
 __device__ void stats_mfma_body(const StatsMfmaArgs& a, int bid = -1) {   // bid: block of the statistics grid (default: blockIdx.x)
   using R = StatsRole<C, SP>;
-  constexpr int K = C::K, M = C::M, KINDS = R::KINDS, NTW = R::NTW, NR = R::NR, KW = R::KW;
+  constexpr int K = C::K, M = C::M, NTW = R::NTW, NR = R::NR, KW = R::KW;
   HIP_DYNAMIC_SHARED(float, smem);
   const StatsGeom& sg = a.sg;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
@@ -1129,7 +1155,7 @@ __device__ void stats_mfma_body(const StatsMfmaArgs& a, int bid = -1) {   // bid
 #pragma unroll
     for (int slot = 0; slot < 2; ++slot)
       if (G0 + slot < ngroups && !(a.debug & 1))
-        stats_mfma_group<C, KINDS, NTW, BYTE_LUT, R::QDERIVE>(Pt, win + 2 * NPW * slot, lut, nt0, slot, acc);
+        stats_mfma_group<C, R, BYTE_LUT>(Pt, win + 2 * NPW * slot, lut, nt0, slot, acc);
     __builtin_amdgcn_wave_barrier();                   // the slice is rewritten by the next unit
   }
   if (a.debug & 8) return;
@@ -1580,7 +1606,7 @@ __device__ void gibbs_body(const GibbsArgs& a, int bid = -1) {   // bid: block o
 #pragma unroll
           for (int slot = 0; slot < 2; ++slot)
             if (G0 + slot < ngl)
-              stats_mfma_group<C, SR::KINDS, SR::NTW, false>(sPt, swin + 2 * C::NPW * slot, reinterpret_cast<const uint32_t*>(sreg), 0, slot, sacc);
+              stats_mfma_group<C, SR, false>(sPt, swin + 2 * C::NPW * slot, reinterpret_cast<const uint32_t*>(sreg), 0, slot, sacc);
           __builtin_amdgcn_wave_barrier();       // the slice is rewritten by the next unit
         }
       }
