@@ -31,6 +31,31 @@ void run(int blocks, int lds_bytes, int barriers, int n, float* out) {
   printf("blocks %5d x %4d threads, LDS %6d B, %d barriers: %.2f us per launch\n", blocks, THREADS, lds_bytes, barriers, 1e3 * ms / n);
 }
 
+// the same launches replayed from a graph of `per` kernel nodes captured from the stream
+template <int THREADS>
+void run_graph(int blocks, int lds_bytes, int per, int n, float* out) {
+  CHK(hipFuncSetAttribute(reinterpret_cast<const void*>(empty_kernel<THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  hipStream_t st;
+  CHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  hipGraph_t g; hipGraphExec_t ge;
+  CHK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+  for (int i = 0; i < per; ++i) hipLaunchKernelGGL(empty_kernel<THREADS>, dim3(blocks), dim3(THREADS), lds_bytes, st, out, 2);
+  CHK(hipStreamEndCapture(st, &g));
+  CHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+  hipEvent_t e0, e1;
+  CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+  for (int i = 0; i < 5; ++i) CHK(hipGraphLaunch(ge, st));
+  CHK(hipStreamSynchronize(st));
+  CHK(hipEventRecord(e0, st));
+  for (int i = 0; i < n / per; ++i) CHK(hipGraphLaunch(ge, st));
+  CHK(hipEventRecord(e1, st));
+  CHK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  CHK(hipEventElapsedTime(&ms, e0, e1));
+  printf("graph of %3d nodes: blocks %5d x %4d threads, LDS %6d B: %.2f us per kernel\n", per, blocks, THREADS, lds_bytes, 1e3 * ms / (n / per * per));
+  CHK(hipGraphExecDestroy(ge)); CHK(hipGraphDestroy(g)); CHK(hipStreamDestroy(st));
+}
+
 int main() {
   float* out;
   CHK(hipMalloc(&out, 1 << 20));
@@ -47,6 +72,10 @@ int main() {
     run<256>(1792, 22 * 1024, 2, n, out);
     run<512>(256, 110 * 1024, 2, n, out);
     run<768>(256, 110 * 1024, 2, n, out);
+  }
+  for (int per : {1, 3, 20, 100}) {
+    run_graph<1024>(256, 110 * 1024, per, 2000, out);
+    run_graph<256>(1792, 22 * 1024, per, 2000, out);
   }
   return 0;
 }
