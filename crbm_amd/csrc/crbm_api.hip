@@ -471,19 +471,26 @@ int launch_update(crbm_handle* h, int L_data) {
 }
 
 size_t ipc_bytes(const crbm_handle* h);
-float* ipc_sums_of(void* base, const crbm_handle* h, int parity);
-uint32_t* ipc_flag_of(void* base, const crbm_handle* h, int parity);
+float* ipc_slot_of(void* base, const crbm_handle* h, int parity, int source);
+uint32_t* ipc_flag_of(void* base, const crbm_handle* h, int parity, int source);
 
 // the column reductions of both halves in one launch; with the mapped-buffer all-reduce on, straight into this
 // rank's published buffer, flag included (reduce_publish_pair_kernel)
 int launch_reduce_pair(crbm_handle* h, ReducePair pair, bool publish) {
   const dim3 grid((pair.half[0].row + 31) / 32, 2);
   if (publish && h->ipc_on) {
+    // this rank's slot of the step's parity in every rank's buffer, the own one as the base the others are offsets of
     const int parity = (int)(h->ipc_step & 1u);
-    float* base = ipc_sums_of(h->ipc_buf, h, parity);
+    float* base = ipc_slot_of(h->ipc_buf, h, parity, h->rank);
     for (auto& half : pair.half) half.sums = base + (half.sums - h->d_sums);
     PublishTail t;
-    t.ticket = h->d_ticket; t.flag = ipc_flag_of(h->ipc_buf, h, parity); t.value = h->ipc_step + 1u;
+    t.ticket = h->d_ticket; t.value = h->ipc_step + 1u;
+    t.push.n = h->nranks;
+    for (int r = 0; r < IPC_MAX_RANKS; ++r) {
+      void* peer = r < h->nranks ? h->ipc_peer[r] : h->ipc_buf;
+      t.push.delta[r] = (long long)(reinterpret_cast<char*>(ipc_slot_of(peer, h, parity, h->rank)) - reinterpret_cast<char*>(base));
+      t.flag[r] = ipc_flag_of(peer, h, parity, h->rank);
+    }
     hipLaunchKernelGGL(reduce_publish_pair_kernel, grid, dim3(1024), 0, h->stream, pair, t);
     h->ipc_published = true;
   } else {
@@ -558,13 +565,17 @@ int train_local_dev(crbm_handle* h, const uint32_t* d_letters, int n, int L, boo
 }
 
 // ---- IPC all-reduce (update_tables_ipc_body) -------------------------------------------------
-size_t ipc_bytes(const crbm_handle* h) { return ((size_t)2 * h->ipc_stride + 64) * sizeof(float); }
-float* ipc_sums_of(void* base, const crbm_handle* h, int parity) { return static_cast<float*>(base) + (size_t)parity * h->ipc_stride; }
-uint32_t* ipc_flag_of(void* base, const crbm_handle* h, int parity) {
-  return reinterpret_cast<uint32_t*>(static_cast<float*>(base) + (size_t)2 * h->ipc_stride) + 16 * parity;   // one flag per 64-byte line
+// A rank's buffer: [2 parities][8 source ranks][ipc_stride floats] of sums, then [2][8] flag words on 64-byte lines
+// of their own, then the status word
+size_t ipc_bytes(const crbm_handle* h) { return ((size_t)2 * IPC_MAX_RANKS * h->ipc_stride + (2 * IPC_MAX_RANKS + 1) * 16) * sizeof(float); }
+float* ipc_slot_of(void* base, const crbm_handle* h, int parity, int source) {
+  return static_cast<float*>(base) + ((size_t)parity * IPC_MAX_RANKS + source) * h->ipc_stride;
+}
+uint32_t* ipc_flag_of(void* base, const crbm_handle* h, int parity, int source) {
+  return reinterpret_cast<uint32_t*>(static_cast<float*>(base) + (size_t)2 * IPC_MAX_RANKS * h->ipc_stride) + 16 * (parity * IPC_MAX_RANKS + source);
 }
 uint32_t* ipc_status_of(void* base, const crbm_handle* h) {
-  return reinterpret_cast<uint32_t*>(static_cast<float*>(base) + (size_t)2 * h->ipc_stride) + 32;
+  return reinterpret_cast<uint32_t*>(static_cast<float*>(base) + (size_t)2 * IPC_MAX_RANKS * h->ipc_stride) + 16 * 2 * IPC_MAX_RANKS;
 }
 
 int ipc_allocate(crbm_handle* h) {
@@ -582,26 +593,30 @@ int ipc_allocate(crbm_handle* h) {
   return CRBM_OK;
 }
 
-// this rank's sums of the step -> its published buffer + flag; then the update that sums all ranks' buffers
+// this rank's sums of the step -> its slot in every rank's buffer + flags; then the update that sums the slots of its own buffer
 int launch_ipc_allreduce_update(crbm_handle* h, int L_data) {
   const int parity = (int)(h->ipc_step & 1u);
   const uint32_t value = h->ipc_step + 1u;
   if (!h->ipc_published) {
     // the sums of this step were formed in d_sums (separate reductions of the two halves, or a rank without data
-    // rows): copy them into the published buffer and raise its flag in a launch of its own
+    // rows): push them and raise the flags in a launch of its own
     PublishArgs pa;
-    pa.src = h->d_sums; pa.dst = ipc_sums_of(h->ipc_buf, h, parity); pa.flag = ipc_flag_of(h->ipc_buf, h, parity);
-    pa.value = value; pa.count = h->sl.count;
+    pa.src = h->d_sums; pa.value = value; pa.count = h->sl.count; pa.n = h->nranks;
+    for (int r = 0; r < IPC_MAX_RANKS; ++r) {
+      void* peer = r < h->nranks ? h->ipc_peer[r] : h->ipc_buf;
+      pa.dst[r] = ipc_slot_of(peer, h, parity, h->rank);
+      pa.flag[r] = ipc_flag_of(peer, h, parity, h->rank);
+    }
     hipLaunchKernelGGL(publish_sums_kernel, dim3(1), dim3(1024), 0, h->stream, pa);
     HIPCHK(hipGetLastError());
   }
   h->ipc_published = false;
   UpdateIpcArgs a;
   fill_update_args(h, L_data, a.ut);
-  for (int r = 0; r < IPC_MAX_RANKS; ++r) {
-    void* base = r < h->nranks ? h->ipc_peer[r] : h->ipc_buf;
-    a.ipc.sums[r] = ipc_sums_of(base, h, parity);
-    a.ipc.flags[r] = ipc_flag_of(base, h, parity);
+  for (int r = 0; r < IPC_MAX_RANKS; ++r) {            // everything the update reads is in this rank's own buffer
+    const int src = r < h->nranks ? r : 0;
+    a.ipc.sums[r] = ipc_slot_of(h->ipc_buf, h, parity, src);
+    a.ipc.flags[r] = ipc_flag_of(h->ipc_buf, h, parity, src);
   }
   a.ipc.status = ipc_status_of(h->ipc_buf, h);
   a.ipc.expect = value; a.ipc.nranks = h->nranks; a.ipc.count = h->sl.count;
@@ -1763,6 +1778,10 @@ int crbm_ipc_export(crbm_handle* h, uint8_t handle[CRBM_IPC_HANDLE_BYTES]) {
   static_assert(sizeof(hipIpcMemHandle_t) == CRBM_IPC_HANDLE_BYTES, "hipIpcMemHandle_t size");
   int rc = ipc_allocate(h);
   if (rc) return rc;
+  // flags and status start from zero with every attachment (the step count does too): cleared here, before the
+  // handle leaves -- no peer pushes into this buffer before it has seen the handles of all ranks
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemset(h->ipc_buf, 0, ipc_bytes(h)));
   hipIpcMemHandle_t mh;
   HIPCHK(hipIpcGetMemHandle(&mh, h->ipc_buf));
   memcpy(handle, &mh, sizeof(mh));

@@ -2022,21 +2022,25 @@ __device__ void update_tables_body(const UpdateTablesArgs& a) {
 
 // ---------------------------------------------------------------------------
 // The all-reduce of a data-parallel training step WITHOUT a collective launch (an alternative to
-// ncclAllReduce for the few-KB sums buffer, whose cost is pure latency).  Every rank publishes its packed
-// sums in a buffer that all ranks of the node have mapped (hipIpcOpenMemHandle; double-buffered by step
-// parity) and then raises that buffer's flag to the step number (publish_sums_kernel).  The update launch of
-// every rank waits for the flags of all ranks, adds the R copies IN RANK ORDER (so every rank forms the
+// ncclAllReduce for the few-KB sums buffer, whose cost is pure latency).  Every rank owns a buffer that all
+// ranks of the node have mapped (hipIpcOpenMemHandle): per step parity one slot of sums and one flag word per
+// SOURCE rank.  A rank PUSHES: the column reduction of its step writes its packed sums into its slot of every
+// rank's buffer (its own included) and then raises its flag there to the step number
+// (reduce_publish_pair_kernel; publish_sums_kernel where the sums were formed in d_sums).  The update launch of
+// every rank waits for the R flags in ITS OWN buffer, adds the R slots IN RANK ORDER (so every rank forms the
 // bit-identical sum, and with it the bit-identical update) and goes on as update_tables_body does: no
-// collective launch, no extra kernel boundary on the critical path.
-// Buffer reuse: a rank overwrites parity p only after its own update of the step before, which waited for
-// every peer's flag of that step -- raised after the peer's update two steps back had read parity p.
+// collective launch, no extra kernel boundary, and nothing on the critical path reads remote memory -- a
+// step's traffic over xGMI is one posted copy of the sums per peer (a few KB), where pulling would have every
+// block of every rank's update fetch every peer's sums and poll remote flags.
+// Buffer reuse: a rank writes parity p of a peer's buffer only after its own update of the step before, which
+// waited for that peer's flag of that step -- raised after the peer's update two steps back had read parity p.
 // The wait is bounded (a peer that died must not hang this GPU): on a time-out the kernel raises
 // `status[0]`, later launches do not wait at all, and the host reports it (crbm_ipc_status).
 // ---------------------------------------------------------------------------
 constexpr int IPC_MAX_RANKS = 8;
 struct IpcArgs {
-  const float* sums[IPC_MAX_RANKS];       // every rank's published sums of this step's parity (this rank's own included)
-  const uint32_t* flags[IPC_MAX_RANKS];   // ... and their flag words: == expect once the sums are complete
+  const float* sums[IPC_MAX_RANKS];       // the slots of this step's parity in THIS rank's buffer, one per source rank
+  const uint32_t* flags[IPC_MAX_RANKS];   // ... and their flag words: == expect once a source's sums are complete
   uint32_t* status;                       // [0] != 0: a wait timed out (sticky)
   uint32_t expect;
   int32_t nranks, count;
@@ -2095,10 +2099,22 @@ struct ReduceArgs {
   float n_value;                  // written after the last kept column
 };
 
-// SYSTEM: the sums go out with system-scope stores (into the buffer the other ranks of a node have mapped:
-// reduce_publish_pair_kernel)
+// Where a pushing rank's sums go: the same offset in its slot of every rank's buffer (byte distances from the
+// rank's own buffer, which ReduceArgs::sums points into; own = 0)
+struct PushTargets {
+  int32_t n;
+  long long delta[8];
+};
+__device__ __forceinline__ void push_store(float* own, const PushTargets& t, float v) {
+#pragma unroll
+  for (int r = 0; r < 8; ++r)
+    if (r < t.n) store_system(reinterpret_cast<float*>(reinterpret_cast<char*>(own) + t.delta[r]), v);
+}
+
+// SYSTEM: the sums go out with system-scope stores into the buffers the ranks of a node have mapped
+// (reduce_publish_pair_kernel)
 template <bool SYSTEM = false>
-__device__ __forceinline__ void reduce_partials_body(const ReduceArgs& a) {
+__device__ __forceinline__ void reduce_partials_body(const ReduceArgs& a, const PushTargets* push = nullptr) {
   __shared__ float part[32][33];
   const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int ngrp = (int)(blockDim.x >> 5);          // 32 row groups in the 1024-thread launches of the product
@@ -2138,11 +2154,11 @@ __device__ __forceinline__ void reduce_partials_body(const ReduceArgs& a) {
       float s = 0.f;
       for (int g = 0; g < ngrp; ++g) s += part[g][col];
       float* dst = a.sums + (r < a.skip_begin ? r : r - a.skip_len);
-      if (SYSTEM) store_system(dst, s); else *dst = s;
+      if (SYSTEM) push_store(dst, *push, s); else *dst = s;
     }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    if (SYSTEM) store_system(a.sums + (a.row - a.skip_len), a.n_value); else a.sums[a.row - a.skip_len] = a.n_value;
+    if (SYSTEM) push_store(a.sums + (a.row - a.skip_len), *push, a.n_value); else a.sums[a.row - a.skip_len] = a.n_value;
   }
 }
 
@@ -2375,16 +2391,18 @@ __global__ void __launch_bounds__(256) vgh_dense_kernel(VghArgs a) {
 
 __global__ void __launch_bounds__(1024) reduce_partials_kernel(ReduceArgs a) { reduce_partials_body<false>(a); }
 
-// IPC all-reduce: the column reduction writes this rank's sums straight into its published buffer, and the block
-// that arrives last raises the buffer's flag -- the all-reduce then costs no launch of its own (the stores are
-// system-scope and drained before a block's ticket; the last block's fence orders them before the flag)
+// IPC all-reduce: the column reduction writes this rank's sums straight into its slot of every rank's buffer,
+// and the block that arrives last raises the rank's flag in all of them -- the all-reduce then costs no launch of
+// its own (the stores are system-scope and drained before a block's ticket; the last block's fence orders them
+// before the flags)
 struct PublishTail {
   uint32_t* ticket;      // zero before the launch, left zero
-  uint32_t* flag;
+  uint32_t* flag[8];     // this rank's flag word of the step's parity in every rank's buffer
   uint32_t value;
+  PushTargets push;
 };
 __global__ void __launch_bounds__(1024) reduce_publish_pair_kernel(ReducePair p, PublishTail t) {
-  reduce_partials_body<true>(p.half[blockIdx.y]);
+  reduce_partials_body<true>(p.half[blockIdx.y], &t.push);
   wait_vector_memory();
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -2392,7 +2410,7 @@ __global__ void __launch_bounds__(1024) reduce_publish_pair_kernel(ReducePair p,
     if (prev == gridDim.x * gridDim.y - 1u) {
       atomicExch(t.ticket, 0u);
       fence_system();
-      store_system(t.flag, t.value);
+      for (int r = 0; r < t.push.n; ++r) store_system(t.flag[r], t.value);
     }
   }
 }
@@ -2403,21 +2421,25 @@ __global__ void __launch_bounds__(1024) reduce_partials_pair_kernel(ReducePair p
 
 __global__ void apply_update_kernel(UpdateArgs a) { apply_update_body<0>(a, nullptr, true); }   // one block, in place
 
-// IPC all-reduce: this rank's sums of the step -> its published buffer, then the flag (one block)
+// IPC all-reduce: this rank's sums of the step (formed in d_sums) -> its slot of every rank's buffer, then its
+// flags (one block)
 struct PublishArgs {
   const float* src;
-  float* dst;
-  uint32_t* flag;
+  float* dst[8];         // this rank's slot of the step's parity in every rank's buffer
+  uint32_t* flag[8];
   uint32_t value;
-  int32_t count;
+  int32_t count, n;
 };
 __global__ void __launch_bounds__(1024) publish_sums_kernel(PublishArgs a) {
-  for (int i = threadIdx.x; i < a.count; i += blockDim.x) store_system(a.dst + i, a.src[i]);
+  for (int i = threadIdx.x; i < a.count; i += blockDim.x) {
+    const float v = a.src[i];
+    for (int r = 0; r < a.n; ++r) store_system(a.dst[r] + i, v);
+  }
   wait_vector_memory();                             // this wave's (write-through) stores have left ...
   __syncthreads();                                  // ... and so have everybody's
   if (threadIdx.x == 0) {
     fence_system();                                 // one release for the block (a fence per thread costs microseconds)
-    store_system(a.flag, a.value);
+    for (int r = 0; r < a.n; ++r) store_system(a.flag[r], a.value);
   }
 }
 #endif  // CRBM_DEFINE_MISC_KERNELS

@@ -212,9 +212,10 @@ int crbm_comm_broadcast_state(crbm_handle* h, int32_t root);
 /* The same all-reduce WITHOUT a collective launch, for the ranks of one node (at most 8): every rank exports a
  * handle of its sums buffer (crbm_ipc_export, hipIpcGetMemHandle), the host ships the handles to all ranks by
  * any channel, every rank maps them (crbm_ipc_attach, `handles` = nranks x CRBM_IPC_HANDLE_BYTES in rank
- * order).  A training step then publishes its packed sums in the rank's buffer and raises a flag; the update
- * launch of every rank waits for all flags and adds the copies in rank order (bit-identical on all ranks):
- * one small launch instead of ncclAllReduce on the critical path.  Alternative to crbm_comm_init, not to be
+ * order).  The column reduction of a training step then PUSHES the rank's packed sums into its slot of every
+ * rank's buffer and raises its flag there; the update launch of every rank waits for the flags in its own
+ * buffer and adds the slots in rank order (bit-identical on all ranks): no launch at all in place of
+ * ncclAllReduce, and no read of remote memory on the critical path.  Alternative to crbm_comm_init, not to be
  * combined with it; replicas must start identical (crbm_amd.dist.attach ships rank 0's parameters first).
  * crbm_ipc_status: *timed_out != 0 if a wait for a peer ever ran out (results are invalid from then on). */
 #define CRBM_IPC_HANDLE_BYTES 64

@@ -377,7 +377,9 @@ int emu_ipc_update(int id, int nranks, const float* rank_sums, int count, float*
                    int silent_rank) {   // silent_rank >= 0: that rank never publishes (the update must time out, not hang)
   for (int r = 0; r < nranks; ++r) {
     if (r == silent_rank) continue;
-    PublishArgs pa{rank_sums + (size_t)r * count, bufs + (size_t)r * stride, flags + r, step_value, count};
+    PublishArgs pa{};     // rank r pushes into its slot of the observing rank's buffer
+    pa.src = rank_sums + (size_t)r * count; pa.dst[0] = bufs + (size_t)r * stride; pa.flag[0] = flags + r;
+    pa.value = step_value; pa.count = count; pa.n = 1;
     emu::launch([&] { publish_sums_kernel(pa); }, dim3(1), dim3(64), 0);
   }
   CFG_DISPATCH(id, {
