@@ -578,7 +578,11 @@ def main():
         out["secondary_ok"] = not failed        # the training section is secondary: its failure is reported in the line
     emit(train)                                 # (train.error) and through the flag; the headline above stays valid
     control.close()
-    if failed and os.environ.get("CRBM_BENCH_STRICT", "0") == "1":
+    # A failed training section (diverged replicas, a time-out of the mapped-buffer all-reduce, an exception) of a
+    # multi-rank run is a failed run: the line above is complete and says what happened (secondary_ok, train.error),
+    # the exit code says it to whoever only looks at that.  One-GPU runs keep exit 0 for the Gibbs headline unless
+    # CRBM_BENCH_STRICT=1 (the training section is secondary there and has no collective to get wrong).
+    if failed and (world > 1 or os.environ.get("CRBM_BENCH_STRICT", "0") == "1") and os.environ.get("CRBM_BENCH_STRICT", "") != "0":
         sys.exit(4)
 
 

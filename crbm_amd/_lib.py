@@ -14,10 +14,10 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libcrbm_hip.so")
 
 UNIQUE_ID_BYTES = 128
 IPC_HANDLE_BYTES = 64
-ABI_VERSION = 2          # CRBM_AMD_ABI_VERSION of include/crbm_amd.h
+ABI_VERSION = 3          # CRBM_AMD_ABI_VERSION of include/crbm_amd.h
 
 CRBM_OK = 0
-ERR_INVALID, ERR_HIP, ERR_NOT_ONEHOT, ERR_NOT_BINARY, ERR_RCCL, ERR_NO_GPU = -1, -2, -3, -4, -5, -6
+ERR_INVALID, ERR_HIP, ERR_NOT_ONEHOT, ERR_NOT_BINARY, ERR_RCCL, ERR_NO_GPU, ERR_IPC_TIMEOUT = -1, -2, -3, -4, -5, -6, -7
 
 
 class CrbmConfig(ctypes.Structure):

@@ -521,14 +521,16 @@ class CRBM(object):
             # the batch loop of convRBM.py:612-615 runs inside the library: the steps are
             # enqueued back to back, with one host synchronisation per epoch
             if sharded:
+                # All ranks enter an epoch together: rank 0 alone converts and uploads the test set before its first
+                # step and alone evaluates after every epoch (below), while the other ranks come straight back here.
+                # Without this barrier their update launches would spend that time waiting ON THE DEVICE for rank 0's
+                # sums -- a wait that the mapped-buffer all-reduce bounds (CRBM_IPC_TIMEOUT_MS) so that a dead peer
+                # cannot hang a GPU.  Host skew belongs on the host: the control plane waits (CRBM_CONTROL_TIMEOUT).
+                if self._control is not None:
+                    self._control.barrier()
+                # (a wait that ran out inside the epoch comes back as CRBM_ERR_IPC_TIMEOUT: no update was applied
+                #  after it, the parameters are those of the last complete step)
                 self._call("crbm_train_epoch_sharded", self.batchsize, ntrain, int(training_data.shape[-1]))
-                if self._allreduce == "ipc":
-                    # the update launches wait for their peers' sums with a bound: a peer that never delivered must not
-                    # hang the GPU -- and must not go unnoticed either
-                    from . import dist
-                    if dist.ipc_timed_out(self):
-                        raise Exception("data-parallel training: rank %d waited in vain for a peer's statistic sums "
-                                        "(a rank died or fell out of step); the model is invalid from this epoch on" % self.rank)
             else:
                 self._call("crbm_train_epoch_resident", self.batchsize)
             if not evaluates:

@@ -62,6 +62,25 @@ def build(verbose=True, jobs=None):
     return LIB
 
 
+def prune_cache(verbose=True):
+    """Code objects are keyed by the full kernel source text: every file older than the newest kernel source was built
+    from another revision (or another option set) and can never be hit again -- delete those, so that the in-tree
+    cache that travels to the GPU box holds one revision."""
+    cache = os.path.join(HERE, "jit_cache")
+    if not os.path.isdir(cache):
+        return 0
+    newest = max(os.path.getmtime(os.path.join(HERE, h)) for h in ("crbm_kernels.h", "crbm_layout.h", "crbm_jit.h"))
+    gone = 0
+    for f in os.listdir(cache):
+        path = os.path.join(cache, f)
+        if f.endswith((".hsaco", ".tmp")) and os.path.getmtime(path) < newest:
+            os.unlink(path)
+            gone += 1
+    if verbose and gone:
+        print("jit cache: removed %d stale code objects" % gone)
+    return gone
+
+
 def precompile(configs, verbose=True):
     """JIT-compile the kernels of the given models into the on-disk cache.
     configs: iterable of dicts with num_motifs, motif_length, doublestranded,

@@ -157,6 +157,7 @@ struct crbm_handle {
   uint32_t ipc_step = 0;               // steps published so far (the flag value of the next one is ipc_step + 1)
   bool ipc_published = false;          // the column reduction of the running step has written and flagged the published buffer itself
   uint32_t* d_ticket = nullptr;        // arrival counter of that launch (zero between launches)
+  unsigned long long ipc_timeout_ticks = 0;   // bound of an update launch's wait for its peers, in ticks of the GPU's wall clock
   std::string err;
 };
 
@@ -581,11 +582,15 @@ uint32_t* ipc_status_of(void* base, const crbm_handle* h) {
 int ipc_allocate(crbm_handle* h) {
   if (h->ipc_buf) return CRBM_OK;
   h->ipc_stride = (h->sl.count + 31) & ~31;
-  // fine-grained device memory (coherent between agents) where the runtime exports it; plain device memory otherwise --
-  // every access of a peer is a system-scope load or store either way
+  // fine-grained device memory: coherent between agents, so a peer's system-scope stores are what this GPU's
+  // system-scope loads see.  Plain (coarse-grained) device memory may keep stale lines of the rank's own buffer in
+  // L2 after a peer's write over xGMI: refused unless CRBM_IPC_COARSE_OK=1 asks for it (one-GPU experiments).
   void* p = nullptr;
-  if (hipExtMallocWithFlags(&p, ipc_bytes(h), hipDeviceMallocFinegrained) != hipSuccess) {
+  const hipError_t fe = hipExtMallocWithFlags(&p, ipc_bytes(h), hipDeviceMallocFinegrained);
+  if (fe != hipSuccess) {
     (void)hipGetLastError();
+    if (env_int("CRBM_IPC_COARSE_OK", 0) == 0)
+      return fail(h, CRBM_ERR_HIP, std::string("hipExtMallocWithFlags(hipDeviceMallocFinegrained) for the mapped sums buffer: ") + hipGetErrorString(fe));
     HIPCHK(hipMalloc(&p, ipc_bytes(h)));
   }
   HIPCHK(hipMemset(p, 0, ipc_bytes(h)));
@@ -620,8 +625,10 @@ int launch_ipc_allreduce_update(crbm_handle* h, int L_data) {
   }
   a.ipc.status = ipc_status_of(h->ipc_buf, h);
   a.ipc.expect = value; a.ipc.nranks = h->nranks; a.ipc.count = h->sl.count;
+  a.ipc.timeout_ticks = h->ipc_timeout_ticks;
   const unsigned grid = (unsigned)std::max(1, std::min((h->ms.TABLES_ALL + 4095) / 4096, 32));
-  const unsigned lds = (unsigned)((((h->sl.count + 3) & ~3) + h->KAM + h->K + 4) * 4);
+  // the new parameters and one word (update_tables_ipc_body): the published sums are read where they lie, not staged
+  const unsigned lds = (unsigned)((h->KAM + h->K + 4 + 4) * 4);
   HIPCHK(jit_launch(h->jk.update_tables_ipc, a, grid, 1, UPDATE_THREADS, lds, h->stream));
   swap_param_sets(h);
   h->ipc_step += 1;
@@ -637,6 +644,19 @@ int train_core(crbm_handle* h, const uint32_t* d_letters, int n, int L) {
     if (r != ncclSuccess) return fail(h, CRBM_ERR_RCCL, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r));
   }
   return launch_update(h, L);
+}
+
+// The status word of the mapped-buffer all-reduce, read at a point where the stream is idle anyway: a wait for a
+// peer that ran out (update_tables_ipc_body) is an error of every training entry point and of crbm_sync from then on.
+int ipc_check(crbm_handle* h) {
+  if (!h->ipc_on || !h->ipc_buf) return CRBM_OK;
+  uint32_t st = 0;
+  HIPCHK(hipMemcpy(&st, ipc_status_of(h->ipc_buf, h), sizeof(st), hipMemcpyDeviceToHost));
+  if (st != 0)
+    return fail(h, CRBM_ERR_IPC_TIMEOUT, "mapped-buffer all-reduce: waited " + std::to_string(env_int("CRBM_IPC_TIMEOUT_MS", 30000)) +
+                " ms in vain for a peer's statistic sums (a rank died or fell out of step); no update has been applied since, "
+                "the parameters are those of the last complete step");
+  return CRBM_OK;
 }
 
 int check_data_shape(crbm_handle* h, int n, int L) {
@@ -1066,7 +1086,7 @@ int crbm_train_step(crbm_handle* h, const float* D, int32_t n, int32_t L) {
   rc = train_core(h, h->letters.p, n, L);
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(h->stream));
-  return CRBM_OK;
+  return ipc_check(h);
 }
 
 int crbm_dataset_select(crbm_handle* h, int32_t slot) {
@@ -1125,7 +1145,7 @@ int crbm_train_step_resident(crbm_handle* h, int32_t start, int32_t end) {
   int rc = train_core(h, h->dataset[slot].p + (size_t)start * LW, end - start, h->dataset_L[slot]);
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(h->stream));
-  return CRBM_OK;
+  return ipc_check(h);
 }
 
 // One pass over the resident data set in sequential mini-batches of `batchsize`
@@ -1146,7 +1166,7 @@ int crbm_train_epoch_resident(crbm_handle* h, int32_t batchsize) {
     if (rc) return rc;
   }
   HIPCHK(hipStreamSynchronize(h->stream));
-  return CRBM_OK;
+  return ipc_check(h);
 }
 
 // The same loop when the selected slot holds only THIS rank's rows: for every
@@ -1180,7 +1200,7 @@ int crbm_train_epoch_sharded(crbm_handle* h, int32_t batchsize, int32_t total_ro
     off += (size_t)mine;
   }
   HIPCHK(hipStreamSynchronize(h->stream));
-  return CRBM_OK;
+  return ipc_check(h);
 }
 
 int crbm_gibbs_steps_async(crbm_handle* h, int32_t k) {
@@ -1192,6 +1212,8 @@ int crbm_gibbs_steps_async(crbm_handle* h, int32_t k) {
 int crbm_sync(crbm_handle* h) {
   ENTER();
   HIPCHK(hipStreamSynchronize(h->stream));
+  int rc = ipc_check(h);
+  if (rc) return rc;
   return refresh_activity(h);
 }
 
@@ -1204,9 +1226,10 @@ int crbm_gibbs_steps(crbm_handle* h, int32_t k) {
 // waits for an event by polling it: the timed entry points return microseconds after their last launch has completed
 // (a blocking wait wakes up tens of microseconds late, which a 20-launch benchmark run would see in its host clock)
 static hipError_t spin_until(hipEvent_t ev) {
-  for (;;) {
+  for (long i = 0;; ++i) {
     const hipError_t e = hipEventQuery(ev);
     if (e != hipErrorNotReady) return e;
+    if (i > 2000000) return hipEventSynchronize(ev);   // seconds have passed: nothing left to gain from polling, block like everybody else
   }
 }
 
@@ -1238,7 +1261,7 @@ int crbm_time_train(crbm_handle* h, int32_t start, int32_t end, int32_t launches
   HIPCHK(hipEventRecord(h->ev1, h->stream));
   HIPCHK(spin_until(h->ev1));
   HIPCHK(hipEventElapsedTime(total_ms, h->ev0, h->ev1));
-  return CRBM_OK;
+  return ipc_check(h);
 }
 
 // ---- stand-alone passes ------------------------------------------------------
@@ -1806,6 +1829,14 @@ int crbm_ipc_attach(crbm_handle* h, const uint8_t* handles, int32_t nranks, int3
   h->nranks = nranks; h->rank = rank;
   h->ipc_on = true;
   h->ipc_step = 0;
+  // the bound of an update launch's wait for its peers, in ticks of the GPU's constant-rate clock (s_memrealtime;
+  // its rate in kHz = ticks per millisecond, 100 MHz on every part so far)
+  int khz = 0;
+  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->device) != hipSuccess || khz <= 0) {
+    (void)hipGetLastError();
+    khz = 100000;
+  }
+  h->ipc_timeout_ticks = (unsigned long long)std::max(1, env_int("CRBM_IPC_TIMEOUT_MS", 30000)) * (unsigned long long)khz;
   return CRBM_OK;
 }
 

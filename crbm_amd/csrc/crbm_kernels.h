@@ -39,7 +39,10 @@ struct IC {
 };
 
 // ---------------------------------------------------------------------------
-// Philox-4x32-10 (Random123 constants); same counters as oracle/crbm_oracle.py
+// Philox-4x32-7 (Random123 constants; seven rounds is the fewest that its authors report as passing BigCrush --
+// Salmon et al., SC'11, table 2 -- and what Random123 ships as philox4x32_R<7>); same counters and the same
+// round count as oracle/crbm_oracle.py and its C port.  The stream is this library's own definition: the
+// reference seeds Theano's MRG31k3p from the wall clock (convRBM.py:155), so there is no stream to match.
 // ---------------------------------------------------------------------------
 struct Philox4 {
   uint32_t v[4];
@@ -75,7 +78,15 @@ __device__ __forceinline__ uint32_t load_system(const uint32_t* p) { return __hi
 __device__ __forceinline__ void store_system(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ void store_system(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ void fence_system() { __threadfence_system(); }
+// what a consumer needs after it has seen a producer's flag: later loads may not be served from lines cached before
+__device__ __forceinline__ void fence_acquire_system() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); }
+// arrival counter of the blocks of one launch: the increment publishes the block's stores (release) and the block
+// that draws the last ticket sees everybody's (acquire), at the scope of this GPU
+__device__ __forceinline__ uint32_t ticket_add(uint32_t* p) { return __hip_atomic_fetch_add(p, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void short_sleep() { __builtin_amdgcn_s_sleep(8); }
+// the GPU's constant-rate wall clock (s_memrealtime; hipDeviceAttributeWallClockRate ticks per millisecond): bounds
+// the waits for another process in TIME, whatever the shader clock does
+__device__ __forceinline__ uint64_t realtime_ticks() { return __builtin_amdgcn_s_memrealtime(); }
 // x = hi + lo with both halves f16 (round to nearest): 22 significant bits, v_cvt_pk_f16_f32 +
 // v_cvt_f32_f16 + v_pk_add_f32 per pair
 __device__ __forceinline__ void split_f16(const float (&x)[8], HalfFrag& hi, HalfFrag& lo) {
@@ -124,7 +135,10 @@ __device__ __forceinline__ uint32_t load_system(const uint32_t* p) { return __at
 __device__ __forceinline__ void store_system(float* p, float v) { __atomic_store(p, &v, __ATOMIC_RELAXED); }
 __device__ __forceinline__ void store_system(uint32_t* p, uint32_t v) { __atomic_store_n(p, v, __ATOMIC_RELAXED); }
 __device__ __forceinline__ void fence_system() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+__device__ __forceinline__ void fence_acquire_system() { __atomic_thread_fence(__ATOMIC_ACQUIRE); }
+__device__ __forceinline__ uint32_t ticket_add(uint32_t* p) { return __atomic_fetch_add(p, 1u, __ATOMIC_ACQ_REL); }
 __device__ __forceinline__ void short_sleep() {}
+__device__ __forceinline__ uint64_t realtime_ticks() { return emu::realtime_ticks(); }   // microseconds
 __device__ __forceinline__ void split_f16(const float (&x)[8], HalfFrag& hi, HalfFrag& lo) { emu::split_f16(x, hi.r, lo.r); }
 __device__ __forceinline__ floatx4 mfma_16x16x32_f16(const HalfFrag& a, const HalfFrag& b, floatx4 c) {
   float d[4] = {c[0], c[1], c[2], c[3]};
@@ -133,10 +147,13 @@ __device__ __forceinline__ floatx4 mfma_16x16x32_f16(const HalfFrag& a, const Ha
 }
 #endif
 
-__device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+#ifndef CRBM_PHILOX_ROUNDS
+#define CRBM_PHILOX_ROUNDS 7      // anything else (CRBM_JIT_DEFINES) is a timing experiment: the oracle draws seven
+#endif
+__device__ __forceinline__ Philox4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                                  uint32_t k0, uint32_t k1) {
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < CRBM_PHILOX_ROUNDS; ++r) {
     const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
     const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
     const uint32_t n0 = xor3((uint32_t)(p1 >> 32), c1, k0);
@@ -276,7 +293,7 @@ __device__ __forceinline__ void sample_hidden(const float (&z)[C::KP], uint32_t 
   for (int w = 0; w < C::NW; ++w) mask[w] = 0u;
 #pragma unroll
   for (int g = 0; g < C::NGRP; ++g) {
-    const Philox4 rc = philox4x32_10(n, s, rng_word2(kind, strand, 0, (uint32_t)g), step, rng.seed_lo, rng.seed_hi);
+    const Philox4 rc = philox4x32(n, s, rng_word2(kind, strand, 0, (uint32_t)g), step, rng.seed_lo, rng.seed_hi);
     constexpr int kFull = 10;
     const int cnt = C::K - 10 * g < kFull ? C::K - 10 * g : kFull;   // units of this group
     uint32_t not_one = 0u, zero = 0u;     // bit i: unit 10g+i is not certainly 1 / is certainly 0
@@ -310,7 +327,7 @@ __device__ __forceinline__ void sample_hidden(const float (&z)[C::KP], uint32_t 
     const uint32_t amb = not_one & ~zero;   // units of this group that need the fine field
     if constexpr (DEFER) pending[g] = amb;
     if (!DEFER && __any(amb != 0u)) {
-      const Philox4 rf = philox4x32_10(n, s, rng_word2(kind, strand, 1, (uint32_t)g), step, rng.seed_lo, rng.seed_hi);
+      const Philox4 rf = philox4x32(n, s, rng_word2(kind, strand, 1, (uint32_t)g), step, rng.seed_lo, rng.seed_hi);
       auto fix = [&](auto I) {
         constexpr int i = decltype(I)::value;
         const int k = 10 * g + i;
@@ -495,8 +512,8 @@ __device__ __forceinline__ void hidden_uniforms24(uint32_t n, uint32_t s, uint32
                                                   uint32_t step, float (&u)[C::KP]) {
 #pragma unroll
   for (int g = 0; g < C::NGRP; ++g) {
-    const Philox4 rc = philox4x32_10(n, s, rng_word2(kind, strand, 0, (uint32_t)g), step, rng.seed_lo, rng.seed_hi);
-    const Philox4 rf = philox4x32_10(n, s, rng_word2(kind, strand, 1, (uint32_t)g), step, rng.seed_lo, rng.seed_hi);
+    const Philox4 rc = philox4x32(n, s, rng_word2(kind, strand, 0, (uint32_t)g), step, rng.seed_lo, rng.seed_hi);
+    const Philox4 rf = philox4x32(n, s, rng_word2(kind, strand, 1, (uint32_t)g), step, rng.seed_lo, rng.seed_hi);
     auto unit = [&](auto I) {
       constexpr int i = decltype(I)::value;
       const int k = 10 * g + i;
@@ -1401,8 +1418,8 @@ __device__ void gibbs_body(const GibbsArgs& a, int bid = -1) {   // bid: block o
         z = g == 0 ? t : z + t;
       }
       const uint32_t g10 = k / 10u, i10 = k - 10u * g10, step = a.rng.step + (uint32_t)st;
-      const Philox4 rc = philox4x32_10(gn, (uint32_t)s, rng_word2(KIND_CHAIN_H, strand, 0, g10), step, a.rng.seed_lo, a.rng.seed_hi);
-      const Philox4 rf = philox4x32_10(gn, (uint32_t)s, rng_word2(KIND_CHAIN_H, strand, 1, g10), step, a.rng.seed_lo, a.rng.seed_hi);
+      const Philox4 rc = philox4x32(gn, (uint32_t)s, rng_word2(KIND_CHAIN_H, strand, 0, g10), step, a.rng.seed_lo, a.rng.seed_hi);
+      const Philox4 rf = philox4x32(gn, (uint32_t)s, rng_word2(KIND_CHAIN_H, strand, 1, g10), step, a.rng.seed_lo, a.rng.seed_hi);
       const float t = 4096.0f * fast_rcp(1.0f + exp_neg_x(z));
       const float frac = t - (float)philox_field12_dyn(rc, (int)i10);
       const uint32_t one = frac * 4096.0f > (float)philox_field12_dyn(rf, (int)i10) ? 1u : 0u;
@@ -1531,7 +1548,7 @@ __device__ void gibbs_body(const GibbsArgs& a, int bid = -1) {   // bid: block o
           }
         }
         // one Philox call serves the 4 positions of the block (convRBM.py:301-315)
-        const Philox4 r = philox4x32_10(a.rng.seq_offset + (uint32_t)(n0 + nl), (uint32_t)pb,
+        const Philox4 r = philox4x32(a.rng.seq_offset + (uint32_t)(n0 + nl), (uint32_t)pb,
                                         rng_word2(KIND_CHAIN_V, 0, 0, 0), a.rng.step + (uint32_t)st,
                                         a.rng.seed_lo, a.rng.seed_hi);
         uint32_t byte = 0u;
@@ -1919,26 +1936,31 @@ struct UpdateArgs {
 // The kernel is a chain of memory round trips (sums, parameters, velocities -> a few hundred numbers): with
 // NE known the loads of all of a thread's weights are issued before the first is used -- a run-time loop
 // paid one round trip per iteration (three at config #2 with 256 threads: 7.3 us for the launch).
-template <int NE = 0>
-__device__ __forceinline__ void apply_update_body(const UpdateArgs& a, float* nw, bool store) {
+// Sums: how element i of the packed sums is read -- PlainSums: from a.sums; RankSums (update_tables_ipc_body): the
+// ranks' published copies added in rank order.
+struct PlainSums {
+  const float* p;
+  __device__ __forceinline__ float operator()(int i) const { return p[i]; }
+};
+template <int NE = 0, class Sums = PlainSums>
+__device__ __forceinline__ void apply_update_body(const UpdateArgs& a, float* nw, bool store, const Sums& S) {
   const int K = a.K, M = a.M, KAM = K * 4 * M;
-  const float n_d = a.sums[a.n_d], n_m = a.sums[a.n_m];
+  const float n_d = S(a.n_d), n_m = S(a.n_m);
   const float cnt_d = n_d * (float)(a.L_data - M + 1);
   const float cnt_m = n_m * (float)a.Lf;
-  const float* d = a.sums + a.data_off;    // [vh][vh'][h][h'][sw][sb][v]
-  const float* m = a.sums + a.model_off;   // [vh][vh'][h][h'][v]
-  const float* d_vh = d, *d_vhp = d + KAM, *d_h = d + 2 * KAM, *d_hp = d_h + K;
-  const float* d_sw = d + 2 * KAM + 2 * K, *d_sb = d_sw + KAM, *d_v = d_sb + K;
-  const float* m_vh = m, *m_vhp = m + KAM, *m_h = m + 2 * KAM, *m_hp = m_h + K, *m_v = m_hp + K;
+  // offsets into the packed sums: data half [vh][vh'][h][h'][sw][sb][v], model half [vh][vh'][h][h'][v]
+  const int d_vh = a.data_off, d_vhp = d_vh + KAM, d_h = d_vh + 2 * KAM, d_hp = d_h + K;
+  const int d_sw = d_vh + 2 * KAM + 2 * K, d_sb = d_sw + KAM, d_v = d_sb + K;
+  const int m_vh = a.model_off, m_vhp = m_vh + KAM, m_h = m_vh + 2 * KAM, m_hp = m_h + K, m_v = m_hp + K;
   const float q = a.rho;
   struct WeightIn { float dvh, mvh, dvhp, mvhp, dh, dsw, vw, w; };
   auto load_weight = [&](int idx) {
     const int k = idx / (4 * M), al = (idx / M) & 3, j = idx % M;
     const int ridx = (k * 4 + (3 - al)) * M + (M - 1 - j);
     WeightIn in;
-    in.dvh = d_vh[idx]; in.mvh = m_vh[idx];
-    in.dvhp = a.ds ? d_vhp[ridx] : 0.f; in.mvhp = a.ds ? m_vhp[ridx] : 0.f;
-    in.dh = d_h[k]; in.dsw = d_sw[idx]; in.vw = a.vW[idx]; in.w = a.W[idx];
+    in.dvh = S(d_vh + idx); in.mvh = S(m_vh + idx);
+    in.dvhp = a.ds ? S(d_vhp + ridx) : 0.f; in.mvhp = a.ds ? S(m_vhp + ridx) : 0.f;
+    in.dh = S(d_h + k); in.dsw = S(d_sw + idx); in.vw = a.vW[idx]; in.w = a.W[idx];
     return in;
   };
   auto finish_weight = [&](int idx, const WeightIn& in) {
@@ -1972,14 +1994,15 @@ __device__ __forceinline__ void apply_update_body(const UpdateArgs& a, float* nw
     for (int idx = threadIdx.x; idx < KAM; idx += blockDim.x) finish_weight(idx, load_weight(idx));
   }
   for (int k = threadIdx.x; k < K; k += blockDim.x) {
-    float gd = d_h[k] / cnt_d, gm = m_h[k] / cnt_m;
+    const float dh = S(d_h + k);
+    float gd = dh / cnt_d, gm = S(m_h + k) / cnt_m;
     if (a.ds) {
-      gd = 0.5f * (gd + d_hp[k] / cnt_d);
-      gm = 0.5f * (gm + m_hp[k] / cnt_m);
+      gd = 0.5f * (gd + S(d_hp + k) / cnt_d);
+      gm = 0.5f * (gm + S(m_hp + k) / cnt_m);
     }
-    const float p = d_h[k] / cnt_d;
+    const float p = dh / cnt_d;
     const float g = (q / p - (1.f - q) / (1.f - p)) / (float)K;
-    const float reg = -g * d_sb[k] / cnt_d;
+    const float reg = -g * S(d_sb + k) / cnt_d;
     const float v = a.momentum * a.vb[k] + a.lr * (gd - gm - a.lambda_rate * reg);
     const float bn = a.b[k] + v;
     if (store) { a.ovb[k] = v; a.ob[k] = bn; }
@@ -1988,8 +2011,8 @@ __device__ __forceinline__ void apply_update_body(const UpdateArgs& a, float* nw
   if (threadIdx.x < 4) {
     const int al = threadIdx.x;
     const float nd = n_d * (float)a.L_data, nm = n_m * (float)(a.Lf + M - 1);
-    const float gd = d_v[al] / nd + d_v[3 - al] / nd;     // a += a[::-1]  (:345)
-    const float gm = m_v[al] / nm + m_v[3 - al] / nm;
+    const float gd = S(d_v + al) / nd + S(d_v + 3 - al) / nd;     // a += a[::-1]  (:345)
+    const float gm = S(m_v + al) / nm + S(m_v + 3 - al) / nm;
     const float v = a.momentum * a.vc[al] + a.lr * (gd - gm);
     const float cn = a.c[al] + v;
     if (store) { a.ovc[al] = v; a.oc[al] = cn; }
@@ -2013,7 +2036,7 @@ template <class C>
 __device__ void update_tables_body(const UpdateTablesArgs& a) {
   HIP_DYNAMIC_SHARED(float, smem);
   constexpr int KAM = C::K * 4 * C::M;
-  apply_update_body<cdiv(KAM, UPDATE_THREADS) <= 8 ? cdiv(KAM, UPDATE_THREADS) : 0>(a.u, smem, blockIdx.x == 0);
+  apply_update_body<cdiv(KAM, UPDATE_THREADS) <= 8 ? cdiv(KAM, UPDATE_THREADS) : 0>(a.u, smem, blockIdx.x == 0, PlainSums{a.u.sums});
   __syncthreads();
   TablesArgs t;
   t.W = smem; t.b = smem + KAM; t.c = smem + KAM + C::K; t.out = a.tables;
@@ -2034,8 +2057,14 @@ __device__ void update_tables_body(const UpdateTablesArgs& a) {
 // block of every rank's update fetch every peer's sums and poll remote flags.
 // Buffer reuse: a rank writes parity p of a peer's buffer only after its own update of the step before, which
 // waited for that peer's flag of that step -- raised after the peer's update two steps back had read parity p.
-// The wait is bounded (a peer that died must not hang this GPU): on a time-out the kernel raises
-// `status[0]`, later launches do not wait at all, and the host reports it (crbm_ipc_status).
+// The wait is bounded in TIME (the GPU's constant-rate clock, `timeout_ticks`; the host sets it from
+// CRBM_IPC_TIMEOUT_MS, default 30 s): a peer that died must not hang this GPU, and ordinary skew between the ranks'
+// hosts -- a rank that uploads or evaluates while the others already wait -- must not trip it (crbm_amd.crbm.fit
+// also puts a host barrier in front of every epoch's first launch).  A wait that runs out raises `status[0]`,
+// which is sticky: the launch that saw it and every later one apply NO update (parameters and velocities are
+// carried over unchanged, the tables stay), and the host turns the status word into an error at its next
+// synchronisation point (CRBM_ERR_IPC_TIMEOUT) -- the run fails with the last consistent model instead of going on
+// with sums that never arrived.
 // ---------------------------------------------------------------------------
 constexpr int IPC_MAX_RANKS = 8;
 struct IpcArgs {
@@ -2044,10 +2073,26 @@ struct IpcArgs {
   uint32_t* status;                       // [0] != 0: a wait timed out (sticky)
   uint32_t expect;
   int32_t nranks, count;
+  unsigned long long timeout_ticks;       // of realtime_ticks()
 };
 struct UpdateIpcArgs {
   UpdateTablesArgs ut;
   IpcArgs ipc;
+};
+
+// element i of the all-reduced sums: the R published copies added IN RANK ORDER (every rank forms the same fp32
+// sum); all loads of an element are in flight together, nothing is staged in LDS
+struct RankSums {
+  const IpcArgs* ipc;
+  __device__ __forceinline__ float operator()(int i) const {
+    float v[IPC_MAX_RANKS];
+#pragma unroll
+    for (int r = 0; r < IPC_MAX_RANKS; ++r) v[r] = r < ipc->nranks ? load_system(ipc->sums[r] + i) : 0.f;
+    float t = v[0];
+#pragma unroll
+    for (int r = 1; r < IPC_MAX_RANKS; ++r) t += v[r];          // the zeros of absent ranks change nothing
+    return t;
+  }
 };
 
 template <class C>
@@ -2055,30 +2100,35 @@ __device__ void update_tables_ipc_body(const UpdateIpcArgs& a) {
   HIP_DYNAMIC_SHARED(float, smem);
   constexpr int KAM = C::K * 4 * C::M;
   const IpcArgs& ipc = a.ipc;
-  float* ssum = smem;                                // [count], then the new W, b, c
-  float* nw = smem + ((ipc.count + 3) & ~3);
-  if ((int)threadIdx.x < ipc.nranks && load_system(ipc.status) == 0u) {
+  float* nw = smem;                                                       // the new W, b, c
+  uint32_t* gave_up = reinterpret_cast<uint32_t*>(smem + KAM + C::K + 4);   // this block does not apply the step
+  if (threadIdx.x == 0) *gave_up = load_system(ipc.status);              // an earlier launch timed out: sticky
+  __syncthreads();
+  if ((int)threadIdx.x < ipc.nranks && *gave_up == 0u) {
     const uint32_t* f = ipc.flags[threadIdx.x];
-    int spins = 0;
-    while ((int32_t)(load_system(f) - ipc.expect) < 0) {       // flags only grow (step numbers)
-      if (++spins > (1 << 18)) { store_system(ipc.status, 1u); break; }
+    const uint64_t t0 = realtime_ticks();
+    while ((int32_t)(load_system(f) - ipc.expect) < 0) {                  // flags only grow (step numbers)
+      if (realtime_ticks() - t0 > ipc.timeout_ticks) {
+        store_system(ipc.status, 1u);
+        atomicOr(gave_up, 1u);
+        break;
+      }
       short_sleep();
     }
+    fence_acquire_system();                                               // the sums behind the flag, not an older copy
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < ipc.count; i += blockDim.x) {
-    float v[IPC_MAX_RANKS];
-#pragma unroll
-    for (int r = 0; r < IPC_MAX_RANKS; ++r) v[r] = r < ipc.nranks ? load_system(ipc.sums[r] + i) : 0.f;   // all in flight
-    float t = v[0];
-#pragma unroll
-    for (int r = 1; r < IPC_MAX_RANKS; ++r) t += v[r];          // rank order; the zeros of absent ranks change nothing
-    ssum[i] = t;
+  const UpdateArgs& u = a.ut.u;
+  if (*gave_up != 0u) {
+    // the host has already made the other buffer set the current one: carry the state over unchanged
+    if (blockIdx.x == 0) {
+      for (int i = threadIdx.x; i < KAM; i += blockDim.x) { u.oW[i] = u.W[i]; u.ovW[i] = u.vW[i]; }
+      for (int i = threadIdx.x; i < C::K; i += blockDim.x) { u.ob[i] = u.b[i]; u.ovb[i] = u.vb[i]; }
+      if (threadIdx.x < 4) { u.oc[threadIdx.x] = u.c[threadIdx.x]; u.ovc[threadIdx.x] = u.vc[threadIdx.x]; }
+    }
+    return;
   }
-  __syncthreads();
-  UpdateArgs u = a.ut.u;
-  u.sums = ssum;
-  apply_update_body<cdiv(KAM, UPDATE_THREADS) <= 8 ? cdiv(KAM, UPDATE_THREADS) : 0>(u, nw, blockIdx.x == 0);
+  apply_update_body<cdiv(KAM, UPDATE_THREADS) <= 8 ? cdiv(KAM, UPDATE_THREADS) : 0>(u, nw, blockIdx.x == 0, RankSums{&ipc});
   __syncthreads();
   TablesArgs t;
   t.W = nw; t.b = nw + KAM; t.c = nw + KAM + C::K; t.out = a.ut.tables;
@@ -2378,7 +2428,7 @@ __global__ void __launch_bounds__(256) vgh_dense_kernel(VghArgs a) {
         a.prob[o] = e0 * inv; a.prob[o + a.L] = e1 * inv; a.prob[o + 2 * a.L] = e2 * inv; a.prob[o + 3 * a.L] = e3 * inv;
       }
       if (a.sample) {
-        const Philox4 r = philox4x32_10(a.rng.seq_offset + (uint32_t)nn, (uint32_t)(p >> 2),
+        const Philox4 r = philox4x32(a.rng.seq_offset + (uint32_t)nn, (uint32_t)(p >> 2),
                                         rng_word2(a.kind, 0, 0, 0), a.rng.step, a.rng.seed_lo, a.rng.seed_hi);
         const float t = u01(philox_pick(r, p & 3)) * sum;
         const int l = (t >= e0) + (t >= e0 + e1) + (t >= (e0 + e1) + e2);
@@ -2406,7 +2456,7 @@ __global__ void __launch_bounds__(1024) reduce_publish_pair_kernel(ReducePair p,
   wait_vector_memory();
   __syncthreads();
   if (threadIdx.x == 0) {
-    const uint32_t prev = atomicAdd(t.ticket, 1u);
+    const uint32_t prev = ticket_add(t.ticket);
     if (prev == gridDim.x * gridDim.y - 1u) {
       atomicExch(t.ticket, 0u);
       fence_system();
@@ -2419,7 +2469,7 @@ __global__ void __launch_bounds__(1024) reduce_partials_pair_kernel(ReducePair p
   reduce_partials_body<false>(p.half[blockIdx.y]);
 }
 
-__global__ void apply_update_kernel(UpdateArgs a) { apply_update_body<0>(a, nullptr, true); }   // one block, in place
+__global__ void apply_update_kernel(UpdateArgs a) { apply_update_body<0>(a, nullptr, true, PlainSums{a.sums}); }   // one block, in place
 
 // IPC all-reduce: this rank's sums of the step (formed in d_sums) -> its slot of every rank's buffer, then its
 // flags (one block)

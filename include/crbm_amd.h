@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CRBM_AMD_ABI_VERSION 2
+#define CRBM_AMD_ABI_VERSION 3
 
 typedef enum crbm_status {
   CRBM_OK = 0,
@@ -41,14 +41,15 @@ typedef enum crbm_status {
   CRBM_ERR_NOT_ONEHOT = -3,   /* visible data is not exactly one-hot      */
   CRBM_ERR_NOT_BINARY = -4,   /* hidden state is not exactly 0/1          */
   CRBM_ERR_RCCL = -5,         /* an RCCL call failed / RCCL not loadable   */
-  CRBM_ERR_NO_GPU = -6        /* no usable HIP device                      */
+  CRBM_ERR_NO_GPU = -6,       /* no usable HIP device                      */
+  CRBM_ERR_IPC_TIMEOUT = -7   /* mapped-buffer all-reduce: a peer's sums never arrived (crbm_ipc_*) */
 } crbm_status;
 
 /* Hyper-parameters: the reference constructor's arguments
  * (convRBM.py:68-71) plus what Theano kept implicit. */
 typedef struct crbm_config {
   int32_t num_motifs;          /* K                                   :111 */
-  int32_t motif_length;        /* M  (1..32)                          :112 */
+  int32_t motif_length;        /* M  (1..64)                          :112 */
   int32_t input_dims;          /* A, must be 4                        :113 */
   int32_t doublestranded;      /* 0/1                                 :114 */
   int32_t batchsize;           /* number of persistent fantasy chains :115 */
@@ -217,7 +218,11 @@ int crbm_comm_broadcast_state(crbm_handle* h, int32_t root);
  * buffer and adds the slots in rank order (bit-identical on all ranks): no launch at all in place of
  * ncclAllReduce, and no read of remote memory on the critical path.  Alternative to crbm_comm_init, not to be
  * combined with it; replicas must start identical (crbm_amd.dist.attach ships rank 0's parameters first).
- * crbm_ipc_status: *timed_out != 0 if a wait for a peer ever ran out (results are invalid from then on). */
+ * The wait is bounded in time (CRBM_IPC_TIMEOUT_MS, default 30 000, on the GPU's wall clock): once it has run out
+ * no further update is applied (the parameters stay those of the last complete step) and every training entry
+ * point and crbm_sync return CRBM_ERR_IPC_TIMEOUT; crbm_ipc_status reads the same word (*timed_out != 0).
+ * While this form is attached the sums of a step go straight into the mapped buffers: what crbm_train_local-style
+ * readers would find in the handle's own sums buffer is not current. */
 #define CRBM_IPC_HANDLE_BYTES 64
 int crbm_ipc_export(crbm_handle* h, uint8_t handle[CRBM_IPC_HANDLE_BYTES]);
 int crbm_ipc_attach(crbm_handle* h, const uint8_t* handles, int32_t nranks, int32_t rank);

@@ -14,7 +14,7 @@
  * itself cannot run here (Theano absent), so this is a restatement, not Theano.
  * Nothing in crbm_amd/ links or calls it.
  *
- * Randomness: the same Philox-4x32-10 counters as the oracle and the kernels.
+ * Randomness: the same Philox-4x32-7 counters as the oracle and the kernels.
  */
 #include <math.h>
 #include <stdint.h>
@@ -24,9 +24,9 @@
 #include <omp.h>
 #endif
 
-static void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+static void philox4x32_7(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
                           uint32_t out[4]) {
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < 7; ++r) {
     const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
     const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
     const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
@@ -101,7 +101,7 @@ void crbm_cpu_gibbs_step(const float* W, const float* b, const float* c, int K, 
         const float e0 = expf(y0 - mx), e1 = expf(y1 - mx), e2 = expf(y2 - mx), e3 = expf(y3 - mx);
         const float sum = (e0 + e1) + (e2 + e3);
         uint32_t r[4];
-        philox4x32_10(seq_offset + (uint32_t)nn, (uint32_t)(p >> 2), 2u << 28, step, k0, k1, r);
+        philox4x32_7(seq_offset + (uint32_t)nn, (uint32_t)(p >> 2), 2u << 28, step, k0, k1, r);
         const float t = u01(r[p & 3]) * sum;
         const int l = (t >= e0) + (t >= e0 + e1) + (t >= (e0 + e1) + e2);
         vn[p] = l == 0; vn[L + p] = l == 1; vn[2 * L + p] = l == 2; vn[3 * L + p] = l == 3;
@@ -124,8 +124,8 @@ void crbm_cpu_gibbs_step(const float* W, const float* b, const float* c, int K, 
             uint32_t rc[4], rf[4];
             const float p = 1.0f / (1.0f + expf(-x[s]));
             const uint32_t w2 = (1u << 28) | ((uint32_t)strand << 24) | (uint32_t)(k / 10);
-            philox4x32_10(seq_offset + (uint32_t)nn, (uint32_t)s, w2, step, k0, k1, rc);
-            philox4x32_10(seq_offset + (uint32_t)nn, (uint32_t)s, w2 | (1u << 16), step, k0, k1, rf);
+            philox4x32_7(seq_offset + (uint32_t)nn, (uint32_t)s, w2, step, k0, k1, rc);
+            philox4x32_7(seq_offset + (uint32_t)nn, (uint32_t)s, w2 | (1u << 16), step, k0, k1, rf);
             const float u = (float)(field12(rc, k % 10) * 4096u + field12(rf, k % 10)) * 5.9604644775390625e-8f;
             out[(size_t)k * Lh + s] = p > u ? 1.0f : 0.0f;
             if (pout) pout[(size_t)k * Lh + s] = p;

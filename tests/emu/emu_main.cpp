@@ -394,8 +394,9 @@ int emu_ipc_update(int id, int nranks, const float* rank_sums, int count, float*
       a.ipc.flags[r] = flags + (r < nranks ? r : 0);
     }
     a.ipc.status = status; a.ipc.expect = step_value; a.ipc.nranks = nranks; a.ipc.count = count;
+    a.ipc.timeout_ticks = 300000;    // 0.3 s of the emulator's microsecond clock
     emu::launch([&] { update_tables_ipc_body<C>(a); }, dim3(grid), dim3(threads),
-                (size_t)(((count + 3) & ~3) + C::K * 4 * C::M + C::K + 4) * 4);
+                (size_t)(C::K * 4 * C::M + C::K + 4 + 4) * 4);
   });
   return 0;
 }

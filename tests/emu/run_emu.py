@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 from oracle.crbm_oracle import (OracleCRBM, synthetic_onehot, hidden_uniforms, visible_uniforms,  # noqa: E402
-                                KIND_API_H, KIND_API_V, letters_of)
+                                KIND_API_H, KIND_API_V, KIND_CHAIN_H, KIND_CHAIN_V, letters_of)
 
 lib = ctypes.CDLL(os.path.join(HERE, os.environ.get("CRBM_EMU_LIB", "libcrbm_emu.so")))
 F = ctypes.POINTER(ctypes.c_float)
@@ -254,6 +254,48 @@ def run_gibbs(cid, o, tables, S, steps, grid, threads, sparse=1, ones=None):
     return unpack_hidden(hm, K), (unpack_hidden(hmp, K) if ds else None), v, vout, lws
 
 
+TIE = 1e-6
+
+
+def replay_chain_ties(cid, o, tables, S, steps, grid, threads, sparse):
+    """`steps` Gibbs steps one at a time, the emulated kernel restarted from the oracle's state before each: every letter
+    and every hidden unit that differs from the oracle's must sit on a p == u tie (|p - u| < 1e-6: the only place where
+    the kernel's float32 and the oracle's float64 may decide differently).  Returns the number of ties met."""
+    ds = o.doublestranded
+    B, K, _, Lf = o.fantasy_h.shape
+    Lv = Lf + o.motif_length - 1
+    idx = np.arange(B) + o.seq_offset
+    ties = 0
+    for _ in range(steps):
+        t = o.gibbs_step
+        gh, ghp, gv, _, _ = run_gibbs(cid, o, tables, S, 1, grid, threads, sparse)
+        uv = visible_uniforms(o.seed, t, idx, Lv, KIND_CHAIN_V)
+        Pv, v = o._computeVgivenH(o.fantasy_h, o.fantasy_h_prime if ds else None, uv)
+        uh = hidden_uniforms(o.seed, t, idx, K, Lf, 0, KIND_CHAIN_H)
+        P, h = o._computeHgivenV(v, False, uh)
+        pairs = [(gh, h, P, uh)]
+        if ds:
+            uhp = hidden_uniforms(o.seed, t, idx, K, Lf, 1, KIND_CHAIN_H)
+            Pp, hp = o._computeHgivenV(v, True, uhp)
+            pairs.append((ghp, hp, Pp, uhp))
+        badv = (gv != v).any(axis=2)[:, 0]
+        if badv.any():
+            cum = np.cumsum(Pv[:, 0], axis=1)[:, :3]
+            gap = np.min(np.abs(cum - uv[:, None, :]), axis=1)
+            assert np.all(gap[badv] < TIE), "visible sample differs away from a tie"
+            ties += int(badv.sum())
+        clean = ~badv.any(axis=1)
+        for got, want, prob, u in pairs:
+            bad = (got != want) & clean[:, None, None, None]
+            if bad.any():
+                assert np.all(np.abs(prob - u)[bad] < TIE), "hidden sample differs away from a tie"
+                ties += int(bad.sum())
+        o.fantasy_h, o.fantasy_h_prime = h, (hp if ds else o.fantasy_h_prime)
+        o.last_v_model = v
+        o.gibbs_step += 1
+    return ties
+
+
 def test_gibbs(cases=None):
     for cid in (cases or GIBBS_CASES):
         info = case_info(cid)
@@ -268,11 +310,19 @@ def test_gibbs(cases=None):
                     o.fantasy_h_prime = rng.binomial(1, 0.1, size=o.fantasy_h.shape).astype(np.float64)
                 tables = build_tables(cid, o)
                 ones = np.zeros(grid * (threads // 64), dtype=np.uint32)
+                start = (o.fantasy_h.copy(), o.fantasy_h_prime.copy() if ds else None, o.gibbs_step)
                 h, hp, v, _, _ = run_gibbs(cid, o, tables, S, steps, grid, threads, sparse, ones)
                 o.gibbs_steps(steps)
                 mism = int((h != o.fantasy_h).sum()) + (int((hp != o.fantasy_h_prime).sum()) if ds else 0)
                 mism_v = int((v != o.last_v_model).sum())
-                assert mism == 0 and mism_v == 0, ("gibbs mismatch", cid, sparse, mism, mism_v)
+                if mism or mism_v:
+                    # a chain may leave the oracle's only through a p == u tie: replay step by step from identical states
+                    o.fantasy_h, o.gibbs_step = start[0], start[2]
+                    if ds:
+                        o.fantasy_h_prime = start[1]
+                    ties = replay_chain_ties(cid, o, tables, S, steps, grid, threads, sparse)
+                    assert 1 <= ties <= 3, ("gibbs mismatch without a tie", cid, sparse, mism, mism_v, ties)
+                    print("gibbs: %d tie(s) in case %d" % (ties, cid))
                 assert o.fantasy_h.sum() > 0
                 assert int(ones.sum()) == int(h.sum()) + (int(hp.sum()) if ds else 0), "activity monitor"
         print("gibbs ok", cid, info)
@@ -476,6 +526,17 @@ def test_two_ranks():
                                             ctypes.c_float(o.learning_rate), ctypes.c_float(o.momentum), ctypes.c_float(o.rho),
                                             ctypes.c_float(o.lambda_rate), fp(np.zeros_like(new_tables)), 1, 64, 1)
                     assert rc == 0 and status2[0] == 1 and flags2[1] == 0
+                    for x, y in zip(old, scratch):        # ... and no update is applied: the state is carried over unchanged
+                        np.testing.assert_array_equal(x, y)
+                    # the status word is sticky: a later launch whose peers all delivered still applies nothing
+                    scratch = [np.full_like(x, 7.0) for x in old]
+                    rc = lib.emu_ipc_update(cid, world, fp(np.concatenate(per_rank)), count, fp(bufs.copy()), stride, up(flags2), up(status2),
+                                            step_no, *[fp(x) for x in old], *[fp(x) for x in scratch], L, Lf,
+                                            ctypes.c_float(o.learning_rate), ctypes.c_float(o.momentum), ctypes.c_float(o.rho),
+                                            ctypes.c_float(o.lambda_rate), fp(np.zeros_like(new_tables)), 2, 128, -1)
+                    assert rc == 0 and status2[0] == 1
+                    for x, y in zip(old, scratch):
+                        np.testing.assert_array_equal(x, y)
             else:
                 lib.emu_update_tables(cid, fp(total), *[fp(x) for x in old], *[fp(x) for x in nxt], L, Lf,
                                       ctypes.c_float(o.learning_rate), ctypes.c_float(o.momentum), ctypes.c_float(o.rho),

@@ -9,6 +9,7 @@
 #include <pthread.h>
 #include <stdint.h>
 #include <string.h>
+#include <time.h>
 
 #include <algorithm>
 
@@ -132,6 +133,12 @@ static inline void __builtin_amdgcn_sched_barrier(int) {}
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 
 namespace emu {
+// stand-in for the GPU's constant-rate clock (crbm_kernels.h: realtime_ticks): microseconds
+static inline uint64_t realtime_ticks() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (uint64_t)ts.tv_sec * 1000000ull + (uint64_t)ts.tv_nsec / 1000ull;
+}
 static inline float h2f(uint16_t h) { return _cvtsh_ss(h); }
 static inline uint16_t f2h(float f) { return _cvtss_sh(f, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC); }
 // x = hi + lo, both f16 (crbm_kernels.h: split_f16)

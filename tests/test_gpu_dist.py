@@ -29,13 +29,14 @@ def _free_port():
     return p
 
 
-def _run_ranks(mode, tmp_path, world=2):
+def _run_ranks(mode, tmp_path, world=2, extra_env=None, load=True):
     port = _free_port()
     outs = [str(tmp_path / ("rank%d.npz" % r)) for r in range(world)]
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.update(extra_env or {})
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), mode, outs[r]],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = []
@@ -49,6 +50,8 @@ def _run_ranks(mode, tmp_path, world=2):
         logs.append(out.decode(errors="replace"))
     for r, p in enumerate(procs):
         assert p.returncode == 0, "rank %d failed:\n%s" % (r, logs[r][-3000:])
+    if not load:
+        return outs, logs
     return [np.load(o, allow_pickle=True) for o in outs], logs
 
 
@@ -110,6 +113,33 @@ def test_two_processes_ipc_allreduce_equal_single_rank(tmp_path):
     res, logs = _run_ranks("ipc", tmp_path)
     assert "Epoch 1: FE=" in logs[0] and "Epoch" not in logs[1]        # rank 0 alone evaluates and prints
     _check_against_single(res, tmp_path)
+
+
+def test_ipc_allreduce_host_skew_stays_out_of_the_device_wait(tmp_path):
+    """Rank 0 enters fit() 1.5 s late and spends 1.5 s in its per-epoch evaluation while rank 1 is already at the next
+    epoch -- with a device-side bound of 0.3 s.  The host barrier in front of every epoch's first launch (crbm.fit)
+    keeps that skew on the control plane: no time-out, result equal to the one-rank run."""
+    res, logs = _run_ranks("ipc_skew", tmp_path, extra_env={"CRBM_IPC_TIMEOUT_MS": "300"})
+    assert "Epoch 1: FE=" in logs[0]
+    _check_against_single(res, tmp_path)
+
+
+def test_ipc_allreduce_waits_seconds_on_the_device(tmp_path):
+    """Through the C-ABI without any barrier: rank 0 starts every epoch 1.5 s after rank 1, whose update launch waits
+    that long on the GPU for rank 0's flag.  The wait is bounded by the GPU's wall clock (default 30 s), not by an
+    iteration count: no time-out, result equal to the one-rank run."""
+    res, _ = _run_ranks("ipc_devwait", tmp_path)
+    _check_against_single(res, tmp_path)
+
+
+def test_ipc_allreduce_dead_rank_times_out_and_the_gpu_stays_usable(tmp_path):
+    """Rank 1 exits after epoch 0.  Rank 0's next epoch returns CRBM_ERR_IPC_TIMEOUT within the bound (0.5 s per
+    waiting launch), its parameters are those of the last complete step, and a fresh model trains on the same GPU."""
+    outs, logs = _run_ranks("ipc_dead", tmp_path, extra_env={"CRBM_IPC_TIMEOUT_MS": "500"}, load=False)
+    assert "survivor ok" in logs[0], logs[0][-2000:]
+    r0 = np.load(outs[0])
+    assert int(r0["survived"]) == 1 and float(r0["took"]) < 20.0
+    assert not os.path.exists(outs[1])                                   # rank 1 really left early
 
 
 def test_two_gpu_rccl_fit_equals_single_rank(tmp_path):

@@ -18,19 +18,28 @@ def sigmoid(act):                      # reference tests/testcrbm.py:8-9
 
 
 # --------------------------------------------------------------------------
-# Philox-4x32-10 known-answer vectors (Random123 kat_vectors, published)
+# Philox-4x32 known-answer vectors (Random123 kat_vectors, published) for the seven rounds the
+# kernels, the oracle and the C port draw, and for the ten-round variant of the same routine
 # --------------------------------------------------------------------------
-@pytest.mark.parametrize("ctr,key,expect", [
-    ((0, 0, 0, 0), (0, 0),
+@pytest.mark.parametrize("rounds,ctr,key,expect", [
+    (7, (0, 0, 0, 0), (0, 0),
+     (0x5f6fb709, 0x0d893f64, 0x4f121f81, 0x4f730a48)),
+    (7, (0xffffffff,) * 4, (0xffffffff,) * 2,
+     (0x5207ddc2, 0x45165e59, 0x4d8ee751, 0x8c52f662)),
+    (7, (0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+     (0x4dfccaba, 0x190a87f0, 0xc47362ba, 0xb6b5242a)),
+    (10, (0, 0, 0, 0), (0, 0),
      (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
-    ((0xffffffff,) * 4, (0xffffffff,) * 2,
+    (10, (0xffffffff,) * 4, (0xffffffff,) * 2,
      (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
-    ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+    (10, (0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
      (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)),
 ])
-def test_philox_known_answers(ctr, key, expect):
-    out = philox4x32(*ctr, *key)
+def test_philox_known_answers(rounds, ctr, key, expect):
+    out = philox4x32(*ctr, *key, rounds=rounds)
     assert tuple(int(x) for x in out) == expect
+    if rounds == 7:                                   # ... and seven is what everything draws by default
+        assert tuple(int(x) for x in philox4x32(*ctr, *key)) == expect
 
 
 def test_uniform_layout():
