@@ -87,6 +87,28 @@ def build_model(cfg, world, rank, device):
     return model
 
 
+def cpu_share(hw_threads):
+    """CPUs this process can really use: the affinity mask, capped by the cgroup's CPU quota (v2 cpu.max, v1 cfs quota)."""
+    n = hw_threads
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / per + 0.5)))
+        except Exception:
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(cfg, budget_s=10.0):
     """The oracle's C restatement (oracle/crbm_cpu.c) timed on this host's cores on the same
     workload: whole 8192-chain batch on all cores, a 1/16 batch on one core, plus the NumPy
@@ -101,7 +123,8 @@ def cpu_baseline(cfg, budget_s=10.0):
     c = np.zeros(4, dtype=np.float32)
     F = ctypes.POINTER(ctypes.c_float)
     P = lambda a: a.ctypes.data_as(F)
-    cores = lib.crbm_cpu_max_threads()
+    hw_threads = lib.crbm_cpu_max_threads()
+    cores = cpu_share(hw_threads)          # what this process may actually use (affinity mask, cgroup quota)
 
     def run(nchains, threads, budget, max_steps):
         h = np.zeros((nchains, K, Lh), dtype=np.float32)
@@ -127,6 +150,9 @@ def cpu_baseline(cfg, budget_s=10.0):
     sub = max(64, n // 16)
     done1, dt1 = run(sub, 1, 3.0, 50)
     out = {"value": done / dt, "unit": "8192-chain Gibbs steps/s", "cores": int(cores), "kind": "port",
+           "hardware_threads_of_the_host": int(hw_threads),
+           "cores_note": "threads used = the CPU share of this process (scheduler affinity mask and cgroup CPU quota), "
+                         "not the host's hardware threads: a GPU box hands a job a fraction of its host",
            "sample": "%d Gibbs steps of the full %d-chain batch (oracle/crbm_cpu.c, dense fp32, OpenMP, %d threads), %.1f s"
                      % (done, n, cores, dt),
            "value_1thread": (done1 / dt1) * sub / n,
@@ -156,6 +182,180 @@ def cpu_baseline(cfg, budget_s=10.0):
     return out
 
 
+def roofline_object(name, cfg, info, step_s, counters, counters_src, copy_gbs, state_bytes, us_per_step_k16=None):
+    """The roofline object of the chain kernel at one configuration.  step_s: HIP-event time of one launch step (all
+    chains advanced by cfg["k"] Gibbs steps) in seconds; counters: {name: mean per launch} from measure_pmc or None."""
+    k = cfg["k"]
+    parts = max(1, int(info.chain_parts))
+    alg_bytes = algorithmic_bytes_per_seq(cfg["K"], cfg["M"], cfg["L"], cfg["ds"]) * cfg["chains"] * k
+    alg_gbs = alg_bytes / step_s / 1e9
+    # Counters of the chain kernel: measured on this box by the child runs, else the tracked summary of an earlier box
+    # (profiles/gibbs_traffic.json), named as such
+    if counters is None:
+        tfile = os.path.join(ROOT, "profiles", "gibbs_traffic.json")
+        try:
+            t = json.load(open(tfile)).get(name, {})
+            counters = t.get("counters")
+            counters_src = "NOT measured in this run (%s); quoted from %s" % (counters_src, t.get("source"))
+            if counters and int(t.get("chain_parts", 1)) != parts:
+                counters, counters_src = None, counters_src + " -- dropped: collected with another partitioning of the launch"
+        except Exception:
+            counters = None
+    roof = {"kernel": "crbm_gibbs_sparse" if info.gibbs_sparse else "crbm_gibbs",   # name in the rocprofv3 summaries
+            "avg_launch_us": 1e6 * step_s, "counters_source": counters_src,
+            "launches_per_step": parts,
+            "launch_note": ("one step of the whole batch = %d launches of this kernel, one per partition of the chains, on streams of "
+                            "their own; they overlap, so avg_launch_us (HIP events over the timed region / steps: what the step costs) "
+                            "is not the duration of one launch -- kernel_avg_us is (rocprofv3 --kernel-trace --stats of the same "
+                            "launches, measured in this run)" % parts) if parts > 1 else
+                           "one step of the whole batch = one launch of this kernel",
+            "measured_copy_gbs": copy_gbs,
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "algorithmic_gbs": alg_gbs, "algorithmic_frac": alg_gbs / HBM_PEAK_GBS,
+            "algorithmic_note": "SURVEY 8(d) bytes of the reference's dense fp32 layout / step time / 8 TB/s: an "
+                                "equivalent-dense rate, not a bandwidth utilisation (the chain state is bit-packed, so it may "
+                                "exceed 1); north_star's '>= 50 % of HBM roofline' is stated in these units",
+            "state_bytes_per_launch": state_bytes,
+            "us_per_step_at_16_steps_per_launch": us_per_step_k16}
+    if counters:
+        # All counters are means per LAUNCH of the kernel (one partition); a step is `parts` of them.
+        # HBM bytes: 2 x FETCH_SIZE + WRITE_SIZE (KB) -- gfx950 tallies a wide streaming read at half its bytes
+        # (MI355X_MICROARCH.md, HBM).  VALU issue: SQ_ACTIVE_INST_VALU counts quad-cycles in which a wave has a
+        # vector instruction in issue; summed over waves / 1024 SIMDs = cycles a SIMD's vector issue is busy.
+        # The step in shader cycles: its HIP-event time x the shader clock, the clock taken from the same counter pass
+        # (SQ_BUSY_CYCLES / 32 shader engines over the duration of the serialised dispatches).
+        traffic = parts * (2.0 * counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024.0
+        launch_cycles = counters["SQ_BUSY_CYCLES"] / N_SE
+        serial_us = counters.get("SERIAL_NS", 0.0) / 1e3
+        clock_mhz = launch_cycles / serial_us if serial_us > 0 else None
+        valu_cycles = parts * 4.0 * counters["SQ_ACTIVE_INST_VALU"] / N_SIMD
+        if parts == 1 or clock_mhz is None:
+            step_cycles = parts * launch_cycles          # one launch = one step: both counters of the same launches, no clock needed
+            clock_mhz = step_cycles / (1e6 * step_s)
+        else:
+            step_cycles = 1e6 * step_s * clock_mhz
+        roof.update({
+            "bound": "valu_issue", "achieved": valu_cycles, "peak": step_cycles,
+            "unit": "shader cycles per step: a SIMD's vector-issue-busy cycles, summed over the step's launches (achieved) vs the step (peak)",
+            "frac": valu_cycles / step_cycles,
+            "traffic": traffic, "hbm_actual_gbs": traffic / step_s / 1e9,
+            "hbm_actual_frac": traffic / step_s / 1e9 / HBM_PEAK_GBS,
+            "valu_wave_insts_per_launch": counters["SQ_INSTS_VALU"],
+            "valu_wave_insts_per_step": parts * counters["SQ_INSTS_VALU"],
+            "valu_trans_insts_per_launch": counters.get("SQ_INSTS_VALU_TRANS_F32"),
+            "valu_cycles_per_wave_inst": 4.0 * counters["SQ_ACTIVE_INST_VALU"] / counters["SQ_INSTS_VALU"],
+            "valu_issue_us": valu_cycles / clock_mhz,
+            "shader_clock_mhz_during_launch": clock_mhz,
+            "kernel_serialised_us": serial_us or None,
+            "kernel_avg_us": (counters["TRACE_AVG_NS"] / 1e3) if counters.get("TRACE_AVG_NS") else None,
+            "kernel_trace_calls": counters.get("TRACE_CALLS"),
+            "lds_bank_conflict_share": (counters["SQ_LDS_BANK_CONFLICT"] / counters["SQ_LDS_IDX_ACTIVE"])
+                                       if counters.get("SQ_LDS_IDX_ACTIVE") else None,
+            "note": "the kernel is bound by vector-instruction issue (and the LDS gathers behind it), not by HBM: "
+                    "frac = SIMD vector-issue-busy cycles / step cycles from PMC counters of the same kernel on this box "
+                    "(counter collection serialises the launches; with partitioned launches the step's cycles are its HIP-event "
+                    "time x the clock those serialised launches ran at); hbm_actual_frac prices the measured HBM bytes against 8 TB/s"})
+    else:
+        roof.update({"bound": "valu_issue", "achieved": None, "peak": None, "unit": "shader cycles per step",
+                     "frac": None, "traffic": None, "note": "no counters available: " + str(counters_src)})
+    return roof
+
+
+def launch_object(info):
+    return {"grid": info.gibbs_grid, "block": info.gibbs_block, "chains_per_tile": info.gibbs_seqs_per_tile,
+            "lds_bytes": info.gibbs_lds_bytes, "table_group": info.group, "chain_parts": max(1, int(info.chain_parts)),
+            "note": "geometry of ONE launch of the chain kernel; chain_parts of them (one per partition of the chains, each on a "
+                    "stream of its own) make a step of the whole batch"}
+
+
+def train_bound_note(name):
+    what = {"cfg2": "the whole local phase is one launch, crbm_train_local (chain + model statistics + data statistics), which keeps a "
+                    "SIMD's vector issue busy for about 0.77 of its time and moves about 21 MB of HBM per step",
+            "cfg4": "chain launch (5 Gibbs steps), data-half and model-half statistics are three launches; the step moves a few hundred "
+                    "MB of HBM (packed chains and letters)",
+            "cfg5": "chain launch, data-half and model-half statistics are three launches of similar length; the step moves about "
+                    "0.15 GB of HBM (packed chains and letters)"}.get(name, "")
+    return ("equivalent-dense rate like roofline.algorithmic_frac, not a bandwidth utilisation: the step is bound by vector-instruction "
+            "issue, not by HBM -- " + what + " (rocprofv3 PMC summaries per config under profiles/)")
+
+
+def other_config(name, pmc, pmc_note, copy_gbs, steps=40, warmup=10):
+    """Short timed run of another BASELINE configuration on this GPU (world size 1): chain launches and training steps on
+    the driver's clock, with the same roofline object as the headline (counters from the in-run rocprofv3 children)."""
+    from crbm_amd import _lib
+    from crbm_amd._lib import fptr
+    cfg = CONFIGS[name]
+    k = cfg["k"]
+    model = build_model(cfg, 1, 0, 0)
+    h = model._h()
+    lib = model._lib
+    burn = max(1, 300 // k)
+    for _ in range(burn):
+        model._call("crbm_gibbs_steps_async", k)
+    model._call("crbm_sync")
+    ms = ctypes.c_float()
+    model._call("crbm_time_gibbs", k, warmup, ctypes.byref(ms))
+    model._call("crbm_sync")
+    t0 = time.perf_counter()
+    model._call("crbm_time_gibbs", k, steps, ctypes.byref(ms))
+    wall = time.perf_counter() - t0
+    info = _lib.CrbmLaunchInfo()
+    lib.crbm_get_launch_info(h, ctypes.byref(info))
+    step_s = ms.value / 1e3 / steps
+    out = {"workload": name + ": " + cfg["desc"], "launches": steps, "warmup_launches": warmup + burn,
+           "gibbs_steps_per_launch": k,
+           "ms_per_launch": 1e3 * wall / steps, "device_ms_per_launch": 1e3 * step_s,
+           "gibbs_steps_per_s": k * steps / wall,
+           "roofline": roofline_object(name, cfg, info, step_s, pmc, pmc_note, copy_gbs, int(lib.crbm_gibbs_state_bytes(h))),
+           "launch": launch_object(info)}
+    n = cfg["chains"]
+    D = synthetic_onehot(n, cfg["L"], seed=1234)
+    model._call("crbm_dataset_upload", fptr(D), n, cfg["L"])
+    tsteps, twarm = (40, 20) if name == "cfg4" else (100, 50)
+    model._call("crbm_time_train", 0, n, twarm, ctypes.byref(ms))
+    model._call("crbm_sync")
+    t1 = time.perf_counter()
+    model._call("crbm_time_train", 0, n, tsteps, ctypes.byref(ms))
+    twall = time.perf_counter() - t1
+    tb = n * (4 * 4 * cfg["L"] + k * algorithmic_bytes_per_seq(cfg["K"], cfg["M"], cfg["L"], cfg["ds"]))
+    out["train"] = {"ms_per_train_step": ms.value / tsteps, "wall_ms_per_train_step": 1e3 * twall / tsteps,
+                    "steps": tsteps, "warmup_steps": twarm, "cd_k": k, "global_batch": n, "all_reduce": "none",
+                    "algorithmic_bytes_per_step_per_gpu": tb,
+                    "algorithmic_frac": tb / (ms.value / tsteps * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "bound_note": train_bound_note(name)}
+    del model
+    return out
+
+
+def cfg1_fit_gpu():
+    """BASELINE config #1 on the GPU: CRBM(10, 15).fit on 1000 synthetic 200-bp sequences with the reference's defaults
+    (batchsize 20, cd_k 5, doublestranded; tutorial.py:13-16 without the data file), ONE epoch = 50 PCD-5 updates plus
+    the per-epoch evaluation and status line.  The handle exists before the clock starts, as the reference compiles its
+    Theano functions in the constructor (convRBM.py:175)."""
+    import contextlib
+    import io
+    from crbm_amd import CRBM
+    D = synthetic_onehot(1000, 200, seed=1234)
+    out = {}
+    for rep in ("first", "second"):
+        np.random.seed(42)
+        model = CRBM(10, 15, epochs=1, seed=2026)
+        t0 = time.perf_counter()
+        model._h()
+        out["cfg1_create_seconds_%s" % rep] = time.perf_counter() - t0
+        buf = io.StringIO()
+        t0 = time.perf_counter()
+        with contextlib.redirect_stdout(buf):
+            model.fit(D)
+        out["cfg1_fit_seconds_gpu" if rep == "second" else "cfg1_fit_seconds_gpu_first_call"] = time.perf_counter() - t0
+        out["cfg1_status_line"] = [l for l in buf.getvalue().splitlines() if l.startswith("Epoch")][-1]
+        del model
+    out["cfg1_gpu_sample"] = ("one epoch of CRBM(10, 15).fit on 1000 x 200 bp, reference defaults (50 PCD-5 updates, evaluation of the "
+                              "1000 rows in 50 batches, status line), float one-hot input as the reference takes it; the second of two "
+                              "calls (the first pays one-off allocations and kernel loads)")
+    return out
+
+
 PMC_PASSES = (("valu", "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_TRANS_F32 SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT"),
               ("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE"))
 N_SIMD = 256 * 4          # MI355X: 256 CUs x 4 SIMDs
@@ -168,14 +368,20 @@ def pmc_of_csv(path, kernel_prefix):
     import csv
     from collections import defaultdict
     acc = defaultdict(lambda: defaultdict(float))
+    dur = {}
     for r in csv.DictReader(open(path)):
         if r["Kernel_Name"].startswith(kernel_prefix):
             acc[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+            if r.get("End_Timestamp") and r.get("Start_Timestamp"):
+                dur[r["Dispatch_Id"]] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
     out = {}
     for name, per in acc.items():
         ids = sorted(per, key=int)
         ids = ids[len(ids) // 4:]
         out[name] = sum(per[i] for i in ids) / len(ids)
+        if name == "SQ_BUSY_CYCLES" and all(i in dur for i in ids):
+            # duration of the same dispatches (counter collection serialises them): with SQ_BUSY_CYCLES the shader clock
+            out["SERIAL_NS"] = sum(dur[i] for i in ids) / len(ids)
     return out
 
 
@@ -189,9 +395,24 @@ def measure_pmc(config, launches=24, timeout_s=150):
     exe = shutil.which("rocprofv3")
     if exe is None:
         return None, "rocprofv3 not on PATH"
-    vals = {}
+    vals, trace = {}, {}
     tmp = tempfile.mkdtemp(prefix="crbm_pmc_")
     try:
+        # kernel trace alone (no counters: dispatches are not serialised, partitioned launches overlap as in the timed
+        # run): average duration of ONE launch of the chain kernel, as `rocprofv3 --kernel-trace --stats` reports it
+        d = os.path.join(tmp, "trace")
+        cmd = [exe, "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "-o", "t", "--",
+               sys.executable, os.path.join(ROOT, "tools", "prof_gibbs.py"), config, str(8 * launches)]
+        try:
+            r = subprocess.run(cmd, cwd=tmp, env=dict(os.environ, TMPDIR=tmp), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                               timeout=timeout_s)
+            import csv
+            for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row["Name"].startswith("crbm_gibbs"):
+                        trace = {"TRACE_AVG_NS": float(row["AverageNs"]), "TRACE_CALLS": float(row["Calls"])}
+        except Exception:
+            trace = {}
         for tag, counters in PMC_PASSES:
             d = os.path.join(tmp, tag)
             cmd = [exe, "--kernel-trace", "--pmc"] + counters.split() + ["--output-format", "csv", "-d", d, "-o", "p", "--",
@@ -211,6 +432,7 @@ def measure_pmc(config, launches=24, timeout_s=150):
     need = ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES")
     if any(k not in vals for k in need):
         return None, "rocprofv3 output lacks %s" % [k for k in need if k not in vals]
+    vals.update(trace)
     return vals, "measured in this run: rocprofv3 --kernel-trace --pmc (passes: %s) of tools/prof_gibbs.py %s %d" % (
         " | ".join(c for _, c in PMC_PASSES), config, launches)
 
@@ -263,6 +485,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="do not collect the chain kernel's PMC counters in child runs")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of configs #4, #5 and #1 behind the headline")
     ap.add_argument("--multi-step", action="store_true", help="also time 16 Gibbs steps per launch (informational)")
     args = ap.parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -282,11 +505,18 @@ def main():
 
     # counters of the chain kernel on this box (children under rocprofv3, before this process touches the GPU)
     pmc, pmc_note = None, "not collected (multi-rank run, or --no-pmc)"
+    others = [c for c in ("cfg4", "cfg5") if world == 1 and args.config == "cfg2" and not args.no_other_configs]
+    other_pmc = {}
     if world == 1 and not args.no_pmc and os.environ.get("CRBM_BENCH_PMC", "1") != "0":
         try:
             pmc, pmc_note = measure_pmc(args.config)
         except Exception as e:                      # a report, never a reason to lose the line
             pmc, pmc_note = None, "rocprofv3 child failed: %s" % str(e)[:200]
+        for c in others:
+            try:
+                other_pmc[c] = measure_pmc(c, launches=8 if c == "cfg4" else 16)
+            except Exception as e:
+                other_pmc[c] = (None, "rocprofv3 child failed: %s" % str(e)[:200])
 
     from crbm_amd import _lib
     from crbm_amd import dist as cdist
@@ -305,14 +535,16 @@ def main():
     # 6 GiB of copies also bring the clocks up before the short runs the driver asks for
     copy_gbs = ctypes.c_float()
     model._call("crbm_copy_bandwidth", 1 << 30, 5, ctypes.byref(copy_gbs))
-    # chains start at h = 0 (convRBM.py:168): 500 burn-in steps (12 ms), then the W warm-up launches.
+    # chains start at h = 0 (convRBM.py:168): burn-in steps, then the W warm-up launches.
     # The burn-in is part of building the workload, not of the measurement: a persistent chain is never at
-    # h = 0 in training, and a run as short as the driver's (20 launches = 0.5 ms) would otherwise be timed
-    # while the GPU is still leaving its idle power state (measured: 24.6 us per launch after 10 burn-in
-    # steps, 23.6 after 500, 23.5 after 2000; 22.8 in the steady state of a 2000-launch run).
+    # h = 0 in training -- and it is what brings the GPU to its sustained clock: the driver's timed region is 20
+    # launches (0.4 ms), and the part takes tens of milliseconds of load to settle (tools/ramp_probe.py, same
+    # process, 20-launch windows: 20.2-21.3 us per step right behind 500 burn-in steps, 18.5 behind a 2000-step
+    # window, 20.5 again after 10 ms of idling; the steady state of a 2000-launch run is 17.4).  3000 steps are
+    # 55 ms at config #2.  warmup_effective in the line counts them.
     # (as launches of k steps like the timed ones: every launch of the chain kernel in this process is then
-    # the same work, and a profiler's per-kernel average equals avg_launch_us)
-    burn_launches = max(1, int(os.environ.get("CRBM_BENCH_BURNIN", "500")) // k)
+    # the same work, and a profiler's per-kernel average is that of the timed launches)
+    burn_launches = max(1, int(os.environ.get("CRBM_BENCH_BURNIN", "3000")) // k)
     for _ in range(burn_launches):
         model._call("crbm_gibbs_steps_async", k)
     model._call("crbm_sync")
@@ -350,58 +582,8 @@ def main():
     if rank == 0:
         info = _lib.CrbmLaunchInfo()
         lib.crbm_get_launch_info(h, ctypes.byref(info))
-        alg_bytes = algorithmic_bytes_per_seq(cfg["K"], cfg["M"], cfg["L"], cfg["ds"]) * cfg["chains"] * k
-        avg_launch_s = kernel_s / launches
-        alg_gbs = alg_bytes / avg_launch_s / 1e9
-        # Counters of the chain kernel: measured on this box by the child runs above, else the tracked
-        # summary of an earlier box (profiles/gibbs_traffic.json), named as such
-        counters, counters_src = pmc, pmc_note
-        if counters is None:
-            tfile = os.path.join(ROOT, "profiles", "gibbs_traffic.json")
-            try:
-                t = json.load(open(tfile)).get(args.config, {})
-                counters = t.get("counters")
-                counters_src = "NOT measured in this run (%s); quoted from %s" % (pmc_note, t.get("source"))
-            except Exception:
-                counters = None
-        roof = {"kernel": "crbm_gibbs_sparse" if info.gibbs_sparse else "crbm_gibbs",   # name in the rocprofv3 summaries
-                "avg_launch_us": 1e6 * avg_launch_s, "counters_source": counters_src,
-                "measured_copy_gbs": float(copy_gbs.value),
-                "algorithmic_bytes_per_launch": alg_bytes,
-                "algorithmic_gbs": alg_gbs, "algorithmic_frac": alg_gbs / HBM_PEAK_GBS,
-                "algorithmic_note": "SURVEY 8(d) bytes of the reference's dense fp32 layout / launch time / 8 TB/s: an "
-                                    "equivalent-dense rate, not a bandwidth utilisation (the chain state is bit-packed, so it may "
-                                    "exceed 1); north_star's '>= 50 % of HBM roofline' is stated in these units",
-                "state_bytes_per_launch": int(lib.crbm_gibbs_state_bytes(h)),
-                "us_per_step_at_16_steps_per_launch": us_per_step_k16}
-        if counters:
-            # HBM bytes: 2 x FETCH_SIZE + WRITE_SIZE (KB) -- gfx950 tallies a wide streaming read at half its bytes
-            # (MI355X_MICROARCH.md, HBM).  VALU issue: SQ_ACTIVE_INST_VALU counts quad-cycles in which a wave has a
-            # vector instruction in issue; summed over waves / 1024 SIMDs = cycles a SIMD's vector issue is busy.
-            # SQ_BUSY_CYCLES / 32 shader engines = the launch in shader cycles: the fraction needs no clock.
-            traffic = (2.0 * counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024.0
-            launch_cycles = counters["SQ_BUSY_CYCLES"] / N_SE
-            valu_cycles = 4.0 * counters["SQ_ACTIVE_INST_VALU"] / N_SIMD
-            roof.update({
-                "bound": "valu_issue", "achieved": valu_cycles, "peak": launch_cycles,
-                "unit": "shader cycles per launch: a SIMD's vector-issue-busy cycles (achieved) vs the launch (peak)",
-                "frac": valu_cycles / launch_cycles,
-                "traffic": traffic, "hbm_actual_gbs": traffic / avg_launch_s / 1e9,
-                "hbm_actual_frac": traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS,
-                "valu_wave_insts_per_launch": counters["SQ_INSTS_VALU"],
-                "valu_trans_insts_per_launch": counters.get("SQ_INSTS_VALU_TRANS_F32"),
-                "valu_cycles_per_wave_inst": 4.0 * counters["SQ_ACTIVE_INST_VALU"] / counters["SQ_INSTS_VALU"],
-                "valu_issue_us": valu_cycles / (launch_cycles / (1e6 * avg_launch_s)),
-                "shader_clock_mhz_during_launch": launch_cycles / (1e6 * avg_launch_s),
-                "lds_bank_conflict_share": (counters["SQ_LDS_BANK_CONFLICT"] / counters["SQ_LDS_IDX_ACTIVE"])
-                                           if counters.get("SQ_LDS_IDX_ACTIVE") else None,
-                "note": "the kernel is bound by vector-instruction issue (and the LDS gathers behind it), not by HBM: "
-                        "frac = SIMD vector-issue-busy cycles / launch cycles, both from PMC counters of the same launches "
-                        "(profiled launches run a few per cent slower than the timed ones); hbm_actual_frac prices the "
-                        "measured HBM bytes against 8 TB/s"})
-        else:
-            roof.update({"bound": "valu_issue", "achieved": None, "peak": None, "unit": "shader cycles per launch",
-                         "frac": None, "traffic": None, "note": "no counters available: " + str(counters_src)})
+        roof = roofline_object(args.config, cfg, info, kernel_s / launches, pmc, pmc_note, float(copy_gbs.value),
+                               int(lib.crbm_gibbs_state_bytes(h)), us_per_step_k16)
         out = {
             "metric": "Gibbs-steps/sec (PCD-1) at batch 8192x4x200, 10 motifs len 15" if args.config == "cfg2"
                       else "Gibbs-steps/sec, " + cfg["desc"],
@@ -424,8 +606,7 @@ def main():
                       "(chains start at h = 0) together with the --warmup launches",
             "chain_steps_per_s": value * cfg["chains"],
             "roofline": roof,
-            "launch": {"grid": info.gibbs_grid, "block": info.gibbs_block, "chains_per_tile": info.gibbs_seqs_per_tile,
-                       "lds_bytes": info.gibbs_lds_bytes, "table_group": info.group},
+            "launch": launch_object(info),
         }
 
     # The headline line is complete before the secondary section starts.  With N > 1 a
@@ -439,6 +620,19 @@ def main():
         done["printed"] = True
         if rank == 0:
             out["train"] = train_result
+            if others:
+                # every BASELINE configuration that fits one GPU on the same clock (each in its own try: a report)
+                out["other_configs"] = {}
+                for c in others:
+                    try:
+                        cp, cn = other_pmc.get(c, (None, "not collected (--no-pmc)"))
+                        out["other_configs"][c] = other_config(c, cp, cn, float(copy_gbs.value))
+                    except Exception as e:
+                        out["other_configs"][c] = {"error": str(e)[:300]}
+                try:
+                    out["other_configs"]["cfg1"] = cfg1_fit_gpu()
+                except Exception as e:
+                    out["other_configs"]["cfg1"] = {"error": str(e)[:300]}
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(cfg)
             print(json.dumps(out), flush=True)
@@ -565,9 +759,7 @@ def main():
                 tb = n * (4 * 4 * cfg["L"] + k * algorithmic_bytes_per_seq(cfg["K"], cfg["M"], cfg["L"], cfg["ds"]))
                 train["algorithmic_bytes_per_step_per_gpu"] = tb
                 train["algorithmic_frac"] = tb / (train["ms_per_train_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS
-                train["bound_note"] = ("equivalent-dense rate like roofline.algorithmic_frac, not a bandwidth utilisation: the step moves "
-                                       "about 21 MB of HBM and is bound by vector-instruction issue (crbm_train_local keeps a SIMD's "
-                                       "vector issue busy for 0.77 of its launch at config #2: profiles/r03_pmc_summary.txt)")
+                train["bound_note"] = train_bound_note(args.config)
         except Exception as e:                      # report, never hide: the headline is the Gibbs metric
             train = {"error": str(e)[:300]}
             failed = True

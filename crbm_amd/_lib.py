@@ -44,7 +44,7 @@ class CrbmConfig(ctypes.Structure):
 class CrbmLaunchInfo(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         "nq", "group", "gibbs_grid", "gibbs_block", "gibbs_seqs_per_tile", "gibbs_lds_bytes",
-        "stats_grid_x", "stats_grid_y", "stats_block", "stats_lds_bytes", "gibbs_sparse", "activity_ppm", "stats_fused")]
+        "stats_grid_x", "stats_grid_y", "stats_block", "stats_lds_bytes", "gibbs_sparse", "activity_ppm", "stats_fused", "chain_parts")]
 
 
 _H = ctypes.c_void_p

@@ -10,6 +10,11 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -71,6 +76,19 @@ int env_int(const char* name, int dflt) {
   return (v && *v) ? atoi(v) : dflt;
 }
 
+// Letter grouping of PLAIN chain launches (crbm_gibbs_steps*: one 1024-thread block per CU whose LDS is otherwise idle):
+// the largest grouping whose table stays within 48 KB -- config #2: G = 4 (49 152 B, four gathers per position) where the
+// fused training launch, four blocks per CU beside the statistics slices, takes G = 3 (five gathers): 21.7 -> 21.4 us per
+// launch.  Only for models whose training step never launches the plain kernel (Cfg::FUSE_STATS) -- the others would
+// rebuild the second table every step -- and not beyond 48 KB: every block copies its table once per launch (config #5
+// with G = 4, 82 KB: 144.6 -> 150 us).  CRBM_GROUP_SOLO overrides.
+int solo_group(int K, int M, int ds, int G, int pool) {
+  const int forced = env_int("CRBM_GROUP_SOLO", 0);
+  if (forced >= 1 && forced <= 4) return forced;
+  if (!model_shape(K, M, ds, G, pool).FUSE_STATS) return G;
+  return std::max(G, choose_group(K, M, ds, 48 * 1024));
+}
+
 template <typename T>
 struct DevBuf {
   T* p = nullptr;
@@ -94,6 +112,27 @@ struct DevBuf {
 
 }  // namespace
 
+// One host thread per extra partition of the plain chain launches (crbm_handle::chain_parts): it enqueues that
+// partition's launches on the partition's stream while the caller's thread enqueues partition 0's.  Alternating two
+// streams from ONE thread costs ~6 us of host time per launch (2.6 us when a thread stays on one stream), which at two
+// launches per 17.6-us step leaves the GPU waiting for the host in short bursts.
+struct PartJob {
+  hipFunction_t fn;
+  crbm::GibbsArgs args;
+  unsigned grid, threads, lds;
+  unsigned long long delay_ticks;   // > 0: a delay kernel in front (the partition starts this much later)
+};
+struct PartWorker {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv, idle_cv;
+  std::deque<PartJob> jobs;
+  bool stop = false, busy = false;
+  hipError_t error = hipSuccess;
+  int device = 0;
+  hipStream_t stream = nullptr;
+};
+
 struct crbm_handle {
   crbm_config cfg;
   int K = 0, M = 0, ds = 0, NW = 0, G = 0, KAM = 0;
@@ -104,9 +143,13 @@ struct crbm_handle {
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
   bool overlap = false;
   ModelShape ms;
+  ModelShape ms_solo;       // the same model with the letter grouping of plain chain launches (GS; == ms when GS == G)
+  int GS = 0;
   JitKernels jk;            // kernels specialised for this model (hiprtc)
   float* d_tables = nullptr;   // precomputed LDS images (gather / top-down tables, c)
+  float* d_tf_solo = nullptr;  // gather table in the solo grouping (GS != G only), rebuilt lazily before a plain chain launch
   bool tables_dirty = true;
+  uint64_t params_version = 1, tf_solo_version = 0;   // bumped with every change of W, b, c / version d_tf_solo was built from
   // parameters and optimiser state
   float *dW = nullptr, *db = nullptr, *dc = nullptr, *dvW = nullptr, *dvb = nullptr, *dvc = nullptr;
   // the update writes into a second set of buffers; the two sets swap after every step (launch_update)
@@ -133,6 +176,25 @@ struct crbm_handle {
   GibbsLayout glv[2];
   GibbsLayout gl_solo;                 // geometry of plain chain launches of the sparse variant when it differs (solo_threads > 0)
   int solo_threads = 0, solo_grid = 0;
+  // Plain chain launches of short kernels go out as `chain_parts` launches of `part_chains` chains each, one stream per
+  // partition: chains are independent, so partition p's step t+1 only waits for partition p's step t, and the drain of
+  // one partition's kernel, the dispatch and the ramp of its next one are filled by the other partition's blocks on the
+  // same CUs (config #2: 20.9 -> 17.6 us per step of the whole batch).  solo_* / gl_solo then describe ONE partition.
+  int chain_parts = 1, part_chains = 0;
+  hipStream_t part_stream[4] = {nullptr, nullptr, nullptr, nullptr};
+  PartWorker* part_worker[4] = {nullptr, nullptr, nullptr, nullptr};   // [0] stays null: the caller's thread
+  hipEvent_t part_done[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_parts_fork = nullptr;
+  bool forked = false;                 // the partition streams hold work the main stream has not waited for yet
+  bool main_idle_hint = false;         // the main stream was idle when the caller last looked (only its own event record is pending)
+  // Partitions that start together stay in lockstep for hundreds of launches -- their gaps coincide and nothing is
+  // gained (config #2: 20.8 us per step over the first 20 steps, 19.3 over 200, 17.7 once they have drifted apart).
+  // So partition p starts p/P of a launch late: a one-wave delay kernel in front of its first launch after a fork.
+  // The length of a launch is measured on the way (events around partition 0's first launch of the previous fork).
+  double part_launch_us = 0.0;         // 0: not known yet (cost model below)
+  hipEvent_t ev_cal0 = nullptr, ev_cal1 = nullptr;
+  bool cal_pending = false;
+  int wall_khz = 100000;               // ticks of the GPU's wall clock per millisecond
   int threadsv[2] = {256, 256}, gridv[2] = {0, 0};
   bool has_dense = false;
   int gibbs_wpe = 0;                   // register-allocation hint compiled into the sparse Gibbs kernel
@@ -199,6 +261,17 @@ int ensure_tables(crbm_handle* h) {
   const unsigned grid = (unsigned)std::max(1, std::min((h->ms.TABLES_ALL + 255) / 256, h->num_cu * 4));
   HIPCHK(jit_launch(h->jk.build_tables, t, grid, 1, 256, 0, h->stream));
   h->tables_dirty = false;
+  return CRBM_OK;
+}
+
+// the gather table of the solo grouping follows the parameters lazily: built when a plain chain launch finds it stale
+int ensure_solo_table(crbm_handle* h) {
+  if (h->GS == h->G || h->tf_solo_version == h->params_version) return CRBM_OK;
+  TablesArgs t;
+  t.W = h->dW; t.b = h->db; t.c = h->dc; t.out = h->d_tf_solo;
+  const unsigned grid = (unsigned)std::max(1, std::min((h->ms_solo.TAB + 255) / 256, h->num_cu * 4));
+  HIPCHK(jit_launch(h->jk.build_gather_solo, t, grid, 1, 256, 0, h->stream));
+  h->tf_solo_version = h->params_version;
   return CRBM_OK;
 }
 
@@ -286,6 +359,7 @@ int prepare_gibbs(crbm_handle* h, int steps, ReduceArgs* model_reduce, GibbsArgs
   const bool with_stats = model_reduce != nullptr;
   GibbsArgs& a = *out;
   a.tables = h->d_tables;
+  a.tables_tf = nullptr; a.off_ws = 0;
   a.hm = h->d_hm; a.hmp = h->ds ? h->d_hmp : nullptr; a.vout = h->d_vf;
   a.nchains = h->B; a.Lf = h->Lf; a.Lv = h->gl.Lv; a.S = h->gl.S;
   a.nvb = h->gl.nvb; a.nhb = h->gl.nhb; a.Lrow = h->gl.Lrow; a.LWs = h->gl.LWs;
@@ -320,10 +394,136 @@ int prepare_gibbs(crbm_handle* h, int steps, ReduceArgs* model_reduce, GibbsArgs
   return CRBM_OK;
 }
 
+void part_worker_main(PartWorker* w) {
+  (void)hipSetDevice(w->device);
+  std::unique_lock<std::mutex> lock(w->mu);
+  for (;;) {
+    w->cv.wait(lock, [&] { return w->stop || !w->jobs.empty(); });
+    if (w->jobs.empty()) return;       // stop, nothing left
+    PartJob job = w->jobs.front();
+    w->jobs.pop_front();
+    w->busy = true;
+    lock.unlock();
+    hipError_t e = hipSuccess;
+    if (job.delay_ticks > 0) {
+      hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, w->stream, job.delay_ticks);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = jit_launch(job.fn, job.args, job.grid, 1, job.threads, job.lds, w->stream);
+    lock.lock();
+    if (e != hipSuccess && w->error == hipSuccess) w->error = e;
+    w->busy = false;
+    if (w->jobs.empty()) w->idle_cv.notify_all();
+  }
+}
+
+// every launch handed to the partitions' threads has been enqueued on its stream
+int drain_part_workers(crbm_handle* h) {
+  for (int p = 1; p < h->chain_parts; ++p) {
+    PartWorker* w = h->part_worker[p];
+    if (!w) continue;
+    std::unique_lock<std::mutex> lock(w->mu);
+    w->idle_cv.wait(lock, [&] { return w->jobs.empty() && !w->busy; });
+    if (w->error != hipSuccess) {
+      const hipError_t e = w->error;
+      w->error = hipSuccess;
+      return fail(h, CRBM_ERR_HIP, std::string("chain launch of partition ") + std::to_string(p) + ": " + hipGetErrorString(e));
+    }
+  }
+  return CRBM_OK;
+}
+
+// every partition stream has finished what it was given as far as the main stream is concerned
+int join_parts(crbm_handle* h) {
+  if (!h->forked) return CRBM_OK;
+  {
+    const int rc = drain_part_workers(h);
+    if (rc) return rc;
+  }
+  for (int p = 0; p < h->chain_parts; ++p) {
+    HIPCHK(hipEventRecord(h->part_done[p], h->part_stream[p]));
+    HIPCHK(hipStreamWaitEvent(h->stream, h->part_done[p], 0));
+  }
+  h->forked = false;
+  return CRBM_OK;
+}
+
+// `steps` Gibbs steps of all chains as chain_parts launches on the partition streams (see crbm_handle::chain_parts)
+int launch_gibbs_parts(crbm_handle* h, int steps) {
+  bool first_of_fork = false;
+  double stagger_ticks = 0.0;      // first launch after a fork: partition p starts p times this late
+  if (!h->forked) {     // the partitions start after whatever the main stream holds (parameter updates, state uploads)
+    if (!h->main_idle_hint && hipStreamQuery(h->stream) != hipSuccess) {     // ... unless it is idle: nothing to wait for, no cross-stream dependency to resolve
+      (void)hipGetLastError();
+      HIPCHK(hipEventRecord(h->ev_parts_fork, h->stream));
+      for (int p = 0; p < h->chain_parts; ++p) HIPCHK(hipStreamWaitEvent(h->part_stream[p], h->ev_parts_fork, 0));
+    }
+    h->main_idle_hint = false;
+    h->forked = true;
+    first_of_fork = true;
+    if (h->cal_pending && hipEventQuery(h->ev_cal1) == hipSuccess) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, h->ev_cal0, h->ev_cal1) == hipSuccess && ms > 0.f) h->part_launch_us = 1e3 * ms;
+      h->cal_pending = false;
+    }
+    (void)hipGetLastError();
+    if (env_int("CRBM_PART_STAGGER", 1)) {
+      // (before the first measurement: ~1 ns per hidden unit and Gibbs step, what configs #2 and #5 run at)
+      const double est = h->part_launch_us > 0.0 ? h->part_launch_us
+                                                 : 1e-3 * (double)h->B * h->Lf * h->K * (1 + h->ds) * steps;
+      stagger_ticks = 0.9 * est / h->chain_parts * (h->wall_khz / 1000.0);
+    }
+  }
+  GibbsArgs a;
+  unsigned lds = 0;
+  const GibbsLayout gl_keep = h->gl;
+  const int threads_keep = h->gibbs_threads, grid_keep = h->gibbs_grid;
+  h->gl = h->gl_solo; h->gibbs_threads = h->solo_threads; h->gibbs_grid = h->solo_grid;
+  int rc = prepare_gibbs(h, steps, nullptr, &a, &lds);
+  const unsigned grid = (unsigned)h->gibbs_grid, threads = (unsigned)h->gibbs_threads;
+  h->gl = gl_keep; h->gibbs_threads = threads_keep; h->gibbs_grid = grid_keep;
+  if (rc) return rc;
+  const size_t per = (size_t)h->Lf * h->NW;
+  const int waves = (int)threads / 64;
+  h->nset_slots = h->chain_parts * (int)grid * waves;
+  for (int p = 0; p < h->chain_parts; ++p) {
+    const int c0 = p * h->part_chains, n = std::min(h->part_chains, h->B - c0);
+    if (n <= 0) break;
+    GibbsArgs ap = a;
+    ap.hm = a.hm + (size_t)c0 * per;
+    if (ap.hmp) ap.hmp = a.hmp + (size_t)c0 * per;
+    ap.vout = a.vout + (size_t)c0 * a.LWs;
+    ap.nchains = n;
+    ap.rng.seq_offset = a.rng.seq_offset + (uint32_t)c0;
+    ap.ones = a.ones + (size_t)p * grid * waves;
+    ap.nblocks = (int)grid;
+    if (p > 0) {          // the partition's own thread enqueues it
+      PartWorker* w = h->part_worker[p];
+      {
+        std::lock_guard<std::mutex> lock(w->mu);
+        w->jobs.push_back(PartJob{h->jk.gibbs_sparse, ap, grid, threads, lds, (unsigned long long)(stagger_ticks * p)});
+      }
+      w->cv.notify_one();
+      continue;
+    }
+    const bool calibrate = first_of_fork && !h->cal_pending;
+    if (calibrate) HIPCHK(hipEventRecord(h->ev_cal0, h->part_stream[0]));
+    HIPCHK(jit_launch(h->jk.gibbs_sparse, ap, grid, 1, threads, lds, h->part_stream[0]));
+    if (calibrate) {
+      HIPCHK(hipEventRecord(h->ev_cal1, h->part_stream[0]));
+      h->cal_pending = true;
+    }
+  }
+  h->gibbs_step += (uint32_t)steps;
+  h->launches_since_read += 1;
+  return CRBM_OK;
+}
+
 int launch_gibbs(crbm_handle* h, int steps, hipStream_t s = nullptr, ReduceArgs* model_reduce = nullptr) {
   if (!s) s = h->stream;
   int rc = ensure_tables(h);
   if (rc) return rc;
+  if (!model_reduce && h->variant == 1 && h->chain_parts > 1 && s == h->stream) return launch_gibbs_parts(h, steps);
   GibbsArgs a;
   unsigned lds = 0;
   const bool solo = !model_reduce && h->variant == 1 && h->solo_threads > 0;
@@ -331,6 +531,10 @@ int launch_gibbs(crbm_handle* h, int steps, hipStream_t s = nullptr, ReduceArgs*
   const int threads_keep = h->gibbs_threads, grid_keep = h->gibbs_grid;
   if (solo) { h->gl = h->gl_solo; h->gibbs_threads = h->solo_threads; h->gibbs_grid = h->solo_grid; }
   rc = prepare_gibbs(h, steps, model_reduce, &a, &lds);
+  if (!model_reduce && h->variant == 1 && h->GS != h->G) {     // crbm_gibbs_sparse is compiled for the solo grouping
+    a.tables_tf = h->d_tf_solo; a.off_ws = h->ms.OFF_WS;
+    if (rc == CRBM_OK) rc = ensure_solo_table(h);
+  }
   const unsigned grid = (unsigned)h->gibbs_grid, threads = (unsigned)h->gibbs_threads;
   if (solo) { h->gl = gl_keep; h->gibbs_threads = threads_keep; h->gibbs_grid = grid_keep; }
   if (rc) return rc;
@@ -459,6 +663,7 @@ void swap_param_sets(crbm_handle* h) {
   std::swap(h->dW, h->dW2); std::swap(h->db, h->db2); std::swap(h->dc, h->dc2);
   std::swap(h->dvW, h->dvW2); std::swap(h->dvb, h->dvb2); std::swap(h->dvc, h->dvc2);
   h->tables_dirty = false;
+  h->params_version += 1;
 }
 
 // update + rebuild of the table images in one launch (update_tables_body)
@@ -546,6 +751,8 @@ int train_local_dev(crbm_handle* h, const uint32_t* d_letters, int n, int L, boo
     }
   } else {
     rc = launch_gibbs(h, h->cfg.cd_k, sm);
+    if (rc) return rc;
+    rc = join_parts(h);      // (a partitioned chain launch: the statistics read what all partitions leave)
     if (rc) return rc;
     rc = launch_stats(h, h->d_vf, h->B, h->Lv, false, sm, paired ? &pair.half[1] : nullptr);
     if (rc) return rc;
@@ -770,6 +977,41 @@ GibbsGeom choose_gibbs_geometry(const ModelShape& ms, int Lf, int B, int num_cu,
   return best;
 }
 
+// Partitions of a plain chain launch (crbm_handle::chain_parts).  Worth it where a launch is short and its blocks are
+// small: the partitions' kernels then share every CU (several blocks of each resident at once) and one partition's
+// drain / dispatch / ramp is filled by the other's work.  Measured (two handles of half the chains, alternating launches):
+// config #2 with 256-thread blocks of 8 chains 21.7 -> 17.6 us per step of the whole batch (17.4 with four partitions);
+// with one 1024-thread block per CU per partition nothing (20.5 vs 20.6): the partitions then own disjoint CUs.
+// In the library: config #2 20.3 -> 17.8 us, config #5 137.9 -> 136.1 us, config #4 2191 -> 2180 us (not worth a second
+// geometry there); three and four partitions are SLOWER (29 / 26 us at config #2: a process has four hardware queues,
+// the handle's two other streams take two of them, and partitions that share a queue serialise).
+// Auto: two partitions when the small-block geometry of half the batch puts at least two blocks on a CU, still covers
+// every CU, and a launch is short (by the number of hidden units per step); CRBM_CHAIN_PARTS forces 1..4.
+struct PartPlan {
+  int parts, part_chains;
+  GibbsGeom geom;      // of one partition
+};
+PartPlan plan_chain_parts(const ModelShape& ms, int Lf, int B, int num_cu) {
+  PartPlan one{1, B, GibbsGeom{0, 0, 0, 0}};
+  const int forced = env_int("CRBM_CHAIN_PARTS", 0);
+  if (forced == 1 || B < 2) return one;
+  const int parts = forced >= 2 ? std::min(forced, 4) : 2;
+  // small blocks: the geometry the fused training launch uses (at most 256 threads unless they reach half the waves)
+  const int half = (B + parts - 1) / parts;
+  GibbsGeom g = choose_gibbs_geometry(ms, Lf, half, num_cu, true, false);
+  if (g.lds <= 0) return one;
+  const int tiles = (B + g.S - 1) / g.S, tiles_part = (tiles + parts - 1) / parts;
+  const int blocks_cu = std::max(1, std::min((160 * 1024) / g.lds, 1024 / g.threads));
+  if (forced < 2) {
+    const double items = (double)B * Lf * ms.K * (1 + ms.DS);          // hidden units per step
+    if (blocks_cu < 2 || tiles_part < num_cu || items > 256e6) return one;
+  }
+  if (tiles_part < 1) return one;
+  PartPlan p{parts, tiles_part * g.S, g};
+  p.geom.grid = std::min(tiles_part, num_cu * blocks_cu);
+  return p;
+}
+
 // waves per SIMD the sparse Gibbs variant reaches with its geometry; 0 when >= 4 (no hint needed)
 int gibbs_block_bound(int threads) { return threads > 512 ? 1024 : threads > 256 ? 512 : 256; }
 
@@ -797,11 +1039,20 @@ int crbm_precompile(const crbm_config* cfg) {
   bool cached = false;
   std::string file, err;
   const int Lf_pc = cfg->fantasy_hidden_len > 0 ? cfg->fantasy_hidden_len : 200;
-  const GibbsGeom gs = choose_gibbs_geometry(ms, Lf_pc, cfg->batchsize, env_int("CRBM_NUM_CU", 256), true);
+  const int ncu = env_int("CRBM_NUM_CU", 256);
+  const GibbsGeom gs = choose_gibbs_geometry(ms, Lf_pc, cfg->batchsize, ncu, true);
   int tb = gs.threads;
-  if (ms.DENSE) tb = std::max(tb, choose_gibbs_geometry(ms, Lf_pc, cfg->batchsize, env_int("CRBM_NUM_CU", 256), false).threads);
-  tb = std::max(tb, choose_gibbs_geometry(ms, Lf_pc, cfg->batchsize, env_int("CRBM_NUM_CU", 256), true, true).threads);
-  if (jit_compile(ms.K, ms.M, ms.DS, ms.G, ms.POOL, gibbs_wpe_hint(gs), gibbs_block_bound(tb), &code, &cached, &file, &err) != 0) {
+  if (ms.DENSE) tb = std::max(tb, choose_gibbs_geometry(ms, Lf_pc, cfg->batchsize, ncu, false).threads);
+  int GS = G;
+  const PartPlan plan = plan_chain_parts(ms, Lf_pc, cfg->batchsize, ncu);
+  if (plan.parts > 1) tb = std::max(tb, plan.geom.threads);
+  else {
+    GS = solo_group(ms.K, ms.M, ms.DS, G, ms.POOL);
+    GibbsGeom solo = choose_gibbs_geometry(model_shape(ms.K, ms.M, ms.DS, GS, ms.POOL), Lf_pc, cfg->batchsize, ncu, true, true);
+    if (solo.lds <= 0 && GS != G) { GS = G; solo = choose_gibbs_geometry(ms, Lf_pc, cfg->batchsize, ncu, true, true); }
+    tb = std::max(tb, solo.threads);
+  }
+  if (jit_compile(ms.K, ms.M, ms.DS, ms.G, GS, ms.POOL, gibbs_wpe_hint(gs), gibbs_block_bound(tb), &code, &cached, &file, &err) != 0) {
     g_create_error = err;
     return CRBM_ERR_HIP;
   }
@@ -857,11 +1108,30 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
     hh->gridv[v] = geom.grid;
   }
   {
-    const GibbsGeom solo = choose_gibbs_geometry(hh->ms, hh->Lf, hh->B, hh->num_cu, true, true);
-    if (solo.lds > 0 && (solo.threads != hh->threadsv[1] || solo.S != hh->glv[1].S || solo.grid != hh->gridv[1])) {
-      hh->gl_solo = gibbs_layout(hh->ms, hh->Lf, solo.S, true);
-      hh->solo_threads = solo.threads;
-      hh->solo_grid = solo.grid;
+    // plain chain launches: their own geometry; short launches in partitions on streams of their own (chain_parts);
+    // unpartitioned ones of small fused models with their own letter grouping (solo_group)
+    const PartPlan plan = plan_chain_parts(hh->ms, hh->Lf, hh->B, hh->num_cu);
+    hh->chain_parts = plan.parts;
+    if (plan.parts > 1) {
+      hh->GS = hh->G; hh->ms_solo = hh->ms;
+      hh->part_chains = plan.part_chains;
+      hh->gl_solo = gibbs_layout(hh->ms, hh->Lf, plan.geom.S, true);
+      hh->solo_threads = plan.geom.threads;
+      hh->solo_grid = plan.geom.grid;
+    } else {
+      hh->part_chains = hh->B;
+      hh->GS = solo_group(hh->K, hh->M, hh->ds, hh->G, cfg->pooling);
+      hh->ms_solo = model_shape(hh->K, hh->M, hh->ds, hh->GS, cfg->pooling);
+      GibbsGeom solo = choose_gibbs_geometry(hh->ms_solo, hh->Lf, hh->B, hh->num_cu, true, true);
+      if (solo.lds <= 0 && hh->GS != hh->G) {           // the larger table leaves no room for a chain: the model's grouping
+        hh->GS = hh->G; hh->ms_solo = hh->ms;
+        solo = choose_gibbs_geometry(hh->ms_solo, hh->Lf, hh->B, hh->num_cu, true, true);
+      }
+      if (solo.lds > 0 && (hh->GS != hh->G || solo.threads != hh->threadsv[1] || solo.S != hh->glv[1].S || solo.grid != hh->gridv[1])) {
+        hh->gl_solo = gibbs_layout(hh->ms_solo, hh->Lf, solo.S, true);
+        hh->solo_threads = solo.threads;
+        hh->solo_grid = solo.grid;
+      }
     }
   }
   {
@@ -875,7 +1145,7 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
   {
     std::string err;
     const int tb = gibbs_block_bound(std::max(std::max(hh->has_dense ? hh->threadsv[0] : 0, hh->threadsv[1]), hh->solo_threads));
-    if (jit_load(hh->K, hh->M, hh->ds, hh->G, hh->ms.POOL, hh->gibbs_wpe, tb, &hh->jk, &err) != 0) {
+    if (jit_load(hh->K, hh->M, hh->ds, hh->G, hh->GS, hh->ms.POOL, hh->gibbs_wpe, tb, &hh->jk, &err) != 0) {
       g_create_error = "kernel specialisation failed: " + err;
       return bail(CRBM_ERR_HIP);
     }
@@ -886,6 +1156,27 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
   TRY(hipEventCreate(&hh->ev1));
   TRY(hipEventCreateWithFlags(&hh->ev_fork, hipEventDisableTiming));
   TRY(hipEventCreateWithFlags(&hh->ev_join, hipEventDisableTiming));
+  if (hh->chain_parts > 1) {
+    TRY(hipEventCreateWithFlags(&hh->ev_parts_fork, hipEventDisableTiming));
+    TRY(hipEventCreate(&hh->ev_cal0));
+    TRY(hipEventCreate(&hh->ev_cal1));
+    {
+      int khz = 0;
+      if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, hh->device) == hipSuccess && khz > 0) hh->wall_khz = khz;
+      (void)hipGetLastError();
+    }
+    for (int p = 0; p < hh->chain_parts; ++p) {
+      TRY(hipStreamCreateWithFlags(&hh->part_stream[p], hipStreamNonBlocking));
+      TRY(hipEventCreate(&hh->part_done[p]));     // with timestamps: crbm_time_gibbs reads them
+      if (p > 0) {
+        PartWorker* w = new PartWorker();
+        w->device = hh->device;
+        w->stream = hh->part_stream[p];
+        w->th = std::thread(part_worker_main, w);
+        hh->part_worker[p] = w;
+      }
+    }
+  }
   hh->overlap = env_int("CRBM_OVERLAP", 0) != 0;   // measured: no gain once the statistics kernel fills the chip
   const size_t kam = (size_t)hh->KAM, k = (size_t)hh->K;
   TRY(hipMalloc((void**)&hh->dW, kam * 4)); TRY(hipMalloc((void**)&hh->dvW, kam * 4));
@@ -898,6 +1189,7 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
   TRY(hipMalloc((void**)&hh->db2, k * 4));   TRY(hipMalloc((void**)&hh->dvb2, k * 4));
   TRY(hipMalloc((void**)&hh->dc2, 16));      TRY(hipMalloc((void**)&hh->dvc2, 16));
   TRY(hipMalloc((void**)&hh->d_tables, (size_t)hh->ms.TABLES_ALL * 4));
+  if (hh->GS != hh->G) TRY(hipMalloc((void**)&hh->d_tf_solo, (size_t)hh->ms_solo.TAB * 4));
   const size_t mwords = (size_t)hh->B * hh->Lf * hh->NW;
   TRY(hipMalloc((void**)&hh->d_hm, mwords * 4)); TRY(hipMemset(hh->d_hm, 0, mwords * 4));
   TRY(hipMalloc((void**)&hh->d_hmp, mwords * 4)); TRY(hipMemset(hh->d_hmp, 0, mwords * 4));
@@ -906,7 +1198,7 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
   TRY(hipMalloc((void**)&hh->d_flags, 16)); TRY(hipMemset(hh->d_flags, 0, 16));
   TRY(hipMalloc((void**)&hh->d_ones, 16)); TRY(hipMemset(hh->d_ones, 0, 16));
   {
-    const size_t slots = (size_t)std::max(std::max(hh->gridv[0] * (hh->threadsv[0] / 64), hh->gridv[1] * (hh->threadsv[1] / 64)), hh->solo_grid * (hh->solo_threads / 64)) + 64;
+    const size_t slots = (size_t)std::max(std::max(hh->gridv[0] * (hh->threadsv[0] / 64), hh->gridv[1] * (hh->threadsv[1] / 64)), hh->chain_parts * hh->solo_grid * (hh->solo_threads / 64)) + 64;
     TRY(hipMalloc((void**)&hh->d_nset, slots * 4)); TRY(hipMemset(hh->d_nset, 0, slots * 4));
   }
   TRY(hipMalloc((void**)&hh->d_sums, (size_t)hh->sl.count * 4)); TRY(hipMemset(hh->d_sums, 0, (size_t)hh->sl.count * 4));
@@ -933,11 +1225,28 @@ int crbm_destroy(crbm_handle* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->stream2) (void)hipStreamSynchronize(h->stream2);
+  for (int p = 0; p < 4; ++p) {
+    if (PartWorker* w = h->part_worker[p]) {
+      {
+        std::lock_guard<std::mutex> lock(w->mu);
+        w->stop = true;
+      }
+      w->cv.notify_one();
+      if (w->th.joinable()) w->th.join();
+      delete w;
+      h->part_worker[p] = nullptr;
+    }
+    if (h->part_stream[p]) { (void)hipStreamSynchronize(h->part_stream[p]); (void)hipStreamDestroy(h->part_stream[p]); }
+    if (h->part_done[p]) (void)hipEventDestroy(h->part_done[p]);
+  }
+  if (h->ev_parts_fork) (void)hipEventDestroy(h->ev_parts_fork);
+  if (h->ev_cal0) (void)hipEventDestroy(h->ev_cal0);
+  if (h->ev_cal1) (void)hipEventDestroy(h->ev_cal1);
   if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
   for (int r = 0; r < IPC_MAX_RANKS; ++r)
     if (h->ipc_peer[r] && h->ipc_peer[r] != h->ipc_buf) (void)hipIpcCloseMemHandle(h->ipc_peer[r]);
   if (h->ipc_buf) (void)hipFree(h->ipc_buf);
-  void* ptrs[] = {h->dW2, h->db2, h->dc2, h->dvW2, h->dvb2, h->dvc2, h->dW, h->db, h->dc, h->dvW, h->dvb, h->dvc, h->d_hm, h->d_hmp, h->d_vf, h->d_flags, h->d_ones, h->d_nset, h->d_sums, h->d_ticket, h->d_tables};
+  void* ptrs[] = {h->dW2, h->db2, h->dc2, h->dvW2, h->dvb2, h->dvc2, h->dW, h->db, h->dc, h->dvW, h->dvb, h->dvc, h->d_hm, h->d_hmp, h->d_vf, h->d_flags, h->d_ones, h->d_nset, h->d_sums, h->d_ticket, h->d_tables, h->d_tf_solo};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   h->stage.release(); h->stage2.release(); h->out_a.release(); h->out_b.release(); h->out_c.release();
@@ -954,10 +1263,18 @@ int crbm_destroy(crbm_handle* h) {
   return CRBM_OK;
 }
 
-#define ENTER()                                               \
+// ENTER_ASYNC: entry points that may leave work on the partition streams (plain chain launches); every other entry point
+// first lets the main stream wait for them (join_parts: two event calls per partition, only when something is pending)
+#define ENTER_ASYNC()                                         \
   if (!h) return CRBM_ERR_INVALID;                            \
   h->err.clear();                                             \
   HIPCHK(hipSetDevice(h->device))
+#define ENTER()                                               \
+  ENTER_ASYNC();                                              \
+  do {                                                        \
+    const int jrc__ = join_parts(h);                          \
+    if (jrc__) return jrc__;                                  \
+  } while (0)
 
 int crbm_set_params(crbm_handle* h, const float* W, const float* b, const float* c) {
   ENTER();
@@ -967,6 +1284,7 @@ int crbm_set_params(crbm_handle* h, const float* W, const float* b, const float*
   HIPCHK(hipMemcpyAsync(h->dc, c, 16, hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   h->tables_dirty = true;
+  h->params_version += 1;
   return CRBM_OK;
 }
 
@@ -1204,7 +1522,7 @@ int crbm_train_epoch_sharded(crbm_handle* h, int32_t batchsize, int32_t total_ro
 }
 
 int crbm_gibbs_steps_async(crbm_handle* h, int32_t k) {
-  ENTER();
+  ENTER_ASYNC();
   ARGCHK(k >= 1, "k must be positive");
   return launch_gibbs(h, k);
 }
@@ -1236,11 +1554,44 @@ static hipError_t spin_until(hipEvent_t ev) {
 int crbm_time_gibbs(crbm_handle* h, int32_t k, int32_t launches, float* total_ms) {
   ENTER();
   ARGCHK(k >= 0 && launches >= 1 && total_ms, "bad argument");   // k = 0: state load/store only (profiling)
+  h->main_idle_hint = hipStreamQuery(h->stream) == hipSuccess;   // (the opening event below does not count as work to wait for)
+  (void)hipGetLastError();
   HIPCHK(hipEventRecord(h->ev0, h->stream));
+  const auto t_enq0 = std::chrono::steady_clock::now();
+  const bool trace_enq = env_int("CRBM_TIME_ENQUEUE", 0) >= 2;
+  std::vector<double> enq_us;
   for (int i = 0; i < launches; ++i) {
     int rc = launch_gibbs(h, k);
     if (rc) return rc;
+    if (trace_enq) enq_us.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_enq0).count());
   }
+  if (trace_enq) {
+    fprintf(stderr, "enqueue completion times (us):");
+    for (size_t i = 0; i < enq_us.size() && i < 60; ++i) fprintf(stderr, " %.0f", enq_us[i]);
+    fprintf(stderr, "\n");
+  }
+  if (env_int("CRBM_TIME_ENQUEUE", 0))     // measurement aid: host time spent enqueuing the launches
+    fprintf(stderr, "crbm_time_gibbs: %d launch steps enqueued in %.1f us of host time\n", launches,
+            std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_enq0).count());
+  if (h->forked) {
+    // partitioned launches: the interval ends when the last partition's last launch does -- an event behind each
+    // partition's launches, polled by the host (no device-side join in the timed region; the streams stay forked)
+    float worst = 0.f;
+    {
+      const int rc = drain_part_workers(h);
+      if (rc) return rc;
+    }
+    for (int p = 0; p < h->chain_parts; ++p) HIPCHK(hipEventRecord(h->part_done[p], h->part_stream[p]));
+    for (int p = 0; p < h->chain_parts; ++p) {
+      float ms = 0.f;
+      HIPCHK(spin_until(h->part_done[p]));
+      HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->part_done[p]));
+      worst = std::max(worst, ms);
+    }
+    *total_ms = worst;
+    return CRBM_OK;
+  }
+  h->main_idle_hint = false;
   HIPCHK(hipEventRecord(h->ev1, h->stream));
   HIPCHK(spin_until(h->ev1));
   HIPCHK(hipEventElapsedTime(total_ms, h->ev0, h->ev1));
@@ -1791,6 +2142,7 @@ int crbm_comm_broadcast_state(crbm_handle* h, int32_t root) {
   }
   HIPCHK(hipStreamSynchronize(h->stream));
   h->tables_dirty = true;
+  h->params_version += 1;
   return CRBM_OK;
 }
 
@@ -1917,9 +2269,10 @@ int crbm_get_launch_info(const crbm_handle* h, crbm_launch_info* out) {
   const int tabs = h->ms.TAB * 4;
   const StatsMfmaLayout st = stats_mfma_layout(h->ms, 1, h->Lf, 0, tabs);
   const int lds = std::max(st.region_floats * 4 + tabs, st.combine_bytes);
-  out->nq = h->ms.NQ; out->group = h->G;
+  out->nq = h->ms.NQ; out->group = h->GS;   // of the plain chain launch this structure describes
   // the geometry of a plain chain launch (crbm_gibbs_steps*): the solo one where the model has it
   const bool solo = h->variant == 1 && h->solo_threads > 0;
+  out->chain_parts = h->variant == 1 ? h->chain_parts : 1;
   out->gibbs_grid = solo ? h->solo_grid : h->gibbs_grid; out->gibbs_block = solo ? h->solo_threads : h->gibbs_threads;
   out->gibbs_seqs_per_tile = solo ? h->gl_solo.S : h->gl.S; out->gibbs_lds_bytes = solo ? h->gl_solo.lds_bytes : h->gl.lds_bytes;
   out->stats_grid_x = h->stats_rows > 0 ? h->stats_rows

@@ -29,6 +29,7 @@ namespace crbm {
 struct JitKernels {
   hipModule_t module = nullptr;
   hipFunction_t build_tables = nullptr, update_tables = nullptr, update_tables_ipc = nullptr, hgv = nullptr, gibbs = nullptr /* dense top-down; null if the model has none */,
+                build_gather_solo = nullptr /* gather table of the solo letter grouping */,
                 gibbs_sparse = nullptr, gibbs_sparse_stats = nullptr /* empty unless Cfg::FUSE_STATS */, train_local = nullptr /* ditto */, stats_mfma_data = nullptr, stats_mfma_model = nullptr,
                 free_energy = nullptr, hit_summary = nullptr;
   bool from_cache = false;
@@ -69,7 +70,8 @@ inline uint64_t jit_fnv1a(const std::string& s, uint64_t h = 1469598103934665603
 // below 4 (LDS-limited large models): tells the register allocator not to squeeze
 // the kernel for an occupancy it will never see; 0 = no hint.
 // gibbs_tb: block-size bound of the chain kernels (256, 512 or 1024: large models share one table copy per CU)
-inline std::string jit_stub(int K, int M, int DS, int G, int POOL, int gibbs_wpe, int gibbs_tb = 256) {
+// GS: letters per gather-table group of the plain chain kernel (crbm_gibbs_sparse), G of everything else
+inline std::string jit_stub(int K, int M, int DS, int G, int GS, int POOL, int gibbs_wpe, int gibbs_tb = 256) {
   char attr[96] = "", sattr[96] = "";
   if (gibbs_wpe > 0) snprintf(attr, sizeof(attr), "__attribute__((amdgpu_waves_per_eu(1, %d)))", gibbs_wpe);
   else snprintf(attr, sizeof(attr), "__attribute__((amdgpu_waves_per_eu(4)))");   // 4 blocks of 4 waves per CU: at most 128 registers
@@ -84,11 +86,13 @@ inline std::string jit_stub(int K, int M, int DS, int G, int POOL, int gibbs_wpe
            "#ifndef CRBM_GIBBS_STATS_ATTR\n#define CRBM_GIBBS_STATS_ATTR %s\n#endif\n"
            "#ifndef CRBM_STATS_BYTE_LUT\n#define CRBM_STATS_BYTE_LUT true\n#endif\n"
            "using ModelCfg = crbm::Cfg<%d, %d, %d, %d, %d>;\n"
+           "using SoloCfg = crbm::Cfg<%d, %d, %d, %d, %d>;\n"
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_build_tables(crbm::TablesArgs a) { crbm::build_tables_body<ModelCfg>(a); }\n"
+           "extern \"C\" __global__ void __launch_bounds__(256) crbm_build_gather_solo(crbm::TablesArgs a) { crbm::build_gather_table_body<SoloCfg>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(1024) crbm_update_tables(crbm::UpdateTablesArgs a) { crbm::update_tables_body<ModelCfg>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(1024) crbm_update_tables_ipc(crbm::UpdateIpcArgs a) { crbm::update_tables_ipc_body<ModelCfg>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_hgv(crbm::HgvArgs a) { crbm::hgv_body<ModelCfg>(a); }\n"
-           "extern \"C\" __global__ void __launch_bounds__(%d) CRBM_GIBBS_ATTR crbm_gibbs_sparse(crbm::GibbsArgs a) { crbm::gibbs_body<ModelCfg, true>(a); }\n"
+           "extern \"C\" __global__ void __launch_bounds__(%d) CRBM_GIBBS_ATTR crbm_gibbs_sparse(crbm::GibbsArgs a) { crbm::gibbs_body<SoloCfg, true>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) CRBM_GIBBS_STATS_ATTR crbm_gibbs_sparse_stats(crbm::GibbsArgs a) { if constexpr (ModelCfg::FUSE_STATS) crbm::gibbs_body<ModelCfg, true, true>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) CRBM_GIBBS_STATS_ATTR crbm_train_local(crbm::TrainLocalArgs a) { crbm::train_local_body<ModelCfg>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(%d) crbm_gibbs(crbm::GibbsArgs a) { if constexpr (ModelCfg::DENSE) crbm::gibbs_body<ModelCfg, ModelCfg::DENSE ? false : true>(a); }\n"
@@ -97,12 +101,12 @@ inline std::string jit_stub(int K, int M, int DS, int G, int POOL, int gibbs_wpe
            "extern \"C\" __global__ void __launch_bounds__(RoleModel::THREADS) crbm_stats_mfma_model(crbm::StatsMfmaArgs a) { crbm::stats_mfma_body<ModelCfg, false, CRBM_STATS_BYTE_LUT>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_free_energy(crbm::FeArgs a) { crbm::free_energy_body<ModelCfg>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_hit_summary(crbm::HitArgs a) { crbm::hit_summary_body<ModelCfg>(a); }\n",
-           attr, sattr, K, M, DS, G, POOL, gibbs_tb, gibbs_tb);
+           attr, sattr, K, M, DS, G, POOL, K, M, DS, GS, POOL, gibbs_tb, gibbs_tb);
   return buf;
 }
 
 // Compile (or fetch from the cache) the code object; no device needed.
-inline int jit_compile(int K, int M, int DS, int G, int POOL, int gibbs_wpe, int gibbs_tb, std::vector<char>* code, bool* from_cache,
+inline int jit_compile(int K, int M, int DS, int G, int GS, int POOL, int gibbs_wpe, int gibbs_tb, std::vector<char>* code, bool* from_cache,
                        std::string* cache_file, std::string* err) {
   const std::string dir = jit_source_dir();
   std::string kernels, layout;
@@ -110,7 +114,7 @@ inline int jit_compile(int K, int M, int DS, int G, int POOL, int gibbs_wpe, int
     *err = "kernel sources not found in " + dir + " (set CRBM_KERNEL_SRC_DIR)";
     return -1;
   }
-  const std::string stub = jit_stub(K, M, DS, G, POOL, gibbs_wpe, gibbs_tb);
+  const std::string stub = jit_stub(K, M, DS, G, GS, POOL, gibbs_wpe, gibbs_tb);
   std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
                                    "-I" + dir, "-I/opt/rocm/include"};
   if (const char* e = getenv("CRBM_JIT_DEFINES")) {   // tuning knobs, e.g. "-DCRBM_STATS_MAX_TILES=16"
@@ -175,16 +179,16 @@ inline int jit_compile(int K, int M, int DS, int G, int POOL, int gibbs_wpe, int
   return 0;
 }
 
-inline int jit_load(int K, int M, int DS, int G, int POOL, int gibbs_wpe, int gibbs_tb, JitKernels* out, std::string* err) {
+inline int jit_load(int K, int M, int DS, int G, int GS, int POOL, int gibbs_wpe, int gibbs_tb, JitKernels* out, std::string* err) {
   std::vector<char> code;
-  if (jit_compile(K, M, DS, G, POOL, gibbs_wpe, gibbs_tb, &code, &out->from_cache, &out->cache_file, err) != 0) return -1;
+  if (jit_compile(K, M, DS, G, GS, POOL, gibbs_wpe, gibbs_tb, &code, &out->from_cache, &out->cache_file, err) != 0) return -1;
   hipError_t e = hipModuleLoadData(&out->module, code.data());
   if (e != hipSuccess) {
     *err = std::string("hipModuleLoadData: ") + hipGetErrorString(e);
     return -1;
   }
   struct { const char* name; hipFunction_t* f; } syms[] = {
-      {"crbm_build_tables", &out->build_tables}, {"crbm_update_tables", &out->update_tables}, {"crbm_update_tables_ipc", &out->update_tables_ipc}, {"crbm_hgv", &out->hgv}, {"crbm_gibbs", &out->gibbs},
+      {"crbm_build_tables", &out->build_tables}, {"crbm_build_gather_solo", &out->build_gather_solo}, {"crbm_update_tables", &out->update_tables}, {"crbm_update_tables_ipc", &out->update_tables_ipc}, {"crbm_hgv", &out->hgv}, {"crbm_gibbs", &out->gibbs},
       {"crbm_gibbs_sparse", &out->gibbs_sparse}, {"crbm_gibbs_sparse_stats", &out->gibbs_sparse_stats}, {"crbm_train_local", &out->train_local},
       {"crbm_stats_mfma_data", &out->stats_mfma_data},
       {"crbm_stats_mfma_model", &out->stats_mfma_model}, {"crbm_free_energy", &out->free_energy},

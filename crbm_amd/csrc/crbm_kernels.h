@@ -581,11 +581,15 @@ __device__ __forceinline__ void copy_tables(float* dst, const float* src) {
 //    The gather therefore yields z = -x*log2(e), so exp(-x) is one v_exp_f32
 //    (2^z) with no multiply; kernels that need x itself use x = -ln(2)*z.
 //    Pad columns k >= K get +1e30 in group 0: exp(-x) = inf, sigmoid -> 0.
-//  Tv[jr][ch][pat] (float4 over letters) = sum_{bit in pat} W[5ch+bit][:][M-1-jr]
+//  Tv[jr][ch][pat] (float4 over letters) = log2(e) * sum_{bit in pat} W[5ch+bit][:][M-1-jr]
 //  Tvr          = same for rc(W)                           (convRBM.py:279-287)
-//  Ws[jr+4][k]  (float4 over letters) = W[k][:][M-1-jr] for 0 <= jr < M, else 0   (sparse top-down)
+//  Ws[jr+4][k]  (float4 over letters) = log2(e) * W[k][:][M-1-jr] for 0 <= jr < M, else 0   (sparse top-down)
 //  Wsr          = same for rc(W)
+//  c            = log2(e) * c
+//    The top-down images carry log2(e) so that the softmax over the four letters is four v_exp_f32
+//    (2^(y - max)) without a multiply each (sample_letter); free_energy_body, which wants c itself, multiplies back.
 // ---------------------------------------------------------------------------
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 struct TablesArgs {
   const float* W;   // (K,4,M)
   const float* b;   // (K)
@@ -594,10 +598,11 @@ struct TablesArgs {
 };
 
 // entries first, first + stride, ... of the table images
-template <class C>
+// LIMIT: entries [0, LIMIT) only (Cfg::TAB: the gather table alone)
+template <class C, int LIMIT = C::TABLES_ALL>
 __device__ void build_tables_range(const TablesArgs& a, int first, int stride) {
   constexpr int K = C::K, M = C::M;
-  for (int idx = first; idx < C::TABLES_ALL; idx += stride) {
+  for (int idx = first; idx < LIMIT; idx += stride) {
     float val = 0.f;
     if (idx < C::TAB) {                                      // gather table
       const int t0 = idx;
@@ -611,7 +616,7 @@ __device__ void build_tables_range(const TablesArgs& a, int first, int stride) {
           }
         }
         if (g == 0) val += a.b[k];
-        val *= -1.4426950408889634f;
+        val *= -LOG2E;
       } else if (g == 0) {
         val = 1e30f;
       }
@@ -624,15 +629,16 @@ __device__ void build_tables_range(const TablesArgs& a, int first, int stride) {
         if (k < K && ((pat >> bit) & 1))
           val += rc ? a.W[(k * 4 + (3 - al)) * M + jr] : a.W[(k * 4 + al) * M + (M - 1 - jr)];
       }
+      val *= LOG2E;
     } else if (idx < C::TABLES) {
-      val = a.c[idx - C::OFF_C];
+      val = LOG2E * a.c[idx - C::OFF_C];
     } else if (idx < C::OFF_C2) {                            // sparse top-down tables, zero rows at both ends
       const bool rc = C::DS && idx >= C::OFF_WSR;
       const int t0 = idx - (rc ? C::OFF_WSR : C::OFF_WS);
       const int al = t0 & 3, k = (t0 >> 2) % K, jr = (t0 >> 2) / K - 4;
-      if (jr >= 0 && jr < M) val = rc ? a.W[(k * 4 + (3 - al)) * M + jr] : a.W[(k * 4 + al) * M + (M - 1 - jr)];
+      if (jr >= 0 && jr < M) val = LOG2E * (rc ? a.W[(k * 4 + (3 - al)) * M + jr] : a.W[(k * 4 + al) * M + (M - 1 - jr)]);
     } else {
-      val = a.c[idx - C::OFF_C2];
+      val = LOG2E * a.c[idx - C::OFF_C2];
     }
     a.out[idx] = val;
   }
@@ -641,6 +647,12 @@ __device__ void build_tables_range(const TablesArgs& a, int first, int stride) {
 template <class C>
 __device__ void build_tables_body(const TablesArgs& a) {
   build_tables_range<C>(a, (int)(blockIdx.x * blockDim.x + threadIdx.x), (int)(gridDim.x * blockDim.x));
+}
+// the gather table of another letter grouping (plain chain launches of small models take larger groups than the
+// fused training launch, whose LDS is shared with the statistics: crbm_api.hip, solo_group)
+template <class C>
+__device__ void build_gather_table_body(const TablesArgs& a) {
+  build_tables_range<C, C::TAB>(a, (int)(blockIdx.x * blockDim.x + threadIdx.x), (int)(gridDim.x * blockDim.x));
 }
 
 // ---------------------------------------------------------------------------
@@ -1185,7 +1197,9 @@ __device__ void stats_mfma_body(const StatsMfmaArgs& a, int bid = -1) {   // bid
 // for every chain of a tile, entirely in LDS (convRBM.py:397-408).
 // ---------------------------------------------------------------------------
 struct GibbsArgs {
-  const float* tables;
+  const float* tables;    // the model's table images (crbm_layout.h)
+  const float* tables_tf = nullptr;   // sparse variant: the gather table of THIS kernel's letter grouping when it is not the
+  int32_t off_ws = 0;                 // model's (then the top-down tables start at tables + off_ws); null: tables, Cfg::OFF_WS
   uint32_t* hm;        // [nchains][Lf][NW] in/out
   uint32_t* hmp;       // reverse strand (ds) or null
   uint32_t* vout;      // [nchains][LWs] letters of the last visible sample
@@ -1204,10 +1218,11 @@ struct GibbsArgs {
   StatsGeom sg;        // divGPC divides group indices of one tile
 };
 
-// letter of one visible position from its 4 top-down activations
+// letter of one visible position from its 4 top-down activations, given in units of log 2 (the tables carry log2(e))
 __device__ __forceinline__ uint32_t sample_letter(float y0, float y1, float y2, float y3, float u) {
   const float mx = fmaxf(fmaxf(y0, y1), fmaxf(y2, y3));
-  const float e0 = __expf(y0 - mx), e1 = __expf(y1 - mx), e2 = __expf(y2 - mx), e3 = __expf(y3 - mx);
+  const float e0 = __builtin_amdgcn_exp2f(y0 - mx), e1 = __builtin_amdgcn_exp2f(y1 - mx), e2 = __builtin_amdgcn_exp2f(y2 - mx),
+              e3 = __builtin_amdgcn_exp2f(y3 - mx);
   const float t = u * ((e0 + e1) + (e2 + e3));
   return (uint32_t)(t >= e0) + (uint32_t)(t >= e0 + e1) + (uint32_t)(t >= (e0 + e1) + e2);
 }
@@ -1280,8 +1295,8 @@ __device__ void gibbs_body(const GibbsArgs& a, int bid = -1) {   // bid: block o
   bool tables_done = (a.debug & 1) != 0;
   auto copy_all_tables = [&]() {
     if (SPARSE) {
-      copy_tables<C::TAB>(smem, a.tables);
-      copy_tables<C::WS * (1 + C::DS) + 4>(smem + C::SP_WS, a.tables + C::OFF_WS);
+      copy_tables<C::TAB>(smem, a.tables_tf ? a.tables_tf : a.tables);
+      copy_tables<C::WS * (1 + C::DS) + 4>(smem + C::SP_WS, a.tables + (a.tables_tf ? a.off_ws : C::OFF_WS));
     } else {
       copy_tables<C::TABLES>(smem, a.tables);
     }
@@ -1768,8 +1783,8 @@ __device__ void free_energy_body(const FeArgs& a) {
   copy_tables<C::TAB>(Tf, a.tables + C::OFF_TF);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-  const float* cg = a.tables + C::OFF_C;
-  const float c0 = cg[0], c1 = cg[1], c2 = cg[2], c3 = cg[3];
+  const float* cg = a.tables + C::OFF_C;          // log2(e) * c
+  const float c0 = LN2 * cg[0], c1 = LN2 * cg[1], c2 = LN2 * cg[2], c3 = LN2 * cg[3];
   for (int nn = blockIdx.x * nwaves + wave; nn < a.n; nn += gridDim.x * nwaves) {
     const uint32_t* row = a.letters + (size_t)nn * a.LW;
     float acc[KP];
@@ -2437,6 +2452,13 @@ __global__ void __launch_bounds__(256) vgh_dense_kernel(VghArgs a) {
       }
     }
   }
+}
+
+// One wave that does nothing for `ticks` of the GPU's wall clock: put in front of a partition's first chain launch
+// so that the partitions' launches interleave from the start (crbm_api.hip, launch_gibbs_parts)
+__global__ void __launch_bounds__(64) delay_kernel(unsigned long long ticks) {
+  const uint64_t t0 = realtime_ticks();
+  while (realtime_ticks() - t0 < ticks) short_sleep();
 }
 
 __global__ void __launch_bounds__(1024) reduce_partials_kernel(ReduceArgs a) { reduce_partials_body<false>(a); }

@@ -250,6 +250,8 @@ typedef struct crbm_launch_info {
                             model), 0 = dense tables (CRBM_TOPDOWN=dense, small models); fixed per handle  */
   int32_t activity_ppm;  /* hidden units on per million after the last crbm_sync / crbm_gibbs_steps, -1 = not read yet */
   int32_t stats_fused;   /* 1: the model half of the gradient statistics rides in the Gibbs launch of a training step */
+  int32_t chain_parts;   /* plain chain launches (crbm_gibbs_steps*) go out as this many launches of a share of the chains
+                            each, on streams of their own (the gibbs_* fields above then describe ONE of them)          */
 } crbm_launch_info;
 int crbm_get_launch_info(const crbm_handle* h, crbm_launch_info* out);
 /* Device-copy bandwidth (float4 copy kernel, HIP events, read + written bytes

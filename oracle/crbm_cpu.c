@@ -71,8 +71,20 @@ void crbm_cpu_gibbs_step(const float* W, const float* b, const float* c, int K, 
 #endif
 #pragma omp parallel
   {
-    float* y = (float*)malloc(sizeof(float) * 4 * (size_t)L);
-    float* x = (float*)malloc(sizeof(float) * (size_t)Lh);
+    /* per-thread scratch, allocated once per thread and kept between calls: y (4,L) top-down activations, x (K,Lh)
+     * bottom-up activations of one strand */
+    static __thread float* scratch = NULL;
+    static __thread size_t scratch_cap = 0;
+    const size_t need = (size_t)4 * L + (size_t)K * Lh;
+    if (scratch_cap < need) {
+      free(scratch);
+      scratch = (float*)malloc(sizeof(float) * need);
+      scratch_cap = need;
+    }
+    float* y = scratch;
+    float* x = scratch + (size_t)4 * L;
+    /* static schedule: a chain is always worked on by the same thread, which is also the first to touch its rows of
+     * h, h', v (the caller hands freshly allocated, untouched arrays to the first step) */
 #pragma omp for schedule(static)
     for (int nn = 0; nn < n; ++nn) {
       float* hn = h + (size_t)nn * K * Lh;
@@ -94,46 +106,51 @@ void crbm_cpu_gibbs_step(const float* W, const float* b, const float* c, int K, 
               for (int s = 0; s < Lh; ++s) yr[s] += wr * hpr[s];
             }
           }
-      /* softmax over the 4 letters + categorical sample */
-      for (int p = 0; p < L; ++p) {
-        const float y0 = y[p], y1 = y[L + p], y2 = y[2 * L + p], y3 = y[3 * L + p];
-        const float mx = fmaxf(fmaxf(y0, y1), fmaxf(y2, y3));
-        const float e0 = expf(y0 - mx), e1 = expf(y1 - mx), e2 = expf(y2 - mx), e3 = expf(y3 - mx);
-        const float sum = (e0 + e1) + (e2 + e3);
+      /* softmax over the 4 letters + categorical sample: one Philox call serves 4 positions */
+      for (int p0 = 0; p0 < L; p0 += 4) {
         uint32_t r[4];
-        philox4x32_7(seq_offset + (uint32_t)nn, (uint32_t)(p >> 2), 2u << 28, step, k0, k1, r);
-        const float t = u01(r[p & 3]) * sum;
-        const int l = (t >= e0) + (t >= e0 + e1) + (t >= (e0 + e1) + e2);
-        vn[p] = l == 0; vn[L + p] = l == 1; vn[2 * L + p] = l == 2; vn[3 * L + p] = l == 3;
+        philox4x32_7(seq_offset + (uint32_t)nn, (uint32_t)(p0 >> 2), 2u << 28, step, k0, k1, r);
+        for (int p = p0; p < p0 + 4 && p < L; ++p) {
+          const float y0 = y[p], y1 = y[L + p], y2 = y[2 * L + p], y3 = y[3 * L + p];
+          const float mx = fmaxf(fmaxf(y0, y1), fmaxf(y2, y3));
+          const float e0 = expf(y0 - mx), e1 = expf(y1 - mx), e2 = expf(y2 - mx), e3 = expf(y3 - mx);
+          const float sum = (e0 + e1) + (e2 + e3);
+          const float t = u01(r[p & 3]) * sum;
+          const int l = (t >= e0) + (t >= e0 + e1) + (t >= (e0 + e1) + e2);
+          vn[p] = l == 0; vn[L + p] = l == 1; vn[2 * L + p] = l == 2; vn[3 * L + p] = l == 3;
+        }
       }
       /* bottom-up, both strands: x[k][s] = b[k] + sum_{a,j} Wf[k,a,j] v[a,s+j] */
       for (int strand = 0; strand <= ds; ++strand) {
         float* out = strand ? hpn : hn;
         float* pout = strand ? (php ? php + (size_t)nn * K * Lh : NULL) : (ph ? ph + (size_t)nn * K * Lh : NULL);
         for (int k = 0; k < K; ++k) {
-          for (int s = 0; s < Lh; ++s) x[s] = b[k];
+          float* xk = x + (size_t)k * Lh;
+          for (int s = 0; s < Lh; ++s) xk[s] = b[k];
           for (int a = 0; a < 4; ++a)
             for (int j = 0; j < M; ++j) {
               const float w = strand ? W[(k * 4 + (3 - a)) * M + (M - 1 - j)] : W[(k * 4 + a) * M + j];
               const float* vr = vn + a * L + j;
-              for (int s = 0; s < Lh; ++s) x[s] += w * vr[s];
+              for (int s = 0; s < Lh; ++s) xk[s] += w * vr[s];
             }
-          for (int s = 0; s < Lh; ++s) {
-            /* 24-bit uniform of unit k: coarse and fine 12-bit fields of two
-             * Philox calls shared by the 10 units of group k/10 */
+        }
+        /* 24-bit uniform of unit k: coarse and fine 12-bit fields of two Philox calls shared by the 10 units of
+         * group k/10 -- drawn once per (position, group) */
+        for (int s = 0; s < Lh; ++s)
+          for (int g = 0; 10 * g < K; ++g) {
             uint32_t rc[4], rf[4];
-            const float p = 1.0f / (1.0f + expf(-x[s]));
-            const uint32_t w2 = (1u << 28) | ((uint32_t)strand << 24) | (uint32_t)(k / 10);
+            const uint32_t w2 = (1u << 28) | ((uint32_t)strand << 24) | (uint32_t)g;
             philox4x32_7(seq_offset + (uint32_t)nn, (uint32_t)s, w2, step, k0, k1, rc);
             philox4x32_7(seq_offset + (uint32_t)nn, (uint32_t)s, w2 | (1u << 16), step, k0, k1, rf);
-            const float u = (float)(field12(rc, k % 10) * 4096u + field12(rf, k % 10)) * 5.9604644775390625e-8f;
-            out[(size_t)k * Lh + s] = p > u ? 1.0f : 0.0f;
-            if (pout) pout[(size_t)k * Lh + s] = p;
+            for (int i = 0; i < 10 && 10 * g + i < K; ++i) {
+              const int k = 10 * g + i;
+              const float p = 1.0f / (1.0f + expf(-x[(size_t)k * Lh + s]));
+              const float u = (float)(field12(rc, i) * 4096u + field12(rf, i)) * 5.9604644775390625e-8f;
+              out[(size_t)k * Lh + s] = p > u ? 1.0f : 0.0f;
+              if (pout) pout[(size_t)k * Lh + s] = p;
+            }
           }
-        }
       }
     }
-    free(y);
-    free(x);
   }
 }
