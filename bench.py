@@ -182,7 +182,7 @@ def cpu_baseline(cfg, budget_s=10.0):
     return out
 
 
-def roofline_object(name, cfg, info, step_s, counters, counters_src, copy_gbs, state_bytes, us_per_step_k16=None):
+def roofline_object(name, cfg, info, step_s, counters, counters_src, copy_gbs, state_bytes, us_per_step_k16=None, clock_mhz=None):
     """The roofline object of the chain kernel at one configuration.  step_s: HIP-event time of one launch step (all
     chains advanced by cfg["k"] Gibbs steps) in seconds; counters: {name: mean per launch} from measure_pmc or None."""
     k = cfg["k"]
@@ -216,6 +216,7 @@ def roofline_object(name, cfg, info, step_s, counters, counters_src, copy_gbs, s
                                 "equivalent-dense rate, not a bandwidth utilisation (the chain state is bit-packed, so it may "
                                 "exceed 1); north_star's '>= 50 % of HBM roofline' is stated in these units",
             "state_bytes_per_launch": state_bytes,
+            "shader_clock_mhz_timed_run": clock_mhz if clock_mhz and clock_mhz > 100.0 else None,   # sampled by the timed launches themselves
             "us_per_step_at_16_steps_per_launch": us_per_step_k16}
     if counters:
         # All counters are means per LAUNCH of the kernel (one partition); a step is `parts` of them.
@@ -227,12 +228,14 @@ def roofline_object(name, cfg, info, step_s, counters, counters_src, copy_gbs, s
         traffic = parts * (2.0 * counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024.0
         launch_cycles = counters["SQ_BUSY_CYCLES"] / N_SE
         serial_us = counters.get("SERIAL_NS", 0.0) / 1e3
-        clock_mhz = launch_cycles / serial_us if serial_us > 0 else None
+        clock_counters = launch_cycles / serial_us if serial_us > 0 else None      # clock of the serialised (profiled) launches
+        clock_timed = clock_mhz if clock_mhz and clock_mhz > 100.0 else None        # clock of the timed launches (probe)
         valu_cycles = parts * 4.0 * counters["SQ_ACTIVE_INST_VALU"] / N_SIMD
-        if parts == 1 or clock_mhz is None:
-            step_cycles = parts * launch_cycles          # one launch = one step: both counters of the same launches, no clock needed
-            clock_mhz = step_cycles / (1e6 * step_s)
+        if parts == 1:
+            step_cycles = launch_cycles                  # one launch = one step: both counters of the same launches, no clock needed
+            clock_mhz = clock_timed or step_cycles / (1e6 * step_s)
         else:
+            clock_mhz = clock_timed or clock_counters
             step_cycles = 1e6 * step_s * clock_mhz
         roof.update({
             "bound": "valu_issue", "achieved": valu_cycles, "peak": step_cycles,
@@ -246,6 +249,7 @@ def roofline_object(name, cfg, info, step_s, counters, counters_src, copy_gbs, s
             "valu_cycles_per_wave_inst": 4.0 * counters["SQ_ACTIVE_INST_VALU"] / counters["SQ_INSTS_VALU"],
             "valu_issue_us": valu_cycles / clock_mhz,
             "shader_clock_mhz_during_launch": clock_mhz,
+            "shader_clock_mhz_timed_run": clock_timed, "shader_clock_mhz_counter_pass": clock_counters,
             "kernel_serialised_us": serial_us or None,
             "kernel_avg_us": (counters["TRACE_AVG_NS"] / 1e3) if counters.get("TRACE_AVG_NS") else None,
             "kernel_trace_calls": counters.get("TRACE_CALLS"),
@@ -254,7 +258,8 @@ def roofline_object(name, cfg, info, step_s, counters, counters_src, copy_gbs, s
             "note": "the kernel is bound by vector-instruction issue (and the LDS gathers behind it), not by HBM: "
                     "frac = SIMD vector-issue-busy cycles / step cycles from PMC counters of the same kernel on this box "
                     "(counter collection serialises the launches; with partitioned launches the step's cycles are its HIP-event "
-                    "time x the clock those serialised launches ran at); hbm_actual_frac prices the measured HBM bytes against 8 TB/s"})
+                    "time x the shader clock the timed launches themselves sampled); hbm_actual_frac prices the "
+                    "measured HBM bytes against 8 TB/s"})
     else:
         roof.update({"bound": "valu_issue", "achieved": None, "peak": None, "unit": "shader cycles per step",
                      "frac": None, "traffic": None, "note": "no counters available: " + str(counters_src)})
@@ -299,6 +304,8 @@ def other_config(name, pmc, pmc_note, copy_gbs, steps=40, warmup=10):
     t0 = time.perf_counter()
     model._call("crbm_time_gibbs", k, steps, ctypes.byref(ms))
     wall = time.perf_counter() - t0
+    clock = ctypes.c_float()
+    model._call("crbm_last_shader_clock", ctypes.byref(clock))
     info = _lib.CrbmLaunchInfo()
     lib.crbm_get_launch_info(h, ctypes.byref(info))
     step_s = ms.value / 1e3 / steps
@@ -306,7 +313,8 @@ def other_config(name, pmc, pmc_note, copy_gbs, steps=40, warmup=10):
            "gibbs_steps_per_launch": k,
            "ms_per_launch": 1e3 * wall / steps, "device_ms_per_launch": 1e3 * step_s,
            "gibbs_steps_per_s": k * steps / wall,
-           "roofline": roofline_object(name, cfg, info, step_s, pmc, pmc_note, copy_gbs, int(lib.crbm_gibbs_state_bytes(h))),
+           "roofline": roofline_object(name, cfg, info, step_s, pmc, pmc_note, copy_gbs, int(lib.crbm_gibbs_state_bytes(h)),
+                                       clock_mhz=float(clock.value)),
            "launch": launch_object(info)}
     n = cfg["chains"]
     D = synthetic_onehot(n, cfg["L"], seed=1234)
@@ -528,23 +536,23 @@ def main():
     k = cfg["k"]
 
     def barrier():
-        model._call("crbm_sync")      # this rank's stream is idle ...
-        control.barrier()             # ... and so is everybody else's
+        model._call("crbm_wait_idle")     # this rank's streams are idle ...
+        control.barrier()                 # ... and so are everybody else's
 
-    # device-copy bandwidth of this GPU (the measured ceiling quoted beside the 8 TB/s spec); taken first:
-    # 6 GiB of copies also bring the clocks up before the short runs the driver asks for
     copy_gbs = ctypes.c_float()
-    model._call("crbm_copy_bandwidth", 1 << 30, 5, ctypes.byref(copy_gbs))
-    # chains start at h = 0 (convRBM.py:168): burn-in steps, then the W warm-up launches.
+    if os.environ.get("CRBM_BENCH_COPY_FIRST", "0") == "1":      # (A/B switch: the copy test in front of the timed region, as until round 3)
+        model._call("crbm_copy_bandwidth", 1 << 30, 5, ctypes.byref(copy_gbs))
+    # chains start at h = 0 (convRBM.py:168): 500 burn-in steps, then the W warm-up launches.
     # The burn-in is part of building the workload, not of the measurement: a persistent chain is never at
-    # h = 0 in training -- and it is what brings the GPU to its sustained clock: the driver's timed region is 20
-    # launches (0.4 ms), and the part takes tens of milliseconds of load to settle (tools/ramp_probe.py, same
-    # process, 20-launch windows: 20.2-21.3 us per step right behind 500 burn-in steps, 18.5 behind a 2000-step
-    # window, 20.5 again after 10 ms of idling; the steady state of a 2000-launch run is 17.4).  3000 steps are
-    # 55 ms at config #2.  warmup_effective in the line counts them.
+    # h = 0 in training.  (Its length does not change what the driver's short timed region sees: 500, 3000,
+    # 10 000 or 30 000 steps all leave the 20-launch window at 20.4-21.9 us per step with the shader clock at
+    # 2.13-2.26 GHz, against 17.3 us at 2.35 GHz in the steady state of a 2000-launch run -- the part needs
+    # milliseconds of uninterrupted load to reach its sustained clock, and the barrier + synchronise the
+    # contract puts in front of the timed region is an interruption: gpurun_out/r4_tests/burnin.txt,
+    # tools/ramp_probe.py.  shader_clock_mhz_timed_run in the line is the clock the timed launches saw.)
     # (as launches of k steps like the timed ones: every launch of the chain kernel in this process is then
     # the same work, and a profiler's per-kernel average is that of the timed launches)
-    burn_launches = max(1, int(os.environ.get("CRBM_BENCH_BURNIN", "3000")) // k)
+    burn_launches = max(1, int(os.environ.get("CRBM_BENCH_BURNIN", "500")) // k)
     for _ in range(burn_launches):
         model._call("crbm_gibbs_steps_async", k)
     model._call("crbm_sync")
@@ -558,6 +566,8 @@ def main():
     model._call("crbm_time_gibbs", k, args.steps, ctypes.byref(total_ms))     # returns once its last launch has completed
     wall = time.perf_counter() - t0          # this rank's K steps, start barrier -> own stream idle; the closing barrier
     barrier()                                # (TCP round trips, a blocking read-back of the activity monitor) is not step time
+    clock_mhz = ctypes.c_float()
+    model._call("crbm_last_shader_clock", ctypes.byref(clock_mhz))     # sampled by the timed launches themselves
     wall, kernel_s = control.allreduce_max([wall, total_ms.value / 1e3])
     launches = args.steps
     steps_done = args.steps * k                  # Gibbs steps per rank in the timed region
@@ -574,6 +584,10 @@ def main():
         model._call("crbm_time_gibbs", 16, 40, ctypes.byref(multi_ms))
         us_per_step_k16 = 1e3 * multi_ms.value / (40 * 16)
 
+    # device-copy bandwidth of this GPU (the measured ceiling quoted beside the 8 TB/s spec) -- behind the timed region
+    if copy_gbs.value == 0.0:
+        model._call("crbm_copy_bandwidth", 1 << 30, 5, ctypes.byref(copy_gbs))
+
     # hidden-unit activity of the chain (workload descriptor, after timing)
     hf, _ = model.get_fantasy()
     activity = float(hf.mean())
@@ -583,7 +597,7 @@ def main():
         info = _lib.CrbmLaunchInfo()
         lib.crbm_get_launch_info(h, ctypes.byref(info))
         roof = roofline_object(args.config, cfg, info, kernel_s / launches, pmc, pmc_note, float(copy_gbs.value),
-                               int(lib.crbm_gibbs_state_bytes(h)), us_per_step_k16)
+                               int(lib.crbm_gibbs_state_bytes(h)), us_per_step_k16, clock_mhz=float(clock_mhz.value))
         out = {
             "metric": "Gibbs-steps/sec (PCD-1) at batch 8192x4x200, 10 motifs len 15" if args.config == "cfg2"
                       else "Gibbs-steps/sec, " + cfg["desc"],

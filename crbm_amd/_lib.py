@@ -82,6 +82,7 @@ SIGNATURES = {
     "crbm_gibbs_steps": (_I32, [_H, _I32]),
     "crbm_gibbs_steps_async": (_I32, [_H, _I32]),
     "crbm_sync": (_I32, [_H]),
+    "crbm_wait_idle": (_I32, [_H]),
     "crbm_time_gibbs": (_I32, [_H, _I32, _I32, _F]),
     "crbm_time_train": (_I32, [_H, _I32, _I32, _I32, _F]),
     "crbm_h_given_v": (_I32, [_H, _F, _I32, _I32, _I32, _U32, _F, _F, _F]),
@@ -113,6 +114,7 @@ SIGNATURES = {
     "crbm_time_allreduce": (_I32, [_H, _I32, _F]),
     "crbm_get_launch_info": (_I32, [_H, ctypes.POINTER(CrbmLaunchInfo)]),
     "crbm_copy_bandwidth": (_I32, [_H, ctypes.c_int64, _I32, _F]),
+    "crbm_last_shader_clock": (_I32, [_H, _F]),
     "crbm_gibbs_state_bytes": (ctypes.c_int64, [_H]),
 }
 

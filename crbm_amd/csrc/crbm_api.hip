@@ -219,6 +219,9 @@ struct crbm_handle {
   uint32_t ipc_step = 0;               // steps published so far (the flag value of the next one is ipc_step + 1)
   bool ipc_published = false;          // the column reduction of the running step has written and flagged the published buffer itself
   uint32_t* d_ticket = nullptr;        // arrival counter of that launch (zero between launches)
+  unsigned long long* d_probe = nullptr;   // {wall ticks, shader cycles, scratch, scratch} summed over the launches of all crbm_time_gibbs calls
+  unsigned long long probe_base[2] = {0, 0}, probe_last[2] = {0, 0};   // the sums before / after the last call
+  bool probe_on = false;
   unsigned long long ipc_timeout_ticks = 0;   // bound of an update launch's wait for its peers, in ticks of the GPU's wall clock
   std::string err;
 };
@@ -370,6 +373,7 @@ int prepare_gibbs(crbm_handle* h, int steps, ReduceArgs* model_reduce, GibbsArgs
   a.steps = steps;
   a.rng = rng_view(h, h->gibbs_step, h->chain_offset);
   a.ones = h->d_nset;
+  a.clock = h->probe_on ? h->d_probe : nullptr;
   a.debug = env_int("CRBM_GIBBS_DEBUG", 0);
   h->nset_slots = h->gibbs_grid * (h->gibbs_threads / 64);
   a.nblocks = h->gibbs_grid;
@@ -496,6 +500,7 @@ int launch_gibbs_parts(crbm_handle* h, int steps) {
     ap.nchains = n;
     ap.rng.seq_offset = a.rng.seq_offset + (uint32_t)c0;
     ap.ones = a.ones + (size_t)p * grid * waves;
+    if (p > 0) ap.clock = nullptr;
     ap.nblocks = (int)grid;
     if (p > 0) {          // the partition's own thread enqueues it
       PartWorker* w = h->part_worker[p];
@@ -1094,6 +1099,11 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
   hipDeviceProp_t prop;
   TRY(hipGetDeviceProperties(&prop, hh->device));
   hh->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  {
+    int khz = 0;      // ticks of the GPU's constant-rate clock (s_memrealtime) per millisecond
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, hh->device) == hipSuccess && khz > 0) hh->wall_khz = khz;
+    (void)hipGetLastError();
+  }
   // launch geometry, then the model-specific kernels (hiprtc; cached on disk)
   hh->has_dense = hh->ms.DENSE != 0;
   for (int v = hh->has_dense ? 0 : 1; v < 2; ++v) {
@@ -1160,11 +1170,6 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
     TRY(hipEventCreateWithFlags(&hh->ev_parts_fork, hipEventDisableTiming));
     TRY(hipEventCreate(&hh->ev_cal0));
     TRY(hipEventCreate(&hh->ev_cal1));
-    {
-      int khz = 0;
-      if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, hh->device) == hipSuccess && khz > 0) hh->wall_khz = khz;
-      (void)hipGetLastError();
-    }
     for (int p = 0; p < hh->chain_parts; ++p) {
       TRY(hipStreamCreateWithFlags(&hh->part_stream[p], hipStreamNonBlocking));
       TRY(hipEventCreate(&hh->part_done[p]));     // with timestamps: crbm_time_gibbs reads them
@@ -1203,6 +1208,7 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
   }
   TRY(hipMalloc((void**)&hh->d_sums, (size_t)hh->sl.count * 4)); TRY(hipMemset(hh->d_sums, 0, (size_t)hh->sl.count * 4));
   TRY(hipMalloc((void**)&hh->d_ticket, 16)); TRY(hipMemset(hh->d_ticket, 0, 16));
+  TRY(hipMalloc((void**)&hh->d_probe, 32)); TRY(hipMemset(hh->d_probe, 0, 32));
 #undef TRY
   hh->tables_dirty = true;
   {
@@ -1246,7 +1252,7 @@ int crbm_destroy(crbm_handle* h) {
   for (int r = 0; r < IPC_MAX_RANKS; ++r)
     if (h->ipc_peer[r] && h->ipc_peer[r] != h->ipc_buf) (void)hipIpcCloseMemHandle(h->ipc_peer[r]);
   if (h->ipc_buf) (void)hipFree(h->ipc_buf);
-  void* ptrs[] = {h->dW2, h->db2, h->dc2, h->dvW2, h->dvb2, h->dvc2, h->dW, h->db, h->dc, h->dvW, h->dvb, h->dvc, h->d_hm, h->d_hmp, h->d_vf, h->d_flags, h->d_ones, h->d_nset, h->d_sums, h->d_ticket, h->d_tables, h->d_tf_solo};
+  void* ptrs[] = {h->dW2, h->db2, h->dc2, h->dvW2, h->dvb2, h->dvc2, h->dW, h->db, h->dc, h->dvW, h->dvb, h->dvc, h->d_hm, h->d_hmp, h->d_vf, h->d_flags, h->d_ones, h->d_nset, h->d_sums, h->d_ticket, h->d_tables, h->d_tf_solo, h->d_probe};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   h->stage.release(); h->stage2.release(); h->out_a.release(); h->out_b.release(); h->out_c.release();
@@ -1535,6 +1541,13 @@ int crbm_sync(crbm_handle* h) {
   return refresh_activity(h);
 }
 
+// every launch of this handle has completed (no read-back of the activity monitor: crbm_sync does that too)
+int crbm_wait_idle(crbm_handle* h) {
+  ENTER();
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return ipc_check(h);
+}
+
 int crbm_gibbs_steps(crbm_handle* h, int32_t k) {
   int rc = crbm_gibbs_steps_async(h, k);
   if (rc) return rc;
@@ -1554,6 +1567,11 @@ static hipError_t spin_until(hipEvent_t ev) {
 int crbm_time_gibbs(crbm_handle* h, int32_t k, int32_t launches, float* total_ms) {
   ENTER();
   ARGCHK(k >= 0 && launches >= 1 && total_ms, "bad argument");   // k = 0: state load/store only (profiling)
+  // (the launches add their durations to d_probe; the sums before this call were read when the previous one ended:
+  //  nothing touches the GPU here before the opening event)
+  h->probe_base[0] = h->probe_last[0]; h->probe_base[1] = h->probe_last[1];
+  h->probe_on = true;
+  struct ProbeOff { crbm_handle* h; ~ProbeOff() { h->probe_on = false; } } probe_off{h};
   h->main_idle_hint = hipStreamQuery(h->stream) == hipSuccess;   // (the opening event below does not count as work to wait for)
   (void)hipGetLastError();
   HIPCHK(hipEventRecord(h->ev0, h->stream));
@@ -1903,21 +1921,27 @@ int hit_summary_any(crbm_handle* h, const RowSource& src, float* hmax, float* hm
   // a block covers one chunk of 64*HIT_NI positions; its (PC,K) sums share the LDS with the tables
   const int PC = 64 * h->ms.HIT_NI;
   const int nchunks = (Lh + PC - 1) / PC;
-  const unsigned lds = (unsigned)(tabs + (size_t)PC * K * 4);
+  const unsigned lds = (unsigned)(tabs + (size_t)PC * K * 8);    // tables + the block's fixed-point position sums
   ARGCHK(lds <= 160u * 1024u, "model too large for the hit-summary kernel");
+  // sums over sequences per (motif, position): 64-bit fixed point (HIT_FX units), so that the order in which blocks,
+  // slabs and the two streams add does not show in the result
+  unsigned long long* pos_fx = nullptr;
   if (posmean) {
-    HIPCHK(h->out_c.ensure((size_t)K * Lh));
-    HIPCHK(hipMemsetAsync(h->out_c.p, 0, (size_t)K * Lh * 4, h->stream));
+    HIPCHK(h->out_c.ensure((size_t)2 * K * Lh + 2));
+    pos_fx = reinterpret_cast<unsigned long long*>(h->out_c.p);
+    HIPCHK(hipMemsetAsync(pos_fx, 0, (size_t)K * Lh * 8, h->stream));
   }
   rc = sweep_begin(h);          // also orders the memset before both streams' kernels
   if (rc) return rc;
   const int slab = sweep_slab(src, (size_t)2 * K * sizeof(float));
   int prev_start = -1, prev_cnt = 0;
   SweepSet prev = sweep_set(h, 0);
+  // layout of a set's `ob` when the positions come in several chunks: [cnt*K fixed-point sums][cnt*K means]
+  auto mean_of = [&](const SweepSet& set, int cnt) { return nchunks > 1 ? set.ob->p + (size_t)2 * cnt * K : set.ob->p; };
   auto collect = [&]() -> int {
     if (prev_start < 0) return CRBM_OK;
     if (hmax) HIPCHK(hipMemcpyAsync(hmax + (size_t)prev_start * K, prev.oa->p, (size_t)prev_cnt * K * sizeof(float), hipMemcpyDeviceToHost, prev.st));
-    if (hmean) HIPCHK(hipMemcpyAsync(hmean + (size_t)prev_start * K, prev.ob->p, (size_t)prev_cnt * K * sizeof(float), hipMemcpyDeviceToHost, prev.st));
+    if (hmean) HIPCHK(hipMemcpyAsync(hmean + (size_t)prev_start * K, mean_of(prev, prev_cnt), (size_t)prev_cnt * K * sizeof(float), hipMemcpyDeviceToHost, prev.st));
     HIPCHK(hipStreamSynchronize(prev.st));
     return CRBM_OK;
   };
@@ -1928,20 +1952,26 @@ int hit_summary_any(crbm_handle* h, const RowSource& src, float* hmax, float* hm
     rc = sweep_rows(h, src, start, cnt, set, &rows);
     if (rc) return rc;
     HIPCHK(set.oa->ensure((size_t)cnt * K));
-    HIPCHK(set.ob->ensure((size_t)cnt * K));
+    HIPCHK(set.ob->ensure((size_t)cnt * K * (nchunks > 1 ? 3 : 1)));
     if (nchunks > 1) {
       HIPCHK(hipMemsetAsync(set.oa->p, 0, (size_t)cnt * K * 4, set.st));
-      HIPCHK(hipMemsetAsync(set.ob->p, 0, (size_t)cnt * K * 4, set.st));
+      HIPCHK(hipMemsetAsync(set.ob->p, 0, (size_t)cnt * K * 8, set.st));
     }
     HitArgs a;
     a.tables = h->d_tables; a.letters = rows;
     a.n = cnt; a.L = L; a.Lh = Lh; a.LW = letter_words(L);
     a.hmax = hmax ? set.oa->p : nullptr;
-    a.hsum = hmean ? set.ob->p : nullptr;
+    a.hsum = (hmean && nchunks == 1) ? set.ob->p : nullptr;
+    a.hsum_fx = (hmean && nchunks > 1) ? reinterpret_cast<unsigned long long*>(set.ob->p) : nullptr;
     a.inv_Lh = 1.0f / (float)Lh;
-    a.pos = posmean ? h->out_c.p : nullptr;     // both streams add atomically
+    a.pos_fx = pos_fx;                          // both streams add (integers: any order)
     const unsigned gx = (unsigned)std::max(1, std::min((cnt + 3) / 4, std::max(1, h->num_cu * 8 / nchunks)));
     HIPCHK(jit_launch(h->jk.hit_summary, a, gx, (unsigned)nchunks, 256, lds, set.st));
+    if (a.hsum_fx) {
+      hipLaunchKernelGGL(hit_finalize_kernel, dim3(grid_for((long)cnt * K, 256, h->num_cu * 4)), dim3(256), 0, set.st, a.hsum_fx,
+                         mean_of(set, cnt), (size_t)cnt * K, a.inv_Lh / HIT_FX);
+      HIPCHK(hipGetLastError());
+    }
     rc = collect();
     if (rc) return rc;
     prev = set; prev_start = start; prev_cnt = cnt;
@@ -1951,11 +1981,11 @@ int hit_summary_any(crbm_handle* h, const RowSource& src, float* hmax, float* hm
   rc = sweep_finish(h, src);
   if (rc) return rc;
   if (posmean) {
-    rc = copy_out(h, posmean, h->out_c.p, (size_t)K * Lh);
-    if (rc) return rc;
+    std::vector<unsigned long long> fx((size_t)K * Lh);
+    HIPCHK(hipMemcpyAsync(fx.data(), pos_fx, fx.size() * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    const float inv = 1.0f / (float)n;
-    for (size_t i = 0; i < (size_t)K * Lh; ++i) posmean[i] *= inv;
+    const double inv = 1.0 / ((double)n * (double)HIT_FX);
+    for (size_t i = 0; i < fx.size(); ++i) posmean[i] = (float)((double)fx[i] * inv);
   }
   return CRBM_OK;
 }
@@ -2309,6 +2339,19 @@ int crbm_copy_bandwidth(crbm_handle* h, int64_t bytes, int32_t reps, float* gb_p
   (void)hipFree(src); (void)hipFree(dst);
   if (e != hipSuccess) return fail(h, CRBM_ERR_HIP, std::string("copy bandwidth: ") + hipGetErrorString(e));
   *gb_per_s = (float)(2.0 * (double)n4 * 16.0 * reps / (ms * 1e-3) / 1e9);   // bytes read + written
+  return CRBM_OK;
+}
+
+// Shader clock during the launches of the last crbm_time_gibbs call: block 0 of every launch (of partition 0) adds its
+// duration in wall-clock ticks and in shader cycles (GibbsArgs::clock); MHz = cycles / ticks x tick rate.  0 if unknown.
+int crbm_last_shader_clock(crbm_handle* h, float* mhz) {
+  ENTER();
+  ARGCHK(mhz, "null argument");
+  *mhz = 0.f;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpy(h->probe_last, h->d_probe, sizeof(h->probe_last), hipMemcpyDeviceToHost));
+  const unsigned long long ticks = h->probe_last[0] - h->probe_base[0], cycles = h->probe_last[1] - h->probe_base[1];
+  if (ticks) *mhz = (float)((double)cycles / ((double)ticks / (h->wall_khz / 1000.0)));
   return CRBM_OK;
 }
 

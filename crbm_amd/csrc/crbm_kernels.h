@@ -87,6 +87,7 @@ __device__ __forceinline__ void short_sleep() { __builtin_amdgcn_s_sleep(8); }
 // the GPU's constant-rate wall clock (s_memrealtime; hipDeviceAttributeWallClockRate ticks per millisecond): bounds
 // the waits for another process in TIME, whatever the shader clock does
 __device__ __forceinline__ uint64_t realtime_ticks() { return __builtin_amdgcn_s_memrealtime(); }
+__device__ __forceinline__ uint64_t shader_cycles() { return __builtin_amdgcn_s_memtime(); }   // counts shader clocks
 // x = hi + lo with both halves f16 (round to nearest): 22 significant bits, v_cvt_pk_f16_f32 +
 // v_cvt_f32_f16 + v_pk_add_f32 per pair
 __device__ __forceinline__ void split_f16(const float (&x)[8], HalfFrag& hi, HalfFrag& lo) {
@@ -139,6 +140,7 @@ __device__ __forceinline__ void fence_acquire_system() { __atomic_thread_fence(_
 __device__ __forceinline__ uint32_t ticket_add(uint32_t* p) { return __atomic_fetch_add(p, 1u, __ATOMIC_ACQ_REL); }
 __device__ __forceinline__ void short_sleep() {}
 __device__ __forceinline__ uint64_t realtime_ticks() { return emu::realtime_ticks(); }   // microseconds
+__device__ __forceinline__ uint64_t shader_cycles() { return emu::realtime_ticks(); }
 __device__ __forceinline__ void split_f16(const float (&x)[8], HalfFrag& hi, HalfFrag& lo) { emu::split_f16(x, hi.r, lo.r); }
 __device__ __forceinline__ floatx4 mfma_16x16x32_f16(const HalfFrag& a, const HalfFrag& b, floatx4 c) {
   float d[4] = {c[0], c[1], c[2], c[3]};
@@ -1211,6 +1213,8 @@ struct GibbsArgs {
   int32_t steps;
   RngView rng;
   uint32_t* ones;      // [gridDim.x * waves per block] set bits of the final hidden state per wave (activity monitor), may be null
+  unsigned long long* clock = nullptr;   // null, or {sum of wall ticks, sum of shader cycles, scratch, scratch}: block 0 adds the duration of
+                               // this launch in both clocks (their ratio is the shader clock WHILE the kernel ran: crbm_time_gibbs)
   int32_t debug;       // profiling only: 1 skips the table copy, 2 the state load, 4 the state store
   // STATS variant only: the model half of the gradient statistics rides in the last h|v pass
   int32_t nblocks;     // blocks [0, nblocks) of the launch run the chain (0: the whole grid)
@@ -1307,6 +1311,10 @@ __device__ void gibbs_body(const GibbsArgs& a, int bid = -1) {   // bid: block o
   const uint32_t per = (uint32_t)(a.Lf * NW);           // state words per chain
   const int ntiles = (a.nchains + a.S - 1) / a.S;
   if (bid < 0) bid = (int)blockIdx.x;
+  if (a.clock && bid == 0 && threadIdx.x == 0) {        // both clocks at the start of the launch, parked in memory (no live registers)
+    a.clock[2] = realtime_ticks();
+    a.clock[3] = shader_cycles();
+  }
   const int nblk = a.nblocks > 0 ? a.nblocks : (int)gridDim.x;
   int nset = 0;
   // statistics state (STATS): the wave's LDS slice, accumulator tiles, letter counts
@@ -1727,6 +1735,10 @@ __device__ void gibbs_body(const GibbsArgs& a, int bid = -1) {   // bid: block o
     const float tot = wave_sum((float)nset);
     if ((threadIdx.x & 63) == 0) a.ones[bid * (blockDim.x >> 6) + (threadIdx.x >> 6)] = (uint32_t)tot;
   }
+  if (a.clock && bid == 0 && threadIdx.x == 0) {
+    a.clock[0] += realtime_ticks() - a.clock[2];
+    a.clock[1] += shader_cycles() - a.clock[3];
+  }
   if constexpr (STATS) stats_mfma_finish<C, false>(a.sg, smem, 0, bid, sacc, vcount);
 }
 
@@ -1839,17 +1851,23 @@ __device__ void free_energy_body(const FeArgs& a) {
 // This kernel produces those three reductions directly, so the dense
 // (n,K,1,Lh) tensor never exists.  One wave per sequence; a lane owns HIT_NI
 // positions (stride 64) of the chunk blockIdx.y of 64*HIT_NI positions and keeps
-// their sums over sequences in registers; chunks are combined with atomics.
+// their sums over sequences in registers.  Whatever is combined across waves, blocks
+// or chunks is combined in FIXED POINT (2^-30 units, 64-bit integer atomics): integer
+// addition does not care about the order, so the sums are the same bits in every run
+// (float atomics gave run-to-run differences in the last place).
 // ===========================================================================
+constexpr float HIT_FX = 1073741824.0f;          // 2^30 units per 1.0: probabilities are <= 1, sums stay far below 2^63
 struct HitArgs {
   const float* tables;
   const uint32_t* letters;
   int32_t n, L, Lh, LW;
   float* hmax;      // (n,K) max over positions   (zero-initialised when gridDim.y > 1)
-  float* hsum;      // (n,K) mean over positions  (zero-initialised when gridDim.y > 1)
+  float* hsum;      // (n,K) mean over positions, written directly when gridDim.y == 1
+  unsigned long long* hsum_fx;   // (n,K) fixed-point sums over positions when gridDim.y > 1 (zero-initialised; hit_finalize_kernel)
   float inv_Lh;     // 1 / Lh
-  float* pos;       // (K,Lh) sum over sequences, accumulated atomically (zero-initialised), or null
+  unsigned long long* pos_fx;    // (K,Lh) fixed-point sums over sequences (zero-initialised), or null
 };
+__device__ __forceinline__ unsigned long long to_fx(float v) { return (unsigned long long)(v * HIT_FX); }
 
 template <class C>
 __device__ void hit_summary_body(const HitArgs& a) {
@@ -1857,11 +1875,11 @@ __device__ void hit_summary_body(const HitArgs& a) {
   constexpr bool BOTH = !C::DS;   // single-stranded models report sigma(x + x'), convRBM.py:511-514
   HIP_DYNAMIC_SHARED(float, smem);
   float* Tf = smem;
-  float* acc = Tf + C::TAB;                    // [PC][K], block total of the waves' register sums
+  unsigned long long* acc = reinterpret_cast<unsigned long long*>(Tf + C::TAB);   // [PC][K], block total of the waves' register sums (TAB: a multiple of 4 floats)
   copy_tables<C::TAB>(Tf, a.tables + C::OFF_TF);
   const int s0 = blockIdx.y * PC;
-  if (a.pos)
-    for (int i = threadIdx.x; i < PC * K; i += blockDim.x) acc[i] = 0.f;
+  if (a.pos_fx)
+    for (int i = threadIdx.x; i < PC * K; i += blockDim.x) acc[i] = 0ull;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   float pacc[NI][K];
@@ -1912,21 +1930,21 @@ __device__ void hit_summary_body(const HitArgs& a) {
           if (a.hsum) a.hsum[idx] = t * a.inv_Lh;
         } else {   // probabilities are >= 0: their bit patterns order like unsigned integers
           if (a.hmax) atomicMax(reinterpret_cast<unsigned int*>(a.hmax) + idx, __float_as_uint(m));
-          if (a.hsum) atomicAdd(a.hsum + idx, t * a.inv_Lh);
+          if (a.hsum_fx) atomicAdd(a.hsum_fx + idx, to_fx(t));
         }
       }
     }
   }
-  if (a.pos) {
+  if (a.pos_fx) {
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll
-      for (int q = 0; q < K; ++q) atomicAdd(&acc[(lane + 64 * i) * K + q], pacc[i][q]);
+      for (int q = 0; q < K; ++q) atomicAdd(&acc[(lane + 64 * i) * K + q], to_fx(pacc[i][q]));
     __syncthreads();
     const int npos = min(PC, a.Lh - s0);
     for (int i = threadIdx.x; i < npos * K; i += blockDim.x) {
       const int sl = i / K, q = i - sl * K;
-      atomicAdd(a.pos + (size_t)q * a.Lh + s0 + sl, acc[i]);
+      if (acc[i]) atomicAdd(a.pos_fx + (size_t)q * a.Lh + s0 + sl, acc[i]);
     }
   }
 }
@@ -2452,6 +2470,12 @@ __global__ void __launch_bounds__(256) vgh_dense_kernel(VghArgs a) {
       }
     }
   }
+}
+
+// fixed-point sums over the position chunks of a sequence (hit_summary_body) -> mean over positions
+__global__ void hit_finalize_kernel(const unsigned long long* fx, float* out, size_t count, float scale) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = (float)((double)fx[i] * (double)scale);
 }
 
 // One wave that does nothing for `ticks` of the GPU's wall clock: put in front of a partition's first chain launch

@@ -139,6 +139,8 @@ int crbm_train_epoch_sharded(crbm_handle* h, int32_t batchsize, int32_t total_ro
 int crbm_gibbs_steps(crbm_handle* h, int32_t k);
 int crbm_gibbs_steps_async(crbm_handle* h, int32_t k);
 int crbm_sync(crbm_handle* h);
+/* crbm_sync without the (blocking) read-back of the activity monitor: returns when everything launched has completed. */
+int crbm_wait_idle(crbm_handle* h);
 /* Times `launches` back-to-back launches of k Gibbs steps each with HIP
  * events on the library's stream; returns the total in milliseconds. */
 int crbm_time_gibbs(crbm_handle* h, int32_t k, int32_t launches, float* total_ms);
@@ -257,6 +259,10 @@ int crbm_get_launch_info(const crbm_handle* h, crbm_launch_info* out);
 /* Device-copy bandwidth (float4 copy kernel, HIP events, read + written bytes
  * per second in GB/s) -- the measured ceiling bench.py reports beside the spec. */
 int crbm_copy_bandwidth(crbm_handle* h, int64_t bytes, int32_t reps, float* gb_per_s);
+/* Shader clock (MHz) during the launches of the last crbm_time_gibbs call, sampled by the chain kernel itself (one
+ * block adds its duration in wall-clock ticks and in shader cycles): bench.py prices a step of overlapping launches in
+ * shader cycles with it.  0 when unknown. */
+int crbm_last_shader_clock(crbm_handle* h, float* mhz);
 /* Actual bytes of chain state one Gibbs launch reads+writes in HBM. */
 int64_t crbm_gibbs_state_bytes(const crbm_handle* h);
 

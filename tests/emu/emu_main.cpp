@@ -416,10 +416,19 @@ int emu_hit_summary(int id, const float* tables, const uint32_t* letters, int n,
                      float* pos, int grid, int threads) {
   HitArgs a;
   a.tables = tables; a.letters = letters; a.n = n; a.L = L; a.LW = letter_words(L);
-  a.hmax = hmax; a.hsum = hsum; a.pos = pos; a.inv_Lh = 1.0f;   // the harness divides by Lh itself
-  CFG_DISPATCH(id, (a.Lh = L - C::M + 1,
-                    emu::launch([&] { hit_summary_body<C>(a); }, dim3(grid, (a.Lh + 64 * C::HIT_NI - 1) / (64 * C::HIT_NI)),
-                                dim3(threads), (size_t)C::TAB * 4 + (size_t)64 * C::HIT_NI * C::K * 4)));
+  a.hmax = hmax; a.inv_Lh = 1.0f;   // the harness divides by Lh itself
+  std::vector<unsigned long long> pos_fx, hsum_fx;
+  int chunks = 1, K = 0, Lh = 0;
+  CFG_DISPATCH(id, (a.Lh = Lh = L - C::M + 1, K = C::K, chunks = (a.Lh + 64 * C::HIT_NI - 1) / (64 * C::HIT_NI),
+                    pos_fx.assign((size_t)C::K * a.Lh, 0ull), hsum_fx.assign((size_t)n * C::K, 0ull),
+                    a.pos_fx = pos_fx.data(), a.hsum = chunks == 1 ? hsum : nullptr, a.hsum_fx = chunks > 1 ? hsum_fx.data() : nullptr,
+                    emu::launch([&] { hit_summary_body<C>(a); }, dim3(grid, chunks),
+                                dim3(threads), (size_t)C::TAB * 4 + (size_t)64 * C::HIT_NI * C::K * 8)));
+  // fixed point (HIT_FX units) -> the floats the harness compares
+  for (size_t i = 0; i < pos_fx.size(); ++i) pos[i] = (float)((double)pos_fx[i] / (double)HIT_FX);
+  if (chunks > 1)
+    for (size_t i = 0; i < hsum_fx.size(); ++i) hsum[i] = (float)((double)hsum_fx[i] / (double)HIT_FX);
+  (void)K; (void)Lh;
   return 0;
 }
 

@@ -381,3 +381,35 @@ def test_pooling_probability():
     x = act.reshape(2, 2, 1, 3, 2)
     ref = np.exp(x) / (2 + np.exp(x).sum(axis=4, keepdims=True))
     np.testing.assert_allclose(p, ref.reshape(2, 2, 1, 6))
+
+
+def test_vh_statistics_as_the_reference_writes_them():
+    """_collectVHStatistics literally (convRBM.py:327-337): conv2d(data.dimshuffle(1,0,2,3), P.dimshuffle(1,0,2,3),
+    border_mode="valid", filter_flip=False) -- the N sequences become the CHANNELS of one 4 x L image, the K motifs' 1 x Lh
+    probability rows the filters -- divided by prod(P.dimshuffle(1,0,2,3).shape[1:]) = N * 1 * Lh and shuffled back.
+    Theano's conv2d without filter flip is a per-channel valid cross-correlation summed over channels, which
+    scipy.signal.correlate2d gives independently of the oracle's einsum."""
+    import scipy.signal
+    rng = np.random.default_rng(12)
+    N, K, M, L = 5, 3, 4, 23
+    Lh = L - M + 1
+    o = OracleCRBM(K, M, doublestranded=True, batchsize=N, seed=1)
+    D = synthetic_onehot(N, L, seed=3).astype(np.float64)
+    P = rng.random((N, K, 1, Lh))
+    image = np.transpose(D, (1, 0, 2, 3))            # (1, N, 4, L): batch 1, N channels
+    filters = np.transpose(P, (1, 0, 2, 3))          # (K, N, 1, Lh): K filters of N channels
+    out = np.zeros((1, K, 4, M))
+    for k in range(K):
+        for n in range(N):
+            out[0, k] += scipy.signal.correlate2d(image[0, n], filters[k, n], mode="valid")
+    out /= np.prod(filters.shape[1:])
+    want = np.transpose(out, (1, 0, 2, 3))           # (K,1,4,M)
+    np.testing.assert_allclose(o._collectVHStatistics(P, D), want, rtol=1e-12, atol=1e-14)
+    # and the strand merge of _collectUpdateStatistics (:364-368): (VH + VH'[:, :, ::-1, ::-1]) / 2, (H + H') / 2
+    Pp = rng.random((N, K, 1, Lh))
+    avh, ah, av = o._collectUpdateStatistics(P, Pp, D)
+    vhp = o._collectVHStatistics(Pp, D)
+    np.testing.assert_allclose(avh, (want + vhp[:, :, ::-1, ::-1]) / 2.0, rtol=1e-12)
+    np.testing.assert_allclose(ah, (P.mean(axis=(0, 2, 3)) + Pp.mean(axis=(0, 2, 3)))[None, :] / 2.0, rtol=1e-12)
+    a = D.mean(axis=(0, 1, 3))
+    np.testing.assert_allclose(av, (a + a[::-1])[None, :], rtol=1e-12)

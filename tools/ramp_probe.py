@@ -18,13 +18,16 @@ if __name__ == "__main__":
     model._call("crbm_sync")
     ms = ctypes.c_float()
 
+    mhz = ctypes.c_float()
+
     def window(n):
         model._call("crbm_time_gibbs", k, n, ctypes.byref(ms))
-        return 1e3 * ms.value / n
-    print("10 windows of 20 steps back to back:", " ".join("%.2f" % window(20) for _ in range(10)), flush=True)
-    print("window of 2000:", "%.2f" % window(2000), flush=True)
-    print("5 windows of 20 right behind it:", " ".join("%.2f" % window(20) for _ in range(5)), flush=True)
+        model._call("crbm_last_shader_clock", ctypes.byref(mhz))
+        return "%.2f@%.0fMHz" % (1e3 * ms.value / n, mhz.value)
+    print("10 windows of 20 steps back to back:", " ".join("%s" % window(20) for _ in range(10)), flush=True)
+    print("window of 2000:", "%s" % window(2000), flush=True)
+    print("5 windows of 20 right behind it:", " ".join("%s" % window(20) for _ in range(5)), flush=True)
     for gap in (0.001, 0.01, 0.1):
         time.sleep(gap)
-        print("after %.0f ms idle, windows of 20:" % (1e3 * gap), " ".join("%.2f" % window(20) for _ in range(4)), flush=True)
-    print("windows of 100:", " ".join("%.2f" % window(100) for _ in range(5)), flush=True)
+        print("after %.0f ms idle, windows of 20:" % (1e3 * gap), " ".join("%s" % window(20) for _ in range(4)), flush=True)
+    print("windows of 100:", " ".join("%s" % window(100) for _ in range(5)), flush=True)
