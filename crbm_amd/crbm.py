@@ -89,12 +89,13 @@ class CRBM(object):
         device = extra.pop("device", None)
         if extra:
             raise TypeError("unexpected keyword arguments: %s" % sorted(extra))
-        # limits of the HIP kernels (README "Limits"): refuse at construction, not in the middle of fit().
-        # Beyond them the bound is the LDS (tables + one chain must fit 160 KB): crbm_create reports it.
-        if num_motifs > 256:
-            raise Exception("num_motifs > 256 is not supported by the HIP kernels.")
-        if motif_length > 64:
-            raise Exception("motif_length > 64 is not supported by the HIP kernels (letter windows of two 64-bit words).")
+        # The reference takes any positive num_motifs and motif_length (convRBM.py:72-108); so does the library: models
+        # beyond its specialised kernels (256 motifs, 64 letters, tables + one chain in the LDS) run on generic ones.
+        # What remains is a capacity limit (README "Limits"): refuse at construction, not in the middle of fit().
+        if num_motifs > 65536:
+            raise Exception("num_motifs > 65536 is not supported.")
+        if motif_length > 512:
+            raise Exception("motif_length > 512 is not supported.")
 
         # convRBM.py:111-123
         self.num_motifs = num_motifs

@@ -142,6 +142,7 @@ struct crbm_handle {
   hipStream_t stream2 = nullptr;          // model phase of a training step runs beside the data phase
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_fork = nullptr, ev_join = nullptr;
   bool overlap = false;
+  bool big = false;         // model beyond the LDS-resident kernels: the generic "big" kernels (crbm_kernels.h) serve every entry point
   ModelShape ms;
   ModelShape ms_solo;       // the same model with the letter grouping of plain chain launches (GS; == ms when GS == G)
   int GS = 0;
@@ -258,7 +259,7 @@ int tab_bytes(const crbm_handle* h) { return h->ms.TAB * 4; }
 
 // (re)build the LDS table images after a parameter change
 int ensure_tables(crbm_handle* h) {
-  if (!h->tables_dirty) return CRBM_OK;
+  if (!h->tables_dirty || h->big) return CRBM_OK;
   TablesArgs t;
   t.W = h->dW; t.b = h->db; t.c = h->dc; t.out = h->d_tables;
   const unsigned grid = (unsigned)std::max(1, std::min((h->ms.TABLES_ALL + 255) / 256, h->num_cu * 4));
@@ -275,6 +276,115 @@ int ensure_solo_table(crbm_handle* h) {
   const unsigned grid = (unsigned)std::max(1, std::min((h->ms_solo.TAB + 255) / 256, h->num_cu * 4));
   HIPCHK(jit_launch(h->jk.build_gather_solo, t, grid, 1, 256, 0, h->stream));
   h->tf_solo_version = h->params_version;
+  return CRBM_OK;
+}
+
+// ---- the "big" path (crbm_kernels.h: models beyond the LDS-resident kernels) --------------------------------------
+BigModel big_model(const crbm_handle* h) {
+  BigModel m;
+  m.W = h->dW; m.b = h->db; m.c = h->dc;
+  m.K = h->K; m.M = h->M; m.ds = h->ds; m.NW = h->NW;
+  return m;
+}
+
+// h | v on packed rows: dense outputs (API), a count of sampled ones (evaluateData) or the masks of one strand (chain)
+int big_launch_hgv(crbm_handle* h, const uint32_t* d_letters, int n, int L, int mode, float* act, float* prob, float* sample,
+                   unsigned long long* ones, uint32_t* masks, uint32_t kind, uint32_t step, uint32_t seq_offset, hipStream_t st) {
+  BigHgvArgs a;
+  a.m = big_model(h);
+  a.letters = d_letters;
+  a.n = n; a.L = L; a.Lh = L - h->M + 1; a.LW = letter_words(L);
+  int ks = 32;                                               // motifs per staged slab: a divisor of 32 whose filters fit 96 KB
+  while (ks > 1 && (size_t)ks * h->M * 16 > 96 * 1024) ks >>= 1;
+  a.KS = ks;
+  // rows per tile: enough tiles to cover the chip a few times over (every tile stages the filters once per slab), at most
+  // what the LDS takes of packed letters and ~4096 positions
+  a.TS = std::max(1, std::min(std::min((n + 4 * h->num_cu - 1) / (4 * h->num_cu), (32 * 1024) / (a.LW * 4)), std::max(1, 4096 / a.Lh)));
+  a.mode = mode;
+  a.act = act; a.prob = prob; a.sample = sample; a.ones = ones; a.masks = masks;
+  a.rng = rng_view(h, step, seq_offset);
+  a.kind = kind;
+  const size_t lds = ((size_t)ks * h->M * 4 + 32) * 4 + (size_t)a.TS * a.LW * 4;
+  ARGCHK(lds <= 160 * 1024, "motif_length too large for the h|v kernel");
+  const int ntiles = (n + a.TS - 1) / a.TS;
+  hipLaunchKernelGGL(big_hgv_kernel, dim3(std::max(1, std::min(ntiles, h->num_cu * 8))), dim3(256), lds, st, a);
+  HIPCHK(hipGetLastError());
+  return CRBM_OK;
+}
+
+// `steps` Gibbs steps of the persistent chains: v | h from the masks, then h | v per strand into the masks
+int big_launch_gibbs(crbm_handle* h, int steps, hipStream_t st) {
+  BigVghArgs v;
+  v.m = big_model(h);
+  v.hm = h->d_hm; v.hmp = h->ds ? h->d_hmp : nullptr; v.vout = h->d_vf;
+  v.nchains = h->B; v.Lf = h->Lf; v.Lv = h->Lv; v.LWs = h->gl.LWs;
+  v.JS = std::max(1, std::min(h->M, (64 * 1024) / (32 * 16)));
+  const size_t lds = (size_t)v.JS * 32 * 16 + (size_t)BIG_VR * 256;
+  HIPCHK(hipMemsetAsync(h->d_ones, 0, sizeof(unsigned long long), st));
+  for (int t = 0; t < steps; ++t) {
+    v.rng = rng_view(h, h->gibbs_step + (uint32_t)t, h->chain_offset);
+    hipLaunchKernelGGL(big_vgh_kernel, dim3(std::max(1, std::min(h->B, h->num_cu * 8))), dim3(256), lds, st, v);
+    HIPCHK(hipGetLastError());
+    const bool last = t == steps - 1;      // the last step also counts the units that are on (activity monitor)
+    for (int strand = 0; strand <= h->ds; ++strand) {
+      const int rc = big_launch_hgv(h, h->d_vf, h->B, h->Lv, strand, nullptr, nullptr, nullptr, last ? h->d_ones : nullptr,
+                                    strand ? h->d_hmp : h->d_hm, KIND_CHAIN_H, h->gibbs_step + (uint32_t)t, h->chain_offset, st);
+      if (rc) return rc;
+    }
+  }
+  h->gibbs_step += (uint32_t)steps;
+  h->launches_since_read += 1;
+  return CRBM_OK;
+}
+
+// raw statistic sums of (letters, n, L) into partial rows; the column reduction is handed back like launch_stats does
+int big_launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool data_half, hipStream_t st, ReduceArgs* reduce) {
+  DevBuf<float>& pbuf = data_half ? h->partials : h->partials2;
+  const int K = h->K, M = h->M, KAM = h->KAM;
+  BigStatsArgs a;
+  a.m = big_model(h);
+  a.letters = d_letters;
+  a.n = n; a.L = L; a.Lh = L - M + 1; a.LW = letter_words(L);
+  a.want_sparsity = data_half ? 1 : 0;
+  a.R = std::max(1, std::min(n, std::max(1, (h->num_cu * 8) / K)));
+  a.CH = std::max(64, std::min(4096, a.Lh));
+  a.row = 3 * KAM + 3 * K + 4;
+  a.off_vh0 = 0; a.off_vh1 = KAM; a.off_h0 = 2 * KAM; a.off_h1 = 2 * KAM + K;
+  a.off_sw = 2 * KAM + 2 * K; a.off_sb = 3 * KAM + 2 * K; a.off_v = 3 * KAM + 3 * K;
+  HIPCHK(pbuf.ensure((size_t)a.R * a.row));
+  a.partials = pbuf.p;
+  ARGCHK(4 * M <= BIG_ST * 256, "motif_length too large for the statistics kernel");
+  const size_t lds = (((size_t)4 * M + 3) & ~(size_t)3) * 4 + (size_t)3 * a.CH * 4 + 64 + (size_t)a.CH + M;
+  ARGCHK(lds <= 160 * 1024, "motif_length too large for the statistics kernel");
+  hipLaunchKernelGGL(big_stats_kernel, dim3(K, a.R), dim3(256), lds, st, a);
+  HIPCHK(hipGetLastError());
+  ReduceArgs& r = *reduce;
+  r.partials = pbuf.p;
+  r.nrows = a.R; r.row = a.row;
+  r.K = K; r.KAM = KAM; r.ds = h->ds; r.want_sparsity = a.want_sparsity;
+  if (data_half) {
+    r.sums = h->d_sums + h->sl.data_off;
+    r.skip_begin = a.row; r.skip_len = 0;
+  } else {
+    r.sums = h->d_sums + h->sl.model_off;
+    r.skip_begin = h->sl.model_skip_begin; r.skip_len = h->sl.model_skip_len;
+  }
+  r.n_value = (float)n;
+  return CRBM_OK;
+}
+
+// free energies (hits = 0) or motif-hit summaries (hits = 1) of n packed rows
+int big_launch_eval(crbm_handle* h, const uint32_t* rows, int n, int L, int hits, float* fe, float* fem, float* hmax, float* hmean,
+                    unsigned long long* pos_fx, hipStream_t st) {
+  BigEvalArgs a;
+  a.m = big_model(h);
+  a.letters = rows;
+  a.n = n; a.L = L; a.Lh = L - h->M + 1; a.LW = letter_words(L);
+  a.fe = fe; a.fem = fem; a.hmax = hmax; a.hmean = hmean; a.pos_fx = pos_fx; a.hits = hits;
+  const size_t lds = (((size_t)4 * h->M + 3) & ~(size_t)3) * 4 + 64 + (size_t)L;
+  ARGCHK(lds <= 160 * 1024, "sequence too long for the evaluation kernel of a model of this size");
+  hipLaunchKernelGGL(big_eval_kernel, dim3(std::max(1, std::min(n, h->num_cu * 8))), dim3(256), lds, st, a);
+  HIPCHK(hipGetLastError());
   return CRBM_OK;
 }
 
@@ -328,6 +438,7 @@ int encode_codes_host(crbm_handle* h, const uint8_t* codes, int n, int L, uint32
 
 int launch_hgv(crbm_handle* h, const uint32_t* d_letters, int n, int L, int mode, float* act, float* prob,
                float* sample, unsigned long long* ones, uint32_t kind, uint32_t step, uint32_t seq_offset) {
+  if (h->big) return big_launch_hgv(h, d_letters, n, L, mode, act, prob, sample, ones, nullptr, kind, step, seq_offset, h->stream);
   int rc = ensure_tables(h);
   if (rc) return rc;
   HgvArgs a;
@@ -526,6 +637,7 @@ int launch_gibbs_parts(crbm_handle* h, int steps) {
 
 int launch_gibbs(crbm_handle* h, int steps, hipStream_t s = nullptr, ReduceArgs* model_reduce = nullptr) {
   if (!s) s = h->stream;
+  if (h->big) return big_launch_gibbs(h, steps, s);
   int rc = ensure_tables(h);
   if (rc) return rc;
   if (!model_reduce && h->variant == 1 && h->chain_parts > 1 && s == h->stream) return launch_gibbs_parts(h, steps);
@@ -557,6 +669,13 @@ int launch_gibbs(crbm_handle* h, int steps, hipStream_t s = nullptr, ReduceArgs*
 // chains -- rounds identically and draws identical samples.
 int refresh_activity(crbm_handle* h) {
   if (h->launches_since_read == 0) return CRBM_OK;
+  if (h->big) {          // the last step's h|v launches counted into d_ones
+    unsigned long long on = 0;
+    HIPCHK(hipMemcpy(&on, h->d_ones, sizeof(on), hipMemcpyDeviceToHost));
+    h->launches_since_read = 0;
+    h->activity = (double)on / ((double)h->B * h->Lf * h->K * (1 + h->ds));
+    return CRBM_OK;
+  }
   std::vector<uint32_t> slots((size_t)h->nset_slots);
   HIPCHK(hipMemcpy(slots.data(), h->d_nset, slots.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
   unsigned long long last = 0;
@@ -641,10 +760,14 @@ int launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool d
   StatsMfmaArgs a;
   ReduceArgs r;
   int lds = 0, gx = 0, block = 0;
-  rc = prepare_stats(h, d_letters, n, L, data_half, 0, &a, &lds, &gx, &block, &r);
+  if (h->big) rc = big_launch_stats(h, d_letters, n, L, data_half, s, &r);
+  else {
+    rc = prepare_stats(h, d_letters, n, L, data_half, 0, &a, &lds, &gx, &block, &r);
+    if (rc) return rc;
+    rc = jit_launch(data_half ? h->jk.stats_mfma_data : h->jk.stats_mfma_model, a, (unsigned)gx, 1, (unsigned)block, (unsigned)lds, s) == hipSuccess
+             ? CRBM_OK : fail(h, CRBM_ERR_HIP, "launch of the statistics kernel failed");
+  }
   if (rc) return rc;
-  HIPCHK(jit_launch(data_half ? h->jk.stats_mfma_data : h->jk.stats_mfma_model, a, (unsigned)gx, 1, (unsigned)block,
-                    (unsigned)lds, s));
   if (defer) { *defer = r; return CRBM_OK; }
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((r.row + 31) / 32), dim3(1024), 0, s, r);
   HIPCHK(hipGetLastError());
@@ -675,6 +798,14 @@ void swap_param_sets(crbm_handle* h) {
 int launch_update(crbm_handle* h, int L_data) {
   UpdateTablesArgs a;
   fill_update_args(h, L_data, a);
+  if (h->big) {        // element-wise and in place: no table images to rebuild, no second buffer set
+    UpdateArgs& u = a.u;
+    u.oW = h->dW; u.ob = h->db; u.oc = h->dc; u.ovW = h->dvW; u.ovb = h->dvb; u.ovc = h->dvc;
+    hipLaunchKernelGGL(big_update_kernel, dim3(grid_for((long)h->KAM + h->K + 4, 256, h->num_cu * 4)), dim3(256), 0, h->stream, u);
+    HIPCHK(hipGetLastError());
+    h->params_version += 1;
+    return CRBM_OK;
+  }
   const unsigned grid = (unsigned)std::max(1, std::min((h->ms.TABLES_ALL + 4095) / 4096, 32));
   HIPCHK(jit_launch(h->jk.update_tables, a, grid, 1, UPDATE_THREADS, (unsigned)((h->KAM + h->K + 4) * 4), h->stream));
   swap_param_sets(h);
@@ -908,9 +1039,11 @@ int validate_config(const crbm_config* cfg) {
   crbm_handle* h = nullptr;   // fail() routes to the create-error slot
   if (!cfg) return fail(h, CRBM_ERR_INVALID, "null argument");
   ARGCHK(cfg->num_motifs >= 1, "Number of motifs must be positive.");
-  ARGCHK(cfg->num_motifs <= MAX_MOTIFS, "num_motifs > 256 is not supported by the HIP kernels");
+  // (beyond 256 motifs / 64 letters / what the LDS holds the generic kernels take over: crbm_create)
+  ARGCHK(cfg->num_motifs <= 65536, "num_motifs > 65536 is not supported");
   ARGCHK(cfg->motif_length >= 1, "Motif length must be positive.");
-  ARGCHK(cfg->motif_length <= MAX_MOTIF_LENGTH, "motif_length > 64 is not supported by the HIP kernels (two-word letter windows)");
+  ARGCHK(cfg->motif_length <= 4 * 64 * BIG_ST / 4, "motif_length > 512 is not supported (statistics kernel: 4 * motif_length accumulators per 256-thread block)");
+  ARGCHK((long)cfg->num_motifs * cfg->motif_length <= (1L << 24), "num_motifs * motif_length too large");
   ARGCHK(cfg->input_dims == 4, "the HIP kernels require input_dims == 4 (DNA one-hot)");
   ARGCHK(cfg->pooling >= 1 && cfg->pooling <= 64, "pooling must be between 1 and 64");
   ARGCHK(cfg->fantasy_hidden_len % cfg->pooling == 0, "pooling must divide the hidden length of the fantasy chains");
@@ -1017,6 +1150,22 @@ PartPlan plan_chain_parts(const ModelShape& ms, int Lf, int B, int num_cu) {
   return p;
 }
 
+// Does the model need the generic ("big") kernels?  Beyond 256 motifs or 64 letters the specialised templates do not
+// exist; within them the LDS decides: the chain kernel holds its tables and at least one chain, the statistics kernel a
+// column image per 16 motifs beside the gather table (at most 16 roles of 64 threads).  CRBM_FORCE_BIG=1 puts any
+// (unpooled) model on the generic path -- the tests compare the two paths on the same model with it.
+bool model_needs_big(const ModelShape& ms, int Lf, int B, int num_cu) {
+  if (env_int("CRBM_FORCE_BIG", 0) && ms.POOL == 1) return true;
+  if (ms.K > MAX_MOTIFS || ms.M > MAX_MOTIF_LENGTH) return true;
+  if (choose_gibbs_geometry(ms, Lf, B, num_cu, true).lds <= 0) return true;
+  for (int want_sp = 0; want_sp <= 1; ++want_sp) {
+    const int tabs = ms.TAB * 4;
+    const StatsMfmaLayout st = stats_mfma_layout(ms, want_sp, Lf, 0, tabs, true);
+    if (st.threads > 1024 || std::max(st.region_floats * 4 + tabs, st.combine_bytes) > 160 * 1024) return true;
+  }
+  return false;
+}
+
 // waves per SIMD the sparse Gibbs variant reaches with its geometry; 0 when >= 4 (no hint needed)
 int gibbs_block_bound(int threads) { return threads > 512 ? 1024 : threads > 256 ? 512 : 256; }
 
@@ -1045,6 +1194,8 @@ int crbm_precompile(const crbm_config* cfg) {
   std::string file, err;
   const int Lf_pc = cfg->fantasy_hidden_len > 0 ? cfg->fantasy_hidden_len : 200;
   const int ncu = env_int("CRBM_NUM_CU", 256);
+  if (cfg->num_motifs > MAX_MOTIFS || cfg->motif_length > MAX_MOTIF_LENGTH || model_needs_big(ms, Lf_pc, cfg->batchsize, ncu))
+    return CRBM_OK;     // the generic kernels are compiled ahead of time: nothing to specialise
   const GibbsGeom gs = choose_gibbs_geometry(ms, Lf_pc, cfg->batchsize, ncu, true);
   int tb = gs.threads;
   if (ms.DENSE) tb = std::max(tb, choose_gibbs_geometry(ms, Lf_pc, cfg->batchsize, ncu, false).threads);
@@ -1104,9 +1255,25 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
     if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, hh->device) == hipSuccess && khz > 0) hh->wall_khz = khz;
     (void)hipGetLastError();
   }
+  hh->big = (hh->K > MAX_MOTIFS || hh->M > MAX_MOTIF_LENGTH) ? true : model_needs_big(hh->ms, hh->Lf, hh->B, hh->num_cu);
+  if (hh->big && cfg->pooling > 1) {
+    g_create_error = "pooling > 1 needs a model that fits the LDS-resident kernels (at most 256 motifs of at most 64 letters whose "
+                     "tables and one chain fit 160 KB): this one is served by the generic kernels, which do not pool";
+    return bail(CRBM_ERR_INVALID);
+  }
+  if (hh->big) {
+    // no specialised kernels, no table images: the state layout is the same (K-bit masks, 2-bit letters)
+    hh->gl = GibbsLayout();
+    hh->gl.S = 1; hh->gl.Lv = hh->Lv; hh->gl.LWs = letter_words(hh->Lv);
+    hh->glv[0] = hh->glv[1] = hh->gl;
+    hh->variant = 1; hh->topdown_mode = 2;
+    hh->GS = hh->G; hh->ms_solo = hh->ms;
+    hh->chain_parts = 1; hh->part_chains = hh->B;
+    hh->gridv[0] = hh->gridv[1] = 0;
+  }
   // launch geometry, then the model-specific kernels (hiprtc; cached on disk)
-  hh->has_dense = hh->ms.DENSE != 0;
-  for (int v = hh->has_dense ? 0 : 1; v < 2; ++v) {
+  hh->has_dense = !hh->big && hh->ms.DENSE != 0;
+  for (int v = hh->has_dense ? 0 : 1; v < 2 && !hh->big; ++v) {
     const GibbsGeom geom = choose_gibbs_geometry(hh->ms, hh->Lf, hh->B, hh->num_cu, v == 1);
     if (geom.lds <= 0) {
       g_create_error = "model too large for the LDS-resident Gibbs kernel";
@@ -1117,7 +1284,7 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
     hh->threadsv[v] = geom.threads;
     hh->gridv[v] = geom.grid;
   }
-  {
+  if (!hh->big) {
     // plain chain launches: their own geometry; short launches in partitions on streams of their own (chain_parts);
     // unpartitioned ones of small fused models with their own letter grouping (solo_group)
     const PartPlan plan = plan_chain_parts(hh->ms, hh->Lf, hh->B, hh->num_cu);
@@ -1144,7 +1311,7 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
       }
     }
   }
-  {
+  if (!hh->big) {
     // The set-bit walk is the variant of every model (its cost follows the hidden activity,
     // ~2 % under the reference's sparsity target); CRBM_TOPDOWN=dense pins the table variant
     // of small models for A/B runs.  Never switched at run time: the two round differently.
@@ -1152,7 +1319,7 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
     hh->topdown_mode = (td && !strcmp(td, "dense") && hh->has_dense) ? 1 : 2;
     use_variant(hh, hh->topdown_mode == 1 ? 0 : 1);
   }
-  {
+  if (!hh->big) {
     std::string err;
     const int tb = gibbs_block_bound(std::max(std::max(hh->has_dense ? hh->threadsv[0] : 0, hh->threadsv[1]), hh->solo_threads));
     if (jit_load(hh->K, hh->M, hh->ds, hh->G, hh->GS, hh->ms.POOL, hh->gibbs_wpe, tb, &hh->jk, &err) != 0) {
@@ -1193,7 +1360,7 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
   TRY(hipMalloc((void**)&hh->dW2, kam * 4)); TRY(hipMalloc((void**)&hh->dvW2, kam * 4));
   TRY(hipMalloc((void**)&hh->db2, k * 4));   TRY(hipMalloc((void**)&hh->dvb2, k * 4));
   TRY(hipMalloc((void**)&hh->dc2, 16));      TRY(hipMalloc((void**)&hh->dvc2, 16));
-  TRY(hipMalloc((void**)&hh->d_tables, (size_t)hh->ms.TABLES_ALL * 4));
+  TRY(hipMalloc((void**)&hh->d_tables, hh->big ? 64 : (size_t)hh->ms.TABLES_ALL * 4));
   if (hh->GS != hh->G) TRY(hipMalloc((void**)&hh->d_tf_solo, (size_t)hh->ms_solo.TAB * 4));
   const size_t mwords = (size_t)hh->B * hh->Lf * hh->NW;
   TRY(hipMalloc((void**)&hh->d_hm, mwords * 4)); TRY(hipMemset(hh->d_hm, 0, mwords * 4));
@@ -1213,7 +1380,7 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
   hh->tables_dirty = true;
   {
     const char* sv = getenv("CRBM_STATS");
-    hh->fuse_stats = hh->ms.FUSE_STATS && hh->variant == 1 && !(sv && !strcmp(sv, "split"));
+    hh->fuse_stats = !hh->big && hh->ms.FUSE_STATS && hh->variant == 1 && !(sv && !strcmp(sv, "split"));
     hh->one_launch = !(sv && !strcmp(sv, "two"));
     if (hh->fuse_stats) {   // the fused launch appends the statistics slices to the chain image: it must fit the LDS
       const StatsMfmaLayout st = stats_mfma_layout(hh->ms, 0, hh->Lf, hh->gibbs_threads, 0, false);
@@ -1838,6 +2005,7 @@ int launch_free_energy(crbm_handle* h, const uint32_t* rows, int n, int L, const
   if (rc) return rc;
   HIPCHK(set.oa->ensure((size_t)n));
   HIPCHK(set.ob->ensure((size_t)n * h->K));
+  if (h->big) return big_launch_eval(h, rows, n, L, 0, set.oa->p, set.ob->p, nullptr, nullptr, nullptr, set.st);
   FeArgs a;
   a.tables = h->d_tables;
   a.letters = rows;
@@ -1917,12 +2085,12 @@ int hit_summary_any(crbm_handle* h, const RowSource& src, float* hmax, float* hm
   int rc = check_data_shape(h, src.n, src.L);
   if (rc) return rc;
   const int n = src.n, L = src.L, Lh = L - h->M + 1, K = h->K;
-  const int tabs = tab_bytes(h);
+  const int tabs = h->big ? 0 : tab_bytes(h);
   // a block covers one chunk of 64*HIT_NI positions; its (PC,K) sums share the LDS with the tables
   const int PC = 64 * h->ms.HIT_NI;
-  const int nchunks = (Lh + PC - 1) / PC;
+  const int nchunks = h->big ? 1 : (Lh + PC - 1) / PC;           // (the big path's kernel takes a whole sequence per block)
   const unsigned lds = (unsigned)(tabs + (size_t)PC * K * 8);    // tables + the block's fixed-point position sums
-  ARGCHK(lds <= 160u * 1024u, "model too large for the hit-summary kernel");
+  ARGCHK(h->big || lds <= 160u * 1024u, "model too large for the hit-summary kernel");
   // sums over sequences per (motif, position): 64-bit fixed point (HIT_FX units), so that the order in which blocks,
   // slabs and the two streams add does not show in the result
   unsigned long long* pos_fx = nullptr;
@@ -1966,6 +2134,10 @@ int hit_summary_any(crbm_handle* h, const RowSource& src, float* hmax, float* hm
     a.inv_Lh = 1.0f / (float)Lh;
     a.pos_fx = pos_fx;                          // both streams add (integers: any order)
     const unsigned gx = (unsigned)std::max(1, std::min((cnt + 3) / 4, std::max(1, h->num_cu * 8 / nchunks)));
+    if (h->big) {
+      rc = big_launch_eval(h, rows, cnt, L, 1, nullptr, nullptr, a.hmax, a.hsum, pos_fx, set.st);
+      if (rc) return rc;
+    } else
     HIPCHK(jit_launch(h->jk.hit_summary, a, gx, (unsigned)nchunks, 256, lds, set.st));
     if (a.hsum_fx) {
       hipLaunchKernelGGL(hit_finalize_kernel, dim3(grid_for((long)cnt * K, 256, h->num_cu * 4)), dim3(256), 0, set.st, a.hsum_fx,
@@ -2197,6 +2369,7 @@ int crbm_ipc_attach(crbm_handle* h, const uint8_t* handles, int32_t nranks, int3
   ENTER();
   ARGCHK(handles && nranks >= 1 && nranks <= IPC_MAX_RANKS && rank >= 0 && rank < nranks, "bad argument (at most 8 ranks: one node)");
   ARGCHK(!h->comm, "the handle already has an RCCL communicator");
+  ARGCHK(!h->big, "the mapped-buffer all-reduce serves models of the LDS-resident kernels; this one (generic kernels) takes RCCL");
   int rc = ipc_allocate(h);
   if (rc) return rc;
   for (int r = 0; r < nranks; ++r) {
@@ -2295,6 +2468,12 @@ int crbm_time_allreduce(crbm_handle* h, int32_t launches, float* total_ms) {
 
 int crbm_get_launch_info(const crbm_handle* h, crbm_launch_info* out) {
   if (!h || !out) return CRBM_ERR_INVALID;
+  if (h->big) {          // generic kernels: no specialised geometry to report
+    *out = crbm_launch_info();
+    out->gibbs_sparse = 1; out->chain_parts = 1; out->gibbs_block = 256;
+    out->activity_ppm = h->activity < 0.0 ? -1 : (int32_t)(h->activity * 1e6 + 0.5);
+    return CRBM_OK;
+  }
   // the data-half statistics kernel at the chains' shape (stats_mfma_body)
   const int tabs = h->ms.TAB * 4;
   const StatsMfmaLayout st = stats_mfma_layout(h->ms, 1, h->Lf, 0, tabs);

@@ -2472,6 +2472,449 @@ __global__ void __launch_bounds__(256) vgh_dense_kernel(VghArgs a) {
   }
 }
 
+
+// ===========================================================================
+// The "big" path: models the LDS-resident kernels above do not take -- more than 256 motifs, motifs longer than 64
+// letters, or tables that exceed the LDS (120 x 40 double-stranded, 300 x 10, 8 x 100 ...).  The reference accepts any
+// positive num_motifs and motif_length (convRBM.py:72-108, :127-133); these kernels do too.  Plain kernels with
+// run-time K and M, compiled ahead of time: the filters are staged through LDS a slab of motifs (or one motif) at a
+// time, hidden masks are walked word by word, everything else follows the same formulas, the same bit-packed state
+// (K-bit masks, 2-bit letters) and the same Philox counters as the specialised kernels, so a model may cross the
+// boundary between the two paths without its samples changing beyond p == u ties.  Pooling stays with the
+// specialised kernels (the reference calls it "not relevant for cRBM").
+// ===========================================================================
+struct BigModel {
+  const float* W;   // (K,4,M)
+  const float* b;   // (K)
+  const float* c;   // (4)
+  int32_t K, M, ds, NW;
+};
+
+__device__ __forceinline__ uint32_t letter_at(const uint32_t* row, int p) { return (row[p >> 4] >> (2 * (p & 15))) & 3u; }
+__device__ __forceinline__ float sigmoid_x(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// block-wide sum in a fixed order (waves through DPP, then wave totals through LDS); all threads get the total
+__device__ __forceinline__ float big_block_sum(float v, float* xch) {
+  const float w = wave_sum(v);
+  __syncthreads();                                   // xch may still be read from the previous call
+  if ((threadIdx.x & 63) == 0) xch[threadIdx.x >> 6] = w;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += xch[i];
+  return t;
+}
+__device__ __forceinline__ float big_block_max(float v, float* xch) {
+  const float w = wave_max_nonneg(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) xch[threadIdx.x >> 6] = w;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t = fmaxf(t, xch[i]);
+  return t;
+}
+
+// ---- h | v: _bottomUpActivity / _bottomUpProbability / _bottomUpSample (convRBM.py:238-275), motifHitProbs (:507-514),
+// and the h|v half of a Gibbs step (masks out).  A thread owns one hidden position of a tile of rows and takes the
+// motifs KS (<= 32, a divisor of 32) at a time: the slab's filters sit in LDS as Ws[k][j][letter].
+struct BigHgvArgs {
+  BigModel m;
+  const uint32_t* letters;
+  int32_t n, L, Lh, LW;
+  int32_t TS, KS;
+  int32_t mode;                // 0: forward strand, 1: reverse-complement strand, 2: sigma(x + x')
+  float* act;                  // (n,K,1,Lh) each, may be null
+  float* prob;
+  float* sample;
+  unsigned long long* ones;    // += sampled ones, may be null
+  uint32_t* masks;             // [n][Lh][NW] sampled units of the strand (chain state), may be null
+  RngView rng;
+  uint32_t kind;
+};
+
+__global__ void __launch_bounds__(256) big_hgv_kernel(BigHgvArgs a) {
+  HIP_DYNAMIC_SHARED(float, smem);
+  const int K = a.m.K, M = a.m.M, KS = a.KS;
+  float* Ws = smem;                                            // [KS][M][4]
+  float* bs = Ws + (size_t)KS * M * 4;                         // [32]
+  uint32_t* let = reinterpret_cast<uint32_t*>(bs + 32);        // [TS][LW]
+  const bool want_sample = a.sample || a.ones || a.masks;
+  const uint32_t strand = a.mode == 1 ? 1u : 0u;
+  unsigned long long cnt = 0;
+  const int ntiles = (a.n + a.TS - 1) / a.TS;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int n0 = tile * a.TS, ns = min(a.TS, a.n - n0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < ns * a.LW; i += blockDim.x) let[i] = a.letters[(size_t)n0 * a.LW + i];
+    const int items = ns * a.Lh;
+    for (int k0 = 0; k0 < K; k0 += KS) {
+      const int kc = min(KS, K - k0);
+      __syncthreads();
+      for (int i = threadIdx.x; i < kc * M * 4; i += blockDim.x) {
+        const int k = i / (4 * M), j = (i >> 2) % M, al = i & 3;
+        Ws[i] = a.m.W[((size_t)(k0 + k) * 4 + al) * M + j];
+      }
+      if ((int)threadIdx.x < kc) bs[threadIdx.x] = a.m.b[k0 + threadIdx.x];
+      __syncthreads();
+      for (int it = threadIdx.x; it < items; it += blockDim.x) {
+        const int nl = it / a.Lh, s = it - nl * a.Lh, nn = n0 + nl;
+        const uint32_t* lrow = let + (size_t)nl * a.LW;
+        float x[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) x[k] = 0.f;
+        // x[k] = b[k] + sum_j W[k, l(s+j), j]; rc strand: W[k, 3 - l(s+j), M-1-j] (convRBM.py:241); mode 2: both, each with b
+        for (int pass = 0; pass < (a.mode == 2 ? 2 : 1); ++pass) {
+          const bool rc = a.mode == 1 || pass == 1;
+          for (int j = 0; j < M; ++j) {
+            const uint32_t l = letter_at(lrow, s + j);
+            const float* col = Ws + (size_t)((rc ? M - 1 - j : j) * 4 + (rc ? 3u - l : l));
+#pragma unroll
+            for (int k = 0; k < 32; ++k)
+              if (k < kc) x[k] += col[(size_t)k * M * 4];
+          }
+#pragma unroll
+          for (int k = 0; k < 32; ++k)
+            if (k < kc) x[k] += bs[k];
+        }
+        uint32_t bits = 0u;
+        uint32_t last_g = 0xFFFFFFFFu;
+        Philox4 rcs = {}, rfs = {};
+        const uint32_t gn = a.rng.seq_offset + (uint32_t)nn;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+          if (k < kc) {
+            const int gk = k0 + k;
+            const float p = sigmoid_x(x[k]);
+            const size_t idx = ((size_t)nn * K + gk) * a.Lh + s;
+            if (a.act) a.act[idx] = x[k];
+            if (a.prob) a.prob[idx] = p;
+            if (want_sample) {
+              const uint32_t g = (uint32_t)gk / 10u, i10 = (uint32_t)gk - 10u * g;
+              if (g != last_g) {
+                rcs = philox4x32(gn, (uint32_t)s, rng_word2(a.kind, strand, 0, g), a.rng.step, a.rng.seed_lo, a.rng.seed_hi);
+                rfs = philox4x32(gn, (uint32_t)s, rng_word2(a.kind, strand, 1, g), a.rng.step, a.rng.seed_lo, a.rng.seed_hi);
+                last_g = g;
+              }
+              const float u = (float)(philox_field12_dyn(rcs, (int)i10) * 4096u + philox_field12_dyn(rfs, (int)i10)) * 5.9604644775390625e-8f;
+              const uint32_t hb = p > u ? 1u : 0u;
+              if (a.sample) a.sample[idx] = (float)hb;
+              bits |= hb << (gk & 31);
+              cnt += hb;
+            }
+          }
+        }
+        if (a.masks) {      // the slab lies inside one mask word; the same thread meets this item for every slab
+          uint32_t* wp = a.masks + ((size_t)nn * a.Lh + s) * a.m.NW + (k0 >> 5);
+          *wp = (k0 & 31) ? (*wp | bits) : bits;
+        }
+      }
+    }
+  }
+  if (a.ones && cnt) atomicAdd(a.ones, cnt);
+}
+
+// ---- v | h of the chain from the masks (convRBM.py:277-325): y[a,p] = c[a] + sum_k sum_j W[k,a,j] h[k,p-j] (+ rc strand),
+// softmax over the four letters, one categorical draw per position.  One block per chain; a thread owns up to BIG_VR
+// positions and keeps their activations in registers while the filters pass through LDS 32 motifs x JS columns at a time.
+constexpr int BIG_VR = 8;
+struct BigVghArgs {
+  BigModel m;
+  const uint32_t* hm;       // [nchains][Lf][NW]
+  const uint32_t* hmp;      // reverse-complement strand or null
+  uint32_t* vout;           // [nchains][LWs] packed letters of the sample
+  int32_t nchains, Lf, Lv, LWs;
+  int32_t JS;               // filter columns per staged slab
+  RngView rng;
+};
+
+__global__ void __launch_bounds__(256) big_vgh_kernel(BigVghArgs a) {
+  HIP_DYNAMIC_SHARED(float, smem);
+  const int K = a.m.K, M = a.m.M, NW = a.m.NW, JS = a.JS;
+  float4* Wt = reinterpret_cast<float4*>(smem);                       // [JS][32]: W[k, 0..3, j] of the slab
+  unsigned char* lb = reinterpret_cast<unsigned char*>(Wt + (size_t)JS * 32);   // [BIG_VR * blockDim] letters of a chunk
+  const int CH = BIG_VR * (int)blockDim.x;
+  for (int chain = blockIdx.x; chain < a.nchains; chain += gridDim.x) {
+    const uint32_t gn = a.rng.seq_offset + (uint32_t)chain;
+    for (int c0 = 0; c0 < a.Lv; c0 += CH) {
+      float y[BIG_VR][4];
+#pragma unroll
+      for (int r = 0; r < BIG_VR; ++r) { y[r][0] = a.m.c[0]; y[r][1] = a.m.c[1]; y[r][2] = a.m.c[2]; y[r][3] = a.m.c[3]; }
+      for (int w = 0; w < NW; ++w)
+        for (int j0 = 0; j0 < M; j0 += JS) {
+          const int jc = min(JS, M - j0), kc = min(32, K - 32 * w);
+          __syncthreads();
+          for (int i = threadIdx.x; i < jc * 32; i += blockDim.x) {
+            const int j = i >> 5, k = i & 31;
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < kc) {
+              const float* wk = a.m.W + (size_t)(32 * w + k) * 4 * M + (j0 + j);
+              t = make_float4(wk[0], wk[M], wk[2 * M], wk[3 * M]);
+            }
+            Wt[i] = t;
+          }
+          __syncthreads();
+#pragma unroll
+          for (int r = 0; r < BIG_VR; ++r) {
+            const int p = c0 + (int)threadIdx.x + r * (int)blockDim.x;
+            if (p < a.Lv)
+              for (int strand = 0; strand <= (a.hmp ? 1 : 0); ++strand) {
+                const uint32_t* hrow = (strand ? a.hmp : a.hm) + (size_t)chain * a.Lf * NW + w;
+                // forward strand: column j of the filter meets hidden position p - j; rc strand: rc(W)[k,a,j] = W[k,3-a,M-1-j]
+                for (int j = 0; j < jc; ++j) {
+                  const int jj = j0 + j;                       // column of W that is staged at row j
+                  const int s = strand ? p - (M - 1 - jj) : p - jj;
+                  if (s < 0 || s >= a.Lf) continue;
+                  uint32_t bits = hrow[(size_t)s * NW];
+                  while (bits) {
+                    const int k = __ffs(bits) - 1;
+                    bits &= bits - 1u;
+                    const float4 t = Wt[j * 32 + k];
+                    if (strand) { y[r][0] += t.w; y[r][1] += t.z; y[r][2] += t.y; y[r][3] += t.x; }
+                    else { y[r][0] += t.x; y[r][1] += t.y; y[r][2] += t.z; y[r][3] += t.w; }
+                  }
+                }
+              }
+          }
+        }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < BIG_VR; ++r) {
+        const int pl = (int)threadIdx.x + r * (int)blockDim.x, p = c0 + pl;
+        if (p < a.Lv) {
+          const Philox4 rr = philox4x32(gn, (uint32_t)(p >> 2), rng_word2(KIND_CHAIN_V, 0, 0, 0), a.rng.step, a.rng.seed_lo, a.rng.seed_hi);
+          const float mx = fmaxf(fmaxf(y[r][0], y[r][1]), fmaxf(y[r][2], y[r][3]));
+          const float e0 = __expf(y[r][0] - mx), e1 = __expf(y[r][1] - mx), e2 = __expf(y[r][2] - mx), e3 = __expf(y[r][3] - mx);
+          const float t = u01(philox_pick(rr, p & 3)) * ((e0 + e1) + (e2 + e3));
+          lb[pl] = (unsigned char)((t >= e0) + (t >= e0 + e1) + (t >= (e0 + e1) + e2));
+        }
+      }
+      __syncthreads();
+      // 16 letters per word (CH is a multiple of 16: the chunks start on word boundaries); the row's pad words stay zero
+      const int nw = (min(CH, a.Lv - c0) + 15) / 16;
+      for (int wi = threadIdx.x; wi < nw; wi += blockDim.x) {
+        uint32_t word = 0u;
+        for (int t = 0; t < 16; ++t)
+          if (c0 + 16 * wi + t < a.Lv) word |= (uint32_t)lb[16 * wi + t] << (2 * t);
+        a.vout[(size_t)chain * a.LWs + (c0 >> 4) + wi] = word;
+      }
+    }
+    for (int wi = (a.Lv + 15) / 16 + (int)threadIdx.x; wi < a.LWs; wi += blockDim.x) a.vout[(size_t)chain * a.LWs + wi] = 0u;
+  }
+}
+
+// ---- gradient statistics (convRBM.py:327-371) and the sparsity sums (:440-451), raw sums into partial rows of the layout
+// the column reduction expects.  Block (k, r): motif k, rows r, r + R, ...; the motif's filter, a chunk of letters and
+// the probabilities of the chunk's positions sit in LDS; thread t accumulates VH[k, a, j] for (a, j) = t / M, t % M.
+constexpr int BIG_ST = 8;                                   // (a, j) slots per thread: 4 M <= BIG_ST * blockDim
+struct BigStatsArgs {
+  BigModel m;
+  const uint32_t* letters;
+  int32_t n, L, Lh, LW;
+  int32_t want_sparsity, R, CH;
+  float* partials;                                          // [R][row]
+  int32_t row, off_vh0, off_vh1, off_h0, off_h1, off_sw, off_sb, off_v;
+};
+
+__global__ void __launch_bounds__(256) big_stats_kernel(BigStatsArgs a) {
+  HIP_DYNAMIC_SHARED(float, smem);
+  const int M = a.m.M, k = blockIdx.x, r = blockIdx.y, AM = 4 * M, CH = a.CH;
+  float* Wk = smem;                                         // [4][M]
+  float* P = Wk + ((AM + 3) & ~3);                          // [CH] each
+  float* Pp = P + CH;
+  float* Q = Pp + CH;
+  float* xch = Q + CH;                                      // [16]
+  unsigned char* lb = reinterpret_cast<unsigned char*>(xch + 16);   // [CH + M]
+  for (int i = threadIdx.x; i < AM; i += blockDim.x) Wk[i] = a.m.W[(size_t)k * AM + i];
+  const float bk = a.m.b[k];
+  float vh[BIG_ST], vhp[BIG_ST], sw[BIG_ST];
+#pragma unroll
+  for (int t = 0; t < BIG_ST; ++t) vh[t] = vhp[t] = sw[t] = 0.f;
+  float hsum = 0.f, hpsum = 0.f, qsum = 0.f, cnt[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int nn = r; nn < a.n; nn += a.R) {
+    const uint32_t* lrow = a.letters + (size_t)nn * a.LW;
+    for (int c0 = 0; c0 < a.Lh; c0 += CH) {
+      const int cl = min(CH, a.Lh - c0), nl = cl + M - 1;     // positions of the chunk, letters they see
+      __syncthreads();
+      for (int i = threadIdx.x; i < nl; i += blockDim.x) {
+        const uint32_t l = letter_at(lrow, c0 + i);
+        lb[i] = (unsigned char)l;
+        // every visible position once: the chunk's own positions, the last chunk also the M - 1 behind them
+        if (k == 0 && (i < cl || c0 + cl == a.Lh)) { cnt[0] += l == 0u; cnt[1] += l == 1u; cnt[2] += l == 2u; cnt[3] += l == 3u; }
+      }
+      __syncthreads();
+      for (int s = threadIdx.x; s < cl; s += blockDim.x) {
+        float x = bk, xr = bk;
+        for (int j = 0; j < M; ++j) {
+          const int l = lb[s + j];
+          x += Wk[l * M + j];
+          if (a.m.ds) xr += Wk[(3 - l) * M + (M - 1 - j)];
+        }
+        const float p = sigmoid_x(x), pp = a.m.ds ? sigmoid_x(xr) : 0.f, q = a.want_sparsity ? p * (1.0f - p) : 0.f;
+        P[s] = p; Pp[s] = pp; Q[s] = q;
+        hsum += p; hpsum += pp; qsum += q;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < BIG_ST; ++t) {
+        const int e = (int)threadIdx.x + t * (int)blockDim.x;
+        if (e < AM) {
+          const int al = e / M, j = e - al * M;
+          float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+          for (int s = 0; s < cl; ++s)
+            if (lb[s + j] == al) { s0 += P[s]; s1 += Pp[s]; s2 += Q[s]; }
+          vh[t] += s0; vhp[t] += s1; sw[t] += s2;
+        }
+      }
+    }
+  }
+  float* out = a.partials + (size_t)r * a.row;
+#pragma unroll
+  for (int t = 0; t < BIG_ST; ++t) {
+    const int e = (int)threadIdx.x + t * (int)blockDim.x;
+    if (e < AM) {
+      out[a.off_vh0 + (size_t)k * AM + e] = vh[t];
+      if (a.m.ds) out[a.off_vh1 + (size_t)k * AM + e] = vhp[t];
+      if (a.want_sparsity) out[a.off_sw + (size_t)k * AM + e] = sw[t];
+    }
+  }
+  const float H = big_block_sum(hsum, xch), Hp = big_block_sum(hpsum, xch), Sb = big_block_sum(qsum, xch);
+  if (threadIdx.x == 0) {
+    out[a.off_h0 + k] = H;
+    if (a.m.ds) out[a.off_h1 + k] = Hp;
+    if (a.want_sparsity) out[a.off_sb + k] = Sb;
+  }
+  if (k == 0) {
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      const float t = big_block_sum(cnt[l], xch);
+      if (threadIdx.x == 0) out[a.off_v + l] = t;
+    }
+  }
+}
+
+// ---- the update (convRBM.py:358-371, :415-436, :440-451), element-wise and in place, any number of blocks
+__global__ void __launch_bounds__(256) big_update_kernel(UpdateArgs a) {
+  const int K = a.K, M = a.M, KAM = K * 4 * M;
+  const float* S = a.sums;
+  const float n_d = S[a.n_d], n_m = S[a.n_m];
+  const float cnt_d = n_d * (float)(a.L_data - M + 1), cnt_m = n_m * (float)a.Lf;
+  const int d_vh = a.data_off, d_vhp = d_vh + KAM, d_h = d_vh + 2 * KAM, d_hp = d_h + K;
+  const int d_sw = d_vh + 2 * KAM + 2 * K, d_sb = d_sw + KAM, d_v = d_sb + K;
+  const int m_vh = a.model_off, m_vhp = m_vh + KAM, m_h = m_vh + 2 * KAM, m_hp = m_h + K, m_v = m_hp + K;
+  const float q = a.rho;
+  const int total = KAM + K + 4;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    if (i < KAM) {
+      const int k = i / (4 * M), al = (i / M) & 3, j = i % M;
+      const int ri = (k * 4 + (3 - al)) * M + (M - 1 - j);
+      float gd = S[d_vh + i] / cnt_d, gm = S[m_vh + i] / cnt_m;
+      if (a.ds) {
+        gd = 0.5f * (gd + S[d_vhp + ri] / cnt_d);
+        gm = 0.5f * (gm + S[m_vhp + ri] / cnt_m);
+      }
+      const float p = S[d_h + k] / cnt_d;
+      const float g = (q / p - (1.f - q) / (1.f - p)) / (float)K;
+      const float reg = -g * S[d_sw + i] / cnt_d;
+      const float v = a.momentum * a.vW[i] + a.lr * (gd - gm - a.lambda_rate * reg);
+      a.ovW[i] = v;
+      a.oW[i] = a.W[i] + v;
+    } else if (i < KAM + K) {
+      const int k = i - KAM;
+      const float dh = S[d_h + k];
+      float gd = dh / cnt_d, gm = S[m_h + k] / cnt_m;
+      if (a.ds) {
+        gd = 0.5f * (gd + S[d_hp + k] / cnt_d);
+        gm = 0.5f * (gm + S[m_hp + k] / cnt_m);
+      }
+      const float p = dh / cnt_d;
+      const float g = (q / p - (1.f - q) / (1.f - p)) / (float)K;
+      const float reg = -g * S[d_sb + k] / cnt_d;
+      const float v = a.momentum * a.vb[k] + a.lr * (gd - gm - a.lambda_rate * reg);
+      a.ovb[k] = v;
+      a.ob[k] = a.b[k] + v;
+    } else {
+      const int al = i - KAM - K;
+      const float nd = n_d * (float)a.L_data, nm = n_m * (float)(a.Lf + M - 1);
+      const float gd = S[d_v + al] / nd + S[d_v + 3 - al] / nd;     // a += a[::-1]  (:345)
+      const float gm = S[m_v + al] / nm + S[m_v + 3 - al] / nm;
+      const float v = a.momentum * a.vc[al] + a.lr * (gd - gm);
+      a.ovc[al] = v;
+      a.oc[al] = a.c[al] + v;
+    }
+  }
+}
+
+// ---- free energy (convRBM.py:657-697) and the motif-hit summaries (utils.py:113-116, :154, :242-244, :305): one block per
+// sequence, the motifs one after the other (filter in LDS), threads over the hidden positions.
+struct BigEvalArgs {
+  BigModel m;
+  const uint32_t* letters;
+  int32_t n, L, Lh, LW;
+  float* fe;                       // (n)   free-energy mode, may be null
+  float* fem;                      // (n,K) free-energy mode, may be null
+  float* hmax;                     // (n,K) hit mode: max over positions
+  float* hmean;                    // (n,K) hit mode: mean over positions
+  unsigned long long* pos_fx;      // (K,Lh) hit mode: fixed-point sums over sequences (HIT_FX units), may be null
+  int32_t hits;                    // 0: free energy, 1: hit summaries
+};
+
+__global__ void __launch_bounds__(256) big_eval_kernel(BigEvalArgs a) {
+  HIP_DYNAMIC_SHARED(float, smem);
+  const int K = a.m.K, M = a.m.M, AM = 4 * M;
+  float* Wk = smem;                                                  // [4][M]
+  float* xch = Wk + ((AM + 3) & ~3);                                 // [16]
+  unsigned char* lb = reinterpret_cast<unsigned char*>(xch + 16);    // [L]
+  for (int nn = blockIdx.x; nn < a.n; nn += gridDim.x) {
+    const uint32_t* lrow = a.letters + (size_t)nn * a.LW;
+    __syncthreads();
+    float csl = 0.f;
+    for (int p = threadIdx.x; p < a.L; p += blockDim.x) {
+      const uint32_t l = letter_at(lrow, p);
+      lb[p] = (unsigned char)l;
+      csl += a.m.c[l];
+    }
+    const float cs = big_block_sum(csl, xch);
+    float tot = 0.f;
+    for (int k = 0; k < K; ++k) {
+      __syncthreads();
+      for (int i = threadIdx.x; i < AM; i += blockDim.x) Wk[i] = a.m.W[(size_t)k * AM + i];
+      __syncthreads();
+      const float bk = a.m.b[k];
+      float part = 0.f, mx = 0.f;
+      for (int s = threadIdx.x; s < a.Lh; s += blockDim.x) {
+        float x = bk, xr = bk;
+        for (int j = 0; j < M; ++j) {
+          const int l = lb[s + j];
+          x += Wk[l * M + j];
+          xr += Wk[(3 - l) * M + (M - 1 - j)];
+        }
+        if (a.hits) {
+          // convRBM.py:507-514: doublestranded -> sigma(x); single-stranded -> sigma(x + x')
+          const float p = sigmoid_x(a.m.ds ? x : x + xr);
+          part += p;
+          mx = fmaxf(mx, p);
+          if (a.pos_fx) atomicAdd(a.pos_fx + (size_t)k * a.Lh + s, to_fx(p));
+        } else {
+          // softplus(x) = max(x, 0) + log1p(exp(-|x|))
+          part += fmaxf(x, 0.f) + log1pf(__expf(-fabsf(x)));
+          if (a.m.ds) part += fmaxf(xr, 0.f) + log1pf(__expf(-fabsf(xr)));
+        }
+      }
+      const float v = big_block_sum(part, xch);
+      if (a.hits) {
+        const float m = big_block_max(mx, xch);
+        if (threadIdx.x == 0) {
+          if (a.hmax) a.hmax[(size_t)nn * K + k] = m;
+          if (a.hmean) a.hmean[(size_t)nn * K + k] = v / (float)a.Lh;
+        }
+      } else {
+        tot += v;
+        if (threadIdx.x == 0 && a.fem) a.fem[(size_t)nn * K + k] = -v - cs;
+      }
+    }
+    if (!a.hits && threadIdx.x == 0 && a.fe) a.fe[nn] = (-tot - cs) / (float)a.L;
+  }
+}
+
 // fixed-point sums over the position chunks of a sequence (hit_summary_body) -> mean over positions
 __global__ void hit_finalize_kernel(const unsigned long long* fx, float* out, size_t count, float scale) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)

@@ -432,6 +432,87 @@ int emu_hit_summary(int id, const float* tables, const uint32_t* letters, int n,
   return 0;
 }
 
+
+// ---- the generic ("big") kernels: run-time K and M -------------------------------------------------------------------
+static BigModel big_model_of(const float* W, const float* b, const float* c, int K, int M, int ds) {
+  BigModel m;
+  m.W = W; m.b = b; m.c = c; m.K = K; m.M = M; m.ds = ds; m.NW = (K + 31) / 32;
+  return m;
+}
+
+int emu_big_hgv(const float* W, const float* b, const float* c, int K, int M, int ds, const uint32_t* letters, int n, int L,
+                int mode, float* act, float* prob, float* sample, unsigned long long* ones, uint32_t* masks, uint64_t seed,
+                uint32_t step, uint32_t off, uint32_t kind, int TS, int KS, int grid, int threads) {
+  BigHgvArgs a;
+  a.m = big_model_of(W, b, c, K, M, ds);
+  a.letters = letters; a.n = n; a.L = L; a.Lh = L - M + 1; a.LW = letter_words(L);
+  a.TS = TS; a.KS = KS; a.mode = mode;
+  a.act = act; a.prob = prob; a.sample = sample; a.ones = ones; a.masks = masks;
+  a.rng = make_rng(seed, step, off); a.kind = kind;
+  emu::launch([&] { big_hgv_kernel(a); }, dim3(grid), dim3(threads), ((size_t)KS * M * 4 + 32) * 4 + (size_t)TS * a.LW * 4);
+  return 0;
+}
+
+// one Gibbs step: v | h from the masks, then h | v per strand into the masks; returns the letter words per row of vout
+int emu_big_gibbs_step(const float* W, const float* b, const float* c, int K, int M, int ds, uint32_t* hm, uint32_t* hmp,
+                       uint32_t* vout, int nchains, int Lf, uint64_t seed, uint32_t step, uint32_t off, int JS, int KS,
+                       int grid, int threads) {
+  const int Lv = Lf + M - 1, LWs = letter_words(Lv);
+  if (!vout) return LWs;
+  BigVghArgs v;
+  v.m = big_model_of(W, b, c, K, M, ds);
+  v.hm = hm; v.hmp = ds ? hmp : nullptr; v.vout = vout;
+  v.nchains = nchains; v.Lf = Lf; v.Lv = Lv; v.LWs = LWs; v.JS = JS;
+  v.rng = make_rng(seed, step, off);
+  emu::launch([&] { big_vgh_kernel(v); }, dim3(grid), dim3(threads), (size_t)JS * 32 * 16 + (size_t)BIG_VR * threads);
+  for (int strand = 0; strand <= ds; ++strand)
+    emu_big_hgv(W, b, c, K, M, ds, vout, nchains, Lv, strand, nullptr, nullptr, nullptr, nullptr, strand ? hmp : hm, seed, step, off,
+                KIND_CHAIN_H, 2, KS, grid, threads);
+  return LWs;
+}
+
+// raw sums of one half: partial rows through big_stats_kernel, then the host column reduce of the harness
+int emu_big_stats(const float* W, const float* b, const float* c, int K, int M, int ds, const uint32_t* letters, int n, int L,
+                  int LW, int want_sparsity, int R, int CH, int threads, float* sums, int skip_begin, int skip_len) {
+  const int KAM = K * 4 * M, row = 3 * KAM + 3 * K + 4;
+  std::vector<float> partials((size_t)R * row, -777.0f);      // what a launch does not write must not be read
+  BigStatsArgs a;
+  a.m = big_model_of(W, b, c, K, M, ds);
+  a.letters = letters; a.n = n; a.L = L; a.Lh = L - M + 1; a.LW = LW;
+  a.want_sparsity = want_sparsity; a.R = R; a.CH = CH;
+  a.partials = partials.data();
+  a.row = row; a.off_vh0 = 0; a.off_vh1 = KAM; a.off_h0 = 2 * KAM; a.off_h1 = 2 * KAM + K;
+  a.off_sw = 2 * KAM + 2 * K; a.off_sb = 3 * KAM + 2 * K; a.off_v = 3 * KAM + 3 * K;
+  if (4 * M > BIG_ST * threads) return -2;
+  emu::launch([&] { big_stats_kernel(a); }, dim3(K, R), dim3(threads),
+              (((size_t)4 * M + 3) & ~(size_t)3) * 4 + (size_t)3 * CH * 4 + 64 + (size_t)CH + M);
+  host_reduce(partials.data(), R, row, K, KAM, ds, want_sparsity, skip_begin, skip_len, (float)n, sums);
+  return row;
+}
+
+int emu_big_update(const float* sums, float* W, float* b, float* c, float* vW, float* vb, float* vc, int K, int M, int ds,
+                   int L_data, int Lf, float lr, float momentum, float rho, float lambda_rate, int grid, int threads) {
+  const SumsLayout sl = sums_layout(K, M);
+  UpdateArgs u{sums, W, b, c, vW, vb, vc, W, b, c, vW, vb, vc, K, M, ds, L_data, Lf,
+               sl.data_off, sl.n_d, sl.model_off, sl.n_m, lr, momentum, rho, lambda_rate};
+  emu::launch([&] { big_update_kernel(u); }, dim3(grid), dim3(threads), 0);
+  return 0;
+}
+
+int emu_big_eval(const float* W, const float* b, const float* c, int K, int M, int ds, const uint32_t* letters, int n, int L,
+                 int hits, float* fe, float* fem, float* hmax, float* hmean, float* pos, int grid, int threads) {
+  BigEvalArgs a;
+  a.m = big_model_of(W, b, c, K, M, ds);
+  a.letters = letters; a.n = n; a.L = L; a.Lh = L - M + 1; a.LW = letter_words(L);
+  a.fe = fe; a.fem = fem; a.hmax = hmax; a.hmean = hmean; a.hits = hits;
+  std::vector<unsigned long long> pos_fx((size_t)K * a.Lh, 0ull);
+  a.pos_fx = (hits && pos) ? pos_fx.data() : nullptr;
+  emu::launch([&] { big_eval_kernel(a); }, dim3(grid), dim3(threads), (((size_t)4 * M + 3) & ~(size_t)3) * 4 + 64 + (size_t)L);
+  if (hits && pos)
+    for (size_t i = 0; i < pos_fx.size(); ++i) pos[i] = (float)((double)pos_fx[i] / (double)HIT_FX);
+  return 0;
+}
+
 int emu_sums_layout(int K, int M, int* out) {
   const SumsLayout s = sums_layout(K, M);
   out[0] = s.data_off; out[1] = s.n_d; out[2] = s.model_off; out[3] = s.n_m; out[4] = s.count;

@@ -747,6 +747,135 @@ def test_hit_summary():
         print("hit summary ok", (K, M, ds))
 
 
+
+def test_big():
+    """The generic kernels of models beyond the LDS-resident ones (run-time K and M): dense h|v outputs on both
+    strands and their sum, a Gibbs step from the masks (tie-aware), the raw sums of both halves, the update, free
+    energy and hit summaries -- each against the oracle, under the sanitizers.  Shapes: a 70-letter motif (more than two
+    letter-window words), 37 motifs on two strands (a slab that is not a whole mask word: KS = 8), one motif."""
+    for (K, M, ds, KS, JS) in ((37, 70, True, 8, 16), (3, 5, False, 32, 5), (1, 1, True, 32, 1)):
+        o = make_oracle(K, M, ds, seed=K + M, batch=3, Lf=22, cd_k=2, wscale=0.8 if M > 20 else 1.0, rho=0.05)
+        W, b, c = model_arrays(o)
+        n, L = 4, M + 25
+        d = synthetic_onehot(n, L, seed=K)
+        letters, _ = encode(d)
+        LW = lib.emu_letter_words(L)
+        Lh = L - M + 1
+        NW = (K + 31) // 32
+        for mode in (0, 1, 2):
+            act = np.zeros((n, K, 1, Lh), dtype=np.float32)
+            prob = np.zeros_like(act)
+            smp = np.zeros_like(act)
+            ones = ctypes.c_ulonglong(0)
+            assert lib.emu_big_hgv(fp(W), fp(b), fp(c), K, M, int(ds), up(letters), n, L, mode, fp(act), fp(prob), fp(smp),
+                                   ctypes.byref(ones), None, ctypes.c_uint64(o.seed), 4, 6, KIND_API_H, 2, KS, 2, 64) == 0
+            if mode == 2:
+                ref = o._bottomUpActivity(d) + o._bottomUpActivity(d, True)
+            else:
+                ref = o._bottomUpActivity(d, mode == 1)
+            np.testing.assert_allclose(act, ref, rtol=1e-5, atol=2e-5)
+            pref = 1.0 / (1.0 + np.exp(-ref))
+            np.testing.assert_allclose(prob, pref, rtol=2e-5, atol=1e-7)
+            u = hidden_uniforms(o.seed, 4, np.arange(n) + 6, K, Lh, 1 if mode == 1 else 0, KIND_API_H)
+            check_samples("big hgv", smp, pref, u)
+            assert ones.value == int(smp.sum())
+        # one Gibbs step at a time from the oracle's state (tie-aware)
+        rng = np.random.default_rng(9)
+        o.fantasy_h = rng.binomial(1, 0.1, size=o.fantasy_h.shape).astype(np.float64)
+        if ds:
+            o.fantasy_h_prime = rng.binomial(1, 0.1, size=o.fantasy_h.shape).astype(np.float64)
+        o.seq_offset = 5
+        B, Lf = o.fantasy_h.shape[0], o.fantasy_h.shape[3]
+        Lv = Lf + M - 1
+        idx = np.arange(B) + o.seq_offset
+        for _ in range(2):
+            t = o.gibbs_step
+            hm, _f = pack_hidden(f32(o.fantasy_h), NW)
+            hmp = pack_hidden(f32(o.fantasy_h_prime), NW)[0] if ds else np.zeros_like(hm)
+            lws = lib.emu_big_gibbs_step(fp(W), fp(b), fp(c), K, M, int(ds), up(hm), up(hmp), None, B, Lf, ctypes.c_uint64(o.seed), t,
+                                         o.seq_offset, JS, KS, 2, 64)
+            vout = np.zeros((B, lws), dtype=np.uint32)
+            assert lib.emu_big_gibbs_step(fp(W), fp(b), fp(c), K, M, int(ds), up(hm), up(hmp), up(vout), B, Lf, ctypes.c_uint64(o.seed), t,
+                                          o.seq_offset, JS, KS, 2, 64) == lws
+            gv = np.zeros((B, 1, 4, Lv), dtype=np.float32)
+            lib.emu_decode(up(vout), fp(gv), B, Lv, lws, 2)
+            uv = visible_uniforms(o.seed, t, idx, Lv, KIND_CHAIN_V)
+            Pv, v = o._computeVgivenH(o.fantasy_h, o.fantasy_h_prime if ds else None, uv)
+            np.testing.assert_array_equal(gv.sum(axis=2), 1.0)
+            badv = (gv != v).any(axis=2)[:, 0]
+            if badv.any():
+                gap = np.min(np.abs(np.cumsum(Pv[:, 0], axis=1)[:, :3] - uv[:, None, :]), axis=1)
+                assert np.all(gap[badv] < TIE), "big v|h: sample differs away from a tie"
+            clean = ~badv.any(axis=1)
+            uh = hidden_uniforms(o.seed, t, idx, K, Lf, 0, KIND_CHAIN_H)
+            P, h = o._computeHgivenV(v, False, uh)
+            pairs = [(unpack_hidden(hm, K), h, P, uh)]
+            if ds:
+                uhp = hidden_uniforms(o.seed, t, idx, K, Lf, 1, KIND_CHAIN_H)
+                Pp, hp = o._computeHgivenV(v, True, uhp)
+                pairs.append((unpack_hidden(hmp, K), hp, Pp, uhp))
+            for got, want, prob, u in pairs:
+                bad = (got != want) & clean[:, None, None, None]
+                assert np.all(np.abs(prob - u)[bad] < TIE), "big h|v: sample differs away from a tie"
+            o.fantasy_h, o.fantasy_h_prime = h, (hp if ds else o.fantasy_h_prime)
+            o.last_v_model = v
+            o.gibbs_step += 1
+        assert o.fantasy_h.sum() > 0
+        # raw sums of both halves against the oracle's, the update against its finalisation
+        lay = (ctypes.c_int * 7)()
+        lib.emu_sums_layout(K, M, lay)
+        data_off, n_d, model_off, n_m, count, skip_b, skip_l = list(lay)
+        KAM = K * 4 * M
+        row = 3 * KAM + 3 * K + 4
+        sums = np.zeros(count, dtype=np.float32)
+        half = np.zeros(row + 1, dtype=np.float32)
+        assert lib.emu_big_stats(fp(W), fp(b), fp(c), K, M, int(ds), up(letters), n, L, LW, 1, 2, 16, 64, fp(half), -1, 0) == row
+        sums[data_off:data_off + row] = half[:row]
+        sums[n_d] = n
+        P_m, P_mp, v_m = o.gibbs_steps(1)
+        vl, _ = encode(v_m)
+        vlw = lib.emu_letter_words(Lv)
+        assert lib.emu_big_stats(fp(W), fp(b), fp(c), K, M, int(ds), up(vl), B, Lv, vlw, 0, 3, 8, 64, fp(half), skip_b, skip_l) == row
+        sums[model_off:model_off + row - skip_l] = half[:row - skip_l]
+        sums[n_m] = B
+        ref = o.local_sums(d, P_m, P_mp, v_m)
+        got = {"vh_d": sums[data_off:data_off + KAM], "h_d": sums[data_off + 2 * KAM:data_off + 2 * KAM + K],
+               "sw": sums[data_off + 2 * KAM + 2 * K:data_off + 3 * KAM + 2 * K], "sb": sums[data_off + 3 * KAM + 2 * K:data_off + 3 * KAM + 3 * K],
+               "v_d": sums[data_off + 3 * KAM + 3 * K:data_off + 3 * KAM + 3 * K + 4],
+               "vh_m": sums[model_off:model_off + KAM], "h_m": sums[model_off + 2 * KAM:model_off + 2 * KAM + K],
+               "v_m": sums[model_off + 2 * KAM + 2 * K:model_off + 2 * KAM + 2 * K + 4]}
+        if ds:
+            got.update({"vh_dp": sums[data_off + KAM:data_off + 2 * KAM], "h_dp": sums[data_off + 2 * KAM + K:data_off + 2 * KAM + 2 * K],
+                        "vh_mp": sums[model_off + KAM:model_off + 2 * KAM], "h_mp": sums[model_off + 2 * KAM + K:model_off + 2 * KAM + 2 * K]})
+        for key, val in got.items():
+            np.testing.assert_allclose(val, np.ravel(ref[key]), rtol=2e-5, atol=2e-5, err_msg=key)
+        Wn, bn, cn = W.copy(), b.copy(), c.copy()
+        vW, vb, vc = (f32(x).copy() for x in (o.vW, o.vb, o.vc))
+        lib.emu_big_update(fp(sums), fp(Wn), fp(bn), fp(cn), fp(vW), fp(vb), fp(vc), K, M, int(ds), L, Lf,
+                           ctypes.c_float(o.learning_rate), ctypes.c_float(o.momentum), ctypes.c_float(o.rho),
+                           ctypes.c_float(o.lambda_rate), 2, 64)
+        o.finalize_from_sums(ref, L, Lf)
+        np.testing.assert_allclose(Wn.reshape(o.W.shape), o.W, rtol=1e-4, atol=2e-6)
+        np.testing.assert_allclose(bn.reshape(o.b.shape), o.b, rtol=1e-4, atol=2e-6)
+        np.testing.assert_allclose(cn.reshape(o.c.shape), o.c, rtol=1e-4, atol=2e-6)
+        # free energy and hit summaries (the model is the updated oracle now; use fresh arrays)
+        W2, b2, c2 = model_arrays(o)
+        fe = np.zeros(n, dtype=np.float32)
+        fem = np.zeros((n, K), dtype=np.float32)
+        lib.emu_big_eval(fp(W2), fp(b2), fp(c2), K, M, int(ds), up(letters), n, L, 0, fp(fe), fp(fem), None, None, None, 2, 64)
+        np.testing.assert_allclose(fe, o.freeEnergy(d), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(fem, o.freeEnergy(d, True), rtol=1e-4, atol=1e-5)
+        hmax = np.zeros((n, K), dtype=np.float32)
+        hmean = np.zeros((n, K), dtype=np.float32)
+        pos = np.zeros((K, Lh), dtype=np.float32)
+        lib.emu_big_eval(fp(W2), fp(b2), fp(c2), K, M, int(ds), up(letters), n, L, 1, None, None, fp(hmax), fp(hmean), fp(pos), 2, 64)
+        Ph = o.motifHitProbs(d)
+        np.testing.assert_allclose(hmax, Ph.max(axis=(2, 3)), rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(hmean, Ph.mean(axis=(2, 3)), rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(pos / n, Ph.mean(axis=(0, 2)), rtol=1e-5, atol=1e-7)
+        print("big kernels ok", (K, M, ds))
+
+
 def test_large_models():
     """Models beyond 64 motifs (masks of more than two words) and beyond 32-letter motifs (two-word letter
     windows, 128-bit statistics windows): every kernel of a training step, the free energy and the chain."""
@@ -759,7 +888,7 @@ def test_large_models():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["encode_pack", "hgv", "vgh", "gibbs", "stats_mfma", "train_step", "two_ranks", "pooling",
-                             "free_energy", "hit_summary"]
+                             "free_energy", "hit_summary", "big"]
     for w in which:
         globals()["test_" + w]()
     print("EMU ALL OK")

@@ -34,7 +34,7 @@ def emu_env():
 
 
 @pytest.mark.parametrize("which", ["encode_pack", "hgv", "vgh", "gibbs", "stats_mfma", "train_step", "two_ranks", "pooling",
-                                   "free_energy", "hit_summary", "large_models"])
+                                   "free_energy", "hit_summary", "large_models", "big"])
 def test_kernels_on_cpu_threads_with_sanitizers(emu_env, which):
     r = subprocess.run([sys.executable, os.path.join(EMU, "run_emu.py"), which], env=emu_env,
                        capture_output=True, text=True, timeout=1500)

@@ -6,6 +6,8 @@ identical given the shared Philox stream, except at |p - u| < 1e-6 ties.
 """
 import os
 
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -825,11 +827,19 @@ def test_inference_streams_in_slabs(monkeypatch):
                                         # beyond 64 motifs (masks of 3..8 words) and beyond 32-letter motifs (two-word
                                         # letter windows): the reference takes any positive K, M (convRBM.py:72-108)
                                         (100, 15, False, 120, 4), (20, 40, True, 150, 4), (70, 33, True, 90, 3),
-                                        (130, 7, True, 60, 3), (192, 4, False, 40, 2), (256, 4, False, 40, 2), (4, 64, True, 100, 3)])
+                                        (130, 7, True, 60, 3), (192, 4, False, 40, 2), (256, 4, False, 40, 2), (4, 64, True, 100, 3),
+                                        # beyond the LDS-resident kernels (more than 256 motifs, more than 64 letters, tables
+                                        # that exceed the LDS): the generic kernels -- round 3 REFUSED these
+                                        (300, 10, False, 60, 3), (120, 40, True, 100, 3), (8, 100, False, 160, 3), (8, 100, True, 130, 2),
+                                        (256, 4, True, 40, 2), (1, 65, True, 65, 2), (257, 1, False, 9, 2)])
 def test_edge_shapes(K, M, ds, L, n):
     """Smallest and largest supported models, L == M (a single hidden position),
     mask-word and letter-window boundaries: activations, hit probabilities,
     free energy, a Gibbs chain and a training step against the oracle."""
+    check_model_against_oracle(K, M, ds, L, n)
+
+
+def check_model_against_oracle(K, M, ds, L, n):
     Lf = max(1, L - M + 1)
     model, o = make_pair(K, M, ds=ds, batchsize=4, Lf=Lf, cd_k=2, bshift=3.0, wscale=0.7)
     D = synthetic_onehot(n, L, seed=K + M)
@@ -837,10 +847,45 @@ def test_edge_shapes(K, M, ds, L, n):
     np.testing.assert_allclose(model._bottomUpActivity(D, True), o._bottomUpActivity(D, True), rtol=1e-5, atol=2e-5)
     np.testing.assert_allclose(model.motifHitProbs(D), o.motifHitProbs(D), rtol=RTOL, atol=1e-7)
     np.testing.assert_allclose(model.freeEnergy(D), o.freeEnergy(D), rtol=RTOL, atol=1e-6)
+    np.testing.assert_allclose(model.freeEnergy(D, True), o.freeEnergy(D, True), rtol=RTOL, atol=2e-5)
+    P = o.motifHitProbs(D)
+    s = model.motifHitSummary(D)
+    np.testing.assert_allclose(s["max"], P.max(axis=(2, 3)), rtol=RTOL, atol=1e-7)
+    np.testing.assert_allclose(s["mean"], P.mean(axis=(2, 3)), rtol=RTOL, atol=1e-7)
+    np.testing.assert_allclose(s["position_mean"], P.mean(axis=(0, 2)), rtol=RTOL, atol=1e-7)
     assert_chain_steps(model, o, 2)                    # sample for sample, ties only
     model.set_fantasy(o.fantasy_h.astype(np.float32), o.fantasy_h_prime.astype(np.float32) if ds else None)
     twin = lambda: make_pair(K, M, ds=ds, batchsize=4, Lf=Lf, cd_k=2, bshift=3.0, wscale=0.7)
-    assert_train_steps(model, o, [D], twin, atol=5e-6)
+    assert_train_steps(model, o, [D, D], twin, atol=5e-6)
+    return model
+
+
+def test_generic_kernels_on_a_model_the_specialised_ones_take(monkeypatch, capsys):
+    """CRBM_FORCE_BIG=1 puts the reference's default model (10 x 15, both strands) on the generic kernels: the same
+    checks against the oracle, fit() with its status line, a checkpoint that resumes on the specialised kernels --
+    and the chain of the generic path IS the chain of the specialised path (same counters, same rules)."""
+    from crbm_amd import CRBM, _lib
+    monkeypatch.setenv("CRBM_FORCE_BIG", "1")
+    big = check_model_against_oracle(10, 15, True, 90, 5)
+    info = _lib.CrbmLaunchInfo()
+    big._lib.crbm_get_launch_info(big._h(), ctypes.byref(info))
+    assert info.gibbs_grid == 0 and info.chain_parts == 1          # the generic path has no specialised geometry
+    D = synthetic_onehot(37, 90, seed=3)
+    big.epochs = 2
+    big.fit(D)
+    assert "Epoch 1: FE=" in capsys.readouterr().out
+    with pytest.raises(Exception, match="do not pool"):
+        CRBM(300, 10, pooling=2, fantasy_hidden_len=20).gibbsSteps(1)      # (a forced model keeps its specialised kernels when pooled)
+    # the two paths sample the same chain
+    monkeypatch.delenv("CRBM_FORCE_BIG")
+    fast, o = make_pair(10, 15, ds=True, batchsize=4, Lf=76, cd_k=2, bshift=3.0, wscale=0.7)
+    monkeypatch.setenv("CRBM_FORCE_BIG", "1")
+    slow, _ = make_pair(10, 15, ds=True, batchsize=4, Lf=76, cd_k=2, bshift=3.0, wscale=0.7)
+    fast.gibbsSteps(3)
+    slow.gibbsSteps(3)
+    for a, b in zip(fast.get_fantasy(), slow.get_fantasy()):
+        assert (a != b).mean() < 1e-3                              # identical up to p == u ties (float rounding of the two paths)
+    assert fast.get_fantasy()[0].sum() > 0
 
 
 # ---- pooling > 1 (convRBM.py:245-267, :586-599, :664-665) ---------------------------------
@@ -899,16 +944,20 @@ def test_pooling(K, M, ds, pool, capsys):
     assert "Epoch 0: FE=" in capsys.readouterr().out
 
 
-def test_models_beyond_the_lds_are_refused_with_a_reason():
-    """Within K <= 256, M <= 64 the bound is the LDS: tables of both strands plus one chain must fit 160 KB."""
+def test_models_beyond_the_lds_train_on_the_generic_kernels(capsys):
+    """Round 3 refused these (tables of both strands plus one chain exceed the LDS; 16 column roles of the statistics
+    block): now fit() runs them -- against the oracle in test_edge_shapes, here through the reference's entry point."""
     from crbm_amd import CRBM
-    m = CRBM(120, 40, doublestranded=True)             # 77 KB of gather table + 180 KB of top-down tables
-    with pytest.raises(Exception, match="too large for the LDS"):
-        m.gibbsSteps(1)
-    m = CRBM(256, 4, doublestranded=True, batchsize=2, fantasy_hidden_len=20)
-    m.gibbsSteps(1)                                    # the chain fits ...
-    with pytest.raises(Exception, match="too large for the statistics kernel"):
-        m._trainingFct(synthetic_onehot(2, 30, seed=1))   # ... the 16 column roles of the statistics block do not
+    for K, M in ((120, 40), (256, 4)):
+        np.random.seed(K)
+        m = CRBM(K, M, epochs=1, doublestranded=True, batchsize=4, cd_k=2, fantasy_hidden_len=30, seed=5)
+        m.fit(synthetic_onehot(9, M + 29, seed=1))
+        assert "Epoch 0: FE=" in capsys.readouterr().out
+        assert np.isfinite(m.motifs.get_value()).all() and len(m.getPFMs()) == K
+    with pytest.raises(Exception, match="65536"):
+        CRBM(70000, 4)
+    with pytest.raises(Exception, match="512"):
+        CRBM(4, 600)
 
 
 def test_pooling_must_divide_the_chain_length():

@@ -168,16 +168,17 @@ def test_codes_detection():
 
 
 def test_limits_are_refused_at_construction():
-    """what the kernels cannot take must not wait for the middle of fit().  Round 3 lifted the
-    K <= 64 / M <= 32 bounds of the mask and window words (the reference accepts any positive K, M,
-    convRBM.py:72-108): what remains is 256 motifs (statistics block size) and 64-letter motifs (two-word
-    letter windows); beyond that the bound is the LDS, reported when the device handle is created."""
+    """what the kernels cannot take must not wait for the middle of fit().  The reference accepts any
+    positive K, M (convRBM.py:72-108); round 4 lifted the 256-motif / 64-letter / LDS bounds of the specialised
+    kernels (generic kernels take over beyond them), so what is refused at construction is a capacity limit only."""
     from crbm_amd import CRBM
-    with pytest.raises(Exception, match="num_motifs > 256"):
-        CRBM(257, 5)
-    with pytest.raises(Exception, match="motif_length > 64"):
-        CRBM(4, 65)
-    CRBM(256, 64, pooling=4)                  # fine until a GPU is needed (this one exceeds the LDS there)
+    with pytest.raises(Exception, match="num_motifs > 65536"):
+        CRBM(65537, 5)
+    with pytest.raises(Exception, match="motif_length > 512"):
+        CRBM(4, 513)
+    CRBM(257, 5)
+    CRBM(4, 65)
+    CRBM(256, 64, pooling=4)                  # fine until a GPU is needed (pooling with the generic kernels is refused there)
     CRBM(100, 15)
     CRBM(20, 40)
 
