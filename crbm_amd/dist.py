@@ -28,8 +28,9 @@ from . import _lib
 _ID_PORT_OFFSET = 17
 _PORT_TRIES = 8            # rank 0 binds the first free port of MASTER_PORT + 17 + 101*i
 _MAGIC = b"CRBMCTL2"
-_HANDSHAKE_TIMEOUT = 5.0   # seconds a fresh connection gets to identify itself (a silent stranger must not stall the accept loop)
-_MAX_MSG = 1 << 32         # largest frame accepted (checkpoint gathers are tens of MB)
+_HANDSHAKE_TIMEOUT = 5.0   # seconds a fresh connection gets to identify itself, in ALL (a silent or slow-dripping stranger must not stall the accept loop)
+_MAX_HELLO = 64            # largest frame accepted before a peer has authenticated
+_MAX_MSG = 1 << 32         # largest frame accepted afterwards (checkpoint gathers are tens of MB)
 
 
 def env_rank_world():
@@ -191,20 +192,31 @@ def decode(buf):
     return obj
 
 
-def job_secret(world, port):
+def job_secret(world, port, addr="127.0.0.1"):
     """Key of the per-message HMAC.  A launcher that wants real authentication passes a random
     CRBM_JOB_SECRET to every rank (bench.py's own spawner does); otherwise the key is derived from
-    what all ranks of one job share (launcher run id, rendezvous port, world size), which still keeps
-    the ranks of two jobs on one host apart."""
+    what all ranks of one job share (launcher run id, rendezvous port, world size), which keeps the
+    ranks of two jobs on one host apart but is guessable -- good enough on loopback only: a
+    rendezvous on a real interface REQUIRES the secret (every rank evaluates the same condition, so
+    all of them refuse together)."""
     s = os.environ.get("CRBM_JOB_SECRET")
     if not s:
+        if _bind_address(addr) != "127.0.0.1":
+            raise Exception("control plane: MASTER_ADDR=%s is not loopback -- set CRBM_JOB_SECRET (the same random string on "
+                            "every rank) so that strangers on that network cannot claim a rank" % addr)
         s = "|".join([os.environ.get("TORCHELASTIC_RUN_ID", ""), str(port), str(world)])
     return hashlib.sha256(b"crbm-control-plane:" + s.encode("utf-8")).digest()
 
 
-def _recv_exact(sock, n):
+def _recv_exact(sock, n, deadline=None):
+    """n bytes; with `deadline` (time.time() value) the WHOLE read must finish by then, however slowly the bytes drip"""
     chunks = []
     while n > 0:
+        if deadline is not None:
+            left = deadline - time.time()
+            if left <= 0:
+                raise socket.timeout("control plane: peer too slow")
+            sock.settimeout(left)
         part = sock.recv(min(n, 1 << 20))
         if not part:
             raise ConnectionError("control-plane peer closed the connection")
@@ -213,19 +225,43 @@ def _recv_exact(sock, n):
     return b"".join(chunks)
 
 
+# Every frame: length | HMAC-SHA256(key, direction | sequence number | payload) | payload.  The per-connection,
+# per-direction sequence number makes a recorded frame useless later in the same connection (and the nonce of the
+# handshake in another one).
+_SEQ = {}
+
+
+def _mac(key, sock, direction, payload, bump):
+    k = (id(sock), direction)
+    seq = _SEQ.get(k, 0)
+    if bump:
+        _SEQ[k] = seq + 1
+    return hmac.new(key, direction + struct.pack("<Q", seq) + payload, hashlib.sha256).digest()
+
+
 def _send_msg(sock, payload, key):
-    sock.sendall(struct.pack("<Q", len(payload)) + hmac.new(key, payload, hashlib.sha256).digest() + payload)
+    sock.sendall(struct.pack("<Q", len(payload)) + _mac(key, sock, b"S", payload, True) + payload)
 
 
-def _recv_msg(sock, key):
-    (n,) = struct.unpack("<Q", _recv_exact(sock, 8))
-    if n > _MAX_MSG:
+def _recv_msg(sock, key, max_len=_MAX_MSG, deadline=None):
+    (n,) = struct.unpack("<Q", _recv_exact(sock, 8, deadline))
+    if n > max_len:
         raise ConnectionError("control plane: oversized frame (%d bytes)" % n)
-    mac = _recv_exact(sock, 32)
-    payload = _recv_exact(sock, n)
-    if not hmac.compare_digest(mac, hmac.new(key, payload, hashlib.sha256).digest()):
-        raise ConnectionError("control plane: message authentication failed (a peer of another job?)")
+    mac = _recv_exact(sock, 32, deadline)
+    payload = _recv_exact(sock, n, deadline)
+    # the peer's "S" direction is what we verify: its send counter is our receive counter
+    k = (id(sock), b"R")
+    seq = _SEQ.get(k, 0)
+    want = hmac.new(key, b"S" + struct.pack("<Q", seq) + payload, hashlib.sha256).digest()
+    if not hmac.compare_digest(mac, want):
+        raise ConnectionError("control plane: message authentication failed (a peer of another job, or a replayed frame)")
+    _SEQ[k] = seq + 1
     return payload
+
+
+def _forget(sock):
+    _SEQ.pop((id(sock), b"S"), None)
+    _SEQ.pop((id(sock), b"R"), None)
 
 
 def _bind_address(addr):
@@ -259,7 +295,7 @@ class ControlPlane(object):
         addr = _bind_address(addr or os.environ.get("MASTER_ADDR", "127.0.0.1"))
         base = int(port or int(os.environ.get("MASTER_PORT", "29500")) + _ID_PORT_OFFSET)
         ports = [base + 101 * i for i in range(_PORT_TRIES)]
-        self.key = job_secret(self.world, base)
+        self.key = job_secret(self.world, base, addr)
         # hello = magic | world | rank | nonce, authenticated like every later message; rank 0 answers with
         # an authenticated echo of the nonce, so neither side accepts a peer that lacks the job's key
         if self.rank == 0:
@@ -290,9 +326,10 @@ class ControlPlane(object):
                     except socket.timeout:
                         continue
                     try:
+                        _forget(conn)
                         conn.settimeout(_HANDSHAKE_TIMEOUT)
                         conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                        hello = _recv_msg(conn, self.key)
+                        hello = _recv_msg(conn, self.key, _MAX_HELLO, time.time() + _HANDSHAKE_TIMEOUT)
                         magic, w, r, nonce = hello[:8], *struct.unpack("<II", hello[8:16]), hello[16:]
                         if magic != _MAGIC or w != self.world or not (0 < r < self.world) or r in slots or len(nonce) != 16:
                             raise ConnectionError("not a rank of this job")
@@ -300,6 +337,7 @@ class ControlPlane(object):
                         conn.settimeout(self.collective_timeout)
                         slots[r] = conn
                     except (OSError, ConnectionError, ValueError, struct.error):
+                        _forget(conn)
                         conn.close()              # a stranger, a rank of another job, or a silent connection
             finally:
                 srv.close()
@@ -313,16 +351,19 @@ class ControlPlane(object):
                     s = None
                     try:
                         s = socket.create_connection((addr, p), timeout=_HANDSHAKE_TIMEOUT)
+                        _forget(s)
                         s.settimeout(_HANDSHAKE_TIMEOUT)
                         s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                         _send_msg(s, mine, self.key)
-                        if _recv_msg(s, self.key) == _MAGIC + nonce:
+                        if _recv_msg(s, self.key, _MAX_HELLO, time.time() + _HANDSHAKE_TIMEOUT) == _MAGIC + nonce:
                             s.settimeout(self.collective_timeout)
                             self.sock = s
                             break
+                        _forget(s)
                         s.close()
                     except (OSError, ConnectionError):
                         if s is not None:
+                            _forget(s)
                             s.close()
                 if self.sock is None:
                     if time.time() > deadline:
@@ -368,11 +409,13 @@ class ControlPlane(object):
 
     def close(self):
         for p in self.peers:
+            _forget(p)
             try:
                 p.close()
             except OSError:
                 pass
         if self.sock is not None:
+            _forget(self.sock)
             try:
                 self.sock.close()
             except OSError:

@@ -288,6 +288,42 @@ def test_control_plane_survives_strangers(monkeypatch):
     silent.close(); wrong.close()
 
 
+def test_control_plane_frames_cannot_be_replayed_and_real_interfaces_need_a_secret(monkeypatch):
+    """the MAC covers a per-connection, per-direction sequence number (a recorded frame does not verify a
+    second time), the frame a peer may send before it has authenticated is capped at 64 bytes and must arrive within
+    one overall deadline however slowly it drips, and a rendezvous on a real interface requires CRBM_JOB_SECRET."""
+    import struct
+    import time
+    from crbm_amd import dist
+    a, b = socket.socketpair()
+    key = dist.job_secret(2, 12345)
+    try:
+        dist._send_msg(a, b"first", key)
+        dist._send_msg(a, b"second", key)
+        raw = b.recv(4096, socket.MSG_PEEK)
+        assert dist._recv_msg(b, key) == b"first" and dist._recv_msg(b, key) == b"second"
+        a.sendall(raw[:8 + 32 + 5])                      # the recorded first frame once more
+        with pytest.raises(ConnectionError, match="authentication"):
+            dist._recv_msg(b, key)
+        # a frame that claims to be large is refused before its body is read; a dripping peer runs into the deadline
+        a.sendall(struct.pack("<Q", 1 << 20))
+        with pytest.raises(ConnectionError, match="oversized"):
+            dist._recv_msg(b, key, dist._MAX_HELLO)
+        a.sendall(struct.pack("<Q", 32) + b"x" * 10)
+        t0 = time.time()
+        with pytest.raises(socket.timeout):
+            dist._recv_msg(b, key, dist._MAX_HELLO, time.time() + 0.3)
+        assert time.time() - t0 < 2.0
+    finally:
+        dist._forget(a); dist._forget(b)
+        a.close(); b.close()
+    monkeypatch.delenv("CRBM_JOB_SECRET", raising=False)
+    with pytest.raises(Exception, match="CRBM_JOB_SECRET"):
+        dist.job_secret(2, 29517, "10.1.2.3")
+    monkeypatch.setenv("CRBM_JOB_SECRET", "x")
+    assert len(dist.job_secret(2, 29517, "10.1.2.3")) == 32
+
+
 def test_empty_shards_are_known_to_every_rank():
     from crbm_amd.dist import empty_shards, shard_rows
     assert empty_shards(1, 20, 2) == [0]                 # the lone row goes to rank 1: rank 0 owns nothing
