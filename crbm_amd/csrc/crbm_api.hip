@@ -180,8 +180,10 @@ struct crbm_handle {
   // Plain chain launches of short kernels go out as `chain_parts` launches of `part_chains` chains each, one stream per
   // partition: chains are independent, so partition p's step t+1 only waits for partition p's step t, and the drain of
   // one partition's kernel, the dispatch and the ramp of its next one are filled by the other partition's blocks on the
-  // same CUs (config #2: 20.9 -> 17.6 us per step of the whole batch).  solo_* / gl_solo then describe ONE partition.
+  // same CUs (config #2: 20.9 -> 17.6 us per step of the whole batch).
   int chain_parts = 1, part_chains = 0;
+  GibbsLayout gl_part;                 // geometry of ONE partition's launch (chain_parts > 1); solo_* / gl_solo stay the unpartitioned one,
+  int part_threads = 0, part_grid = 0; // which the chain launch INSIDE a training step takes (one launch, then the statistics wait for it)
   hipStream_t part_stream[4] = {nullptr, nullptr, nullptr, nullptr};
   PartWorker* part_worker[4] = {nullptr, nullptr, nullptr, nullptr};   // [0] stays null: the caller's thread
   hipEvent_t part_done[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -593,7 +595,7 @@ int launch_gibbs_parts(crbm_handle* h, int steps) {
   unsigned lds = 0;
   const GibbsLayout gl_keep = h->gl;
   const int threads_keep = h->gibbs_threads, grid_keep = h->gibbs_grid;
-  h->gl = h->gl_solo; h->gibbs_threads = h->solo_threads; h->gibbs_grid = h->solo_grid;
+  h->gl = h->gl_part; h->gibbs_threads = h->part_threads; h->gibbs_grid = h->part_grid;
   int rc = prepare_gibbs(h, steps, nullptr, &a, &lds);
   const unsigned grid = (unsigned)h->gibbs_grid, threads = (unsigned)h->gibbs_threads;
   h->gl = gl_keep; h->gibbs_threads = threads_keep; h->gibbs_grid = grid_keep;
@@ -635,12 +637,14 @@ int launch_gibbs_parts(crbm_handle* h, int steps) {
   return CRBM_OK;
 }
 
-int launch_gibbs(crbm_handle* h, int steps, hipStream_t s = nullptr, ReduceArgs* model_reduce = nullptr) {
+// plain: a launch that only advances the chains, from the API (crbm_gibbs_steps*, crbm_time_gibbs) -- those may go out in
+// partitions; the chain launch inside a training step is followed at once by kernels that wait for all of it and stays whole
+int launch_gibbs(crbm_handle* h, int steps, hipStream_t s = nullptr, ReduceArgs* model_reduce = nullptr, bool plain = false) {
   if (!s) s = h->stream;
   if (h->big) return big_launch_gibbs(h, steps, s);
   int rc = ensure_tables(h);
   if (rc) return rc;
-  if (!model_reduce && h->variant == 1 && h->chain_parts > 1 && s == h->stream) return launch_gibbs_parts(h, steps);
+  if (plain && !model_reduce && h->variant == 1 && h->chain_parts > 1 && s == h->stream) return launch_gibbs_parts(h, steps);
   GibbsArgs a;
   unsigned lds = 0;
   const bool solo = !model_reduce && h->variant == 1 && h->solo_threads > 0;
@@ -1199,15 +1203,12 @@ int crbm_precompile(const crbm_config* cfg) {
   const GibbsGeom gs = choose_gibbs_geometry(ms, Lf_pc, cfg->batchsize, ncu, true);
   int tb = gs.threads;
   if (ms.DENSE) tb = std::max(tb, choose_gibbs_geometry(ms, Lf_pc, cfg->batchsize, ncu, false).threads);
-  int GS = G;
   const PartPlan plan = plan_chain_parts(ms, Lf_pc, cfg->batchsize, ncu);
   if (plan.parts > 1) tb = std::max(tb, plan.geom.threads);
-  else {
-    GS = solo_group(ms.K, ms.M, ms.DS, G, ms.POOL);
-    GibbsGeom solo = choose_gibbs_geometry(model_shape(ms.K, ms.M, ms.DS, GS, ms.POOL), Lf_pc, cfg->batchsize, ncu, true, true);
-    if (solo.lds <= 0 && GS != G) { GS = G; solo = choose_gibbs_geometry(ms, Lf_pc, cfg->batchsize, ncu, true, true); }
-    tb = std::max(tb, solo.threads);
-  }
+  int GS = plan.parts > 1 ? G : solo_group(ms.K, ms.M, ms.DS, G, ms.POOL);
+  GibbsGeom solo = choose_gibbs_geometry(model_shape(ms.K, ms.M, ms.DS, GS, ms.POOL), Lf_pc, cfg->batchsize, ncu, true, true);
+  if (solo.lds <= 0 && GS != G) { GS = G; solo = choose_gibbs_geometry(ms, Lf_pc, cfg->batchsize, ncu, true, true); }
+  tb = std::max(tb, solo.threads);
   if (jit_compile(ms.K, ms.M, ms.DS, ms.G, GS, ms.POOL, gibbs_wpe_hint(gs), gibbs_block_bound(tb), &code, &cached, &file, &err) != 0) {
     g_create_error = err;
     return CRBM_ERR_HIP;
@@ -1289,26 +1290,24 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
     // unpartitioned ones of small fused models with their own letter grouping (solo_group)
     const PartPlan plan = plan_chain_parts(hh->ms, hh->Lf, hh->B, hh->num_cu);
     hh->chain_parts = plan.parts;
+    hh->part_chains = plan.parts > 1 ? plan.part_chains : hh->B;
     if (plan.parts > 1) {
+      hh->gl_part = gibbs_layout(hh->ms, hh->Lf, plan.geom.S, true);
+      hh->part_threads = plan.geom.threads;
+      hh->part_grid = plan.geom.grid;
+    }
+    // the unpartitioned launch: its own geometry and, where nothing else launches that kernel, its own letter grouping
+    hh->GS = plan.parts > 1 ? hh->G : solo_group(hh->K, hh->M, hh->ds, hh->G, cfg->pooling);
+    hh->ms_solo = model_shape(hh->K, hh->M, hh->ds, hh->GS, cfg->pooling);
+    GibbsGeom solo = choose_gibbs_geometry(hh->ms_solo, hh->Lf, hh->B, hh->num_cu, true, true);
+    if (solo.lds <= 0 && hh->GS != hh->G) {           // the larger table leaves no room for a chain: the model's grouping
       hh->GS = hh->G; hh->ms_solo = hh->ms;
-      hh->part_chains = plan.part_chains;
-      hh->gl_solo = gibbs_layout(hh->ms, hh->Lf, plan.geom.S, true);
-      hh->solo_threads = plan.geom.threads;
-      hh->solo_grid = plan.geom.grid;
-    } else {
-      hh->part_chains = hh->B;
-      hh->GS = solo_group(hh->K, hh->M, hh->ds, hh->G, cfg->pooling);
-      hh->ms_solo = model_shape(hh->K, hh->M, hh->ds, hh->GS, cfg->pooling);
-      GibbsGeom solo = choose_gibbs_geometry(hh->ms_solo, hh->Lf, hh->B, hh->num_cu, true, true);
-      if (solo.lds <= 0 && hh->GS != hh->G) {           // the larger table leaves no room for a chain: the model's grouping
-        hh->GS = hh->G; hh->ms_solo = hh->ms;
-        solo = choose_gibbs_geometry(hh->ms_solo, hh->Lf, hh->B, hh->num_cu, true, true);
-      }
-      if (solo.lds > 0 && (hh->GS != hh->G || solo.threads != hh->threadsv[1] || solo.S != hh->glv[1].S || solo.grid != hh->gridv[1])) {
-        hh->gl_solo = gibbs_layout(hh->ms_solo, hh->Lf, solo.S, true);
-        hh->solo_threads = solo.threads;
-        hh->solo_grid = solo.grid;
-      }
+      solo = choose_gibbs_geometry(hh->ms_solo, hh->Lf, hh->B, hh->num_cu, true, true);
+    }
+    if (solo.lds > 0 && (hh->GS != hh->G || solo.threads != hh->threadsv[1] || solo.S != hh->glv[1].S || solo.grid != hh->gridv[1])) {
+      hh->gl_solo = gibbs_layout(hh->ms_solo, hh->Lf, solo.S, true);
+      hh->solo_threads = solo.threads;
+      hh->solo_grid = solo.grid;
     }
   }
   if (!hh->big) {
@@ -1321,7 +1320,7 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
   }
   if (!hh->big) {
     std::string err;
-    const int tb = gibbs_block_bound(std::max(std::max(hh->has_dense ? hh->threadsv[0] : 0, hh->threadsv[1]), hh->solo_threads));
+    const int tb = gibbs_block_bound(std::max(std::max(std::max(hh->has_dense ? hh->threadsv[0] : 0, hh->threadsv[1]), hh->solo_threads), hh->part_threads));
     if (jit_load(hh->K, hh->M, hh->ds, hh->G, hh->GS, hh->ms.POOL, hh->gibbs_wpe, tb, &hh->jk, &err) != 0) {
       g_create_error = "kernel specialisation failed: " + err;
       return bail(CRBM_ERR_HIP);
@@ -1370,7 +1369,7 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
   TRY(hipMalloc((void**)&hh->d_flags, 16)); TRY(hipMemset(hh->d_flags, 0, 16));
   TRY(hipMalloc((void**)&hh->d_ones, 16)); TRY(hipMemset(hh->d_ones, 0, 16));
   {
-    const size_t slots = (size_t)std::max(std::max(hh->gridv[0] * (hh->threadsv[0] / 64), hh->gridv[1] * (hh->threadsv[1] / 64)), hh->chain_parts * hh->solo_grid * (hh->solo_threads / 64)) + 64;
+    const size_t slots = (size_t)std::max(std::max(hh->gridv[0] * (hh->threadsv[0] / 64), hh->gridv[1] * (hh->threadsv[1] / 64)), std::max(hh->solo_grid * (hh->solo_threads / 64), hh->chain_parts * hh->part_grid * (hh->part_threads / 64))) + 64;
     TRY(hipMalloc((void**)&hh->d_nset, slots * 4)); TRY(hipMemset(hh->d_nset, 0, slots * 4));
   }
   TRY(hipMalloc((void**)&hh->d_sums, (size_t)hh->sl.count * 4)); TRY(hipMemset(hh->d_sums, 0, (size_t)hh->sl.count * 4));
@@ -1697,7 +1696,7 @@ int crbm_train_epoch_sharded(crbm_handle* h, int32_t batchsize, int32_t total_ro
 int crbm_gibbs_steps_async(crbm_handle* h, int32_t k) {
   ENTER_ASYNC();
   ARGCHK(k >= 1, "k must be positive");
-  return launch_gibbs(h, k);
+  return launch_gibbs(h, k, nullptr, nullptr, true);
 }
 
 int crbm_sync(crbm_handle* h) {
@@ -1746,7 +1745,7 @@ int crbm_time_gibbs(crbm_handle* h, int32_t k, int32_t launches, float* total_ms
   const bool trace_enq = env_int("CRBM_TIME_ENQUEUE", 0) >= 2;
   std::vector<double> enq_us;
   for (int i = 0; i < launches; ++i) {
-    int rc = launch_gibbs(h, k);
+    int rc = launch_gibbs(h, k, nullptr, nullptr, true);
     if (rc) return rc;
     if (trace_enq) enq_us.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_enq0).count());
   }
@@ -2480,10 +2479,13 @@ int crbm_get_launch_info(const crbm_handle* h, crbm_launch_info* out) {
   const int lds = std::max(st.region_floats * 4 + tabs, st.combine_bytes);
   out->nq = h->ms.NQ; out->group = h->GS;   // of the plain chain launch this structure describes
   // the geometry of a plain chain launch (crbm_gibbs_steps*): the solo one where the model has it
+  const bool parts = h->variant == 1 && h->chain_parts > 1;
   const bool solo = h->variant == 1 && h->solo_threads > 0;
-  out->chain_parts = h->variant == 1 ? h->chain_parts : 1;
-  out->gibbs_grid = solo ? h->solo_grid : h->gibbs_grid; out->gibbs_block = solo ? h->solo_threads : h->gibbs_threads;
-  out->gibbs_seqs_per_tile = solo ? h->gl_solo.S : h->gl.S; out->gibbs_lds_bytes = solo ? h->gl_solo.lds_bytes : h->gl.lds_bytes;
+  out->chain_parts = parts ? h->chain_parts : 1;
+  out->gibbs_grid = parts ? h->part_grid : solo ? h->solo_grid : h->gibbs_grid;
+  out->gibbs_block = parts ? h->part_threads : solo ? h->solo_threads : h->gibbs_threads;
+  out->gibbs_seqs_per_tile = parts ? h->gl_part.S : solo ? h->gl_solo.S : h->gl.S;
+  out->gibbs_lds_bytes = parts ? h->gl_part.lds_bytes : solo ? h->gl_solo.lds_bytes : h->gl.lds_bytes;
   out->stats_grid_x = h->stats_rows > 0 ? h->stats_rows
                                         : h->num_cu * std::max(1, std::min(2048 / st.threads, (160 * 1024) / std::max(1, lds)));
   out->stats_grid_y = 1;
