@@ -542,22 +542,30 @@ def main():
     copy_gbs = ctypes.c_float()
     if os.environ.get("CRBM_BENCH_COPY_FIRST", "0") == "1":      # (A/B switch: the copy test in front of the timed region, as until round 3)
         model._call("crbm_copy_bandwidth", 1 << 30, 5, ctypes.byref(copy_gbs))
-    # chains start at h = 0 (convRBM.py:168): 500 burn-in steps, then the W warm-up launches.
+    # chains start at h = 0 (convRBM.py:168): 3000 burn-in steps (55 ms at config #2), then the W warm-up launches.
     # The burn-in is part of building the workload, not of the measurement: a persistent chain is never at
-    # h = 0 in training.  (Its length does not change what the driver's short timed region sees: 500, 3000,
-    # 10 000 or 30 000 steps all leave the 20-launch window at 20.4-21.9 us per step with the shader clock at
-    # 2.13-2.26 GHz, against 17.3 us at 2.35 GHz in the steady state of a 2000-launch run -- the part needs
-    # milliseconds of uninterrupted load to reach its sustained clock, and the barrier + synchronise the
-    # contract puts in front of the timed region is an interruption: gpurun_out/r4_tests/burnin.txt,
-    # tools/ramp_probe.py.  shader_clock_mhz_timed_run in the line is the clock the timed launches saw.)
+    # h = 0 in training -- and it is what brings the GPU to the clock it holds under load: the part steps between
+    # ~2.14 and ~2.39 GHz with a few milliseconds of hysteresis (tools/ramp_probe.py prints the clock the launches
+    # themselves sample: 2.14 GHz in 20-launch windows right behind 500 steps or 10 ms of idling, 2.39 GHz behind a
+    # 2000-launch window), and the driver's timed region is 0.4 ms long.  With 3000 steps enqueued by the library's
+    # own loop the 20-launch window runs at 2.35 GHz and 19.1-20.4 us per step (gpurun_out/r4_tests/burnin2.txt);
+    # a window that short still carries ~2 us per step of start and tail (the first launches of the two partitions
+    # have nothing to overlap with, the last one runs alone), the steady state of a 2000-launch run is 17.2 us.
+    # warmup_effective in the line counts the burn-in; shader_clock_mhz_timed_run is the clock of the timed launches.
     # (as launches of k steps like the timed ones: every launch of the chain kernel in this process is then
     # the same work, and a profiler's per-kernel average is that of the timed launches)
-    burn_launches = max(1, int(os.environ.get("CRBM_BENCH_BURNIN", "500")) // k)
-    for _ in range(burn_launches):
-        model._call("crbm_gibbs_steps_async", k)
-    model._call("crbm_sync")
-    for _ in range(args.warmup):
-        model._call("crbm_gibbs_steps_async", k)
+    burn_launches = max(1, int(os.environ.get("CRBM_BENCH_BURNIN", "3000")) // k)
+    burn_ms = ctypes.c_float()
+    if os.environ.get("CRBM_BENCH_BURNIN_PY", "0") == "1":        # (A/B switch: one Python call per burn-in launch, as until round 3)
+        for _ in range(burn_launches):
+            model._call("crbm_gibbs_steps_async", k)
+        model._call("crbm_sync")
+    else:
+        # enqueued by the library's own loop: a Python call per launch (10-15 us of host time) does not keep up with 17-us
+        # steps, and a GPU that waits for its host between launches never settles at its sustained clock
+        model._call("crbm_time_gibbs", k, burn_launches, ctypes.byref(burn_ms))
+    if args.warmup > 0:
+        model._call("crbm_time_gibbs", k, args.warmup, ctypes.byref(burn_ms))
 
     # ---- timed region: exactly K launches, HIP events on the library's stream ----
     total_ms = ctypes.c_float()
