@@ -510,6 +510,11 @@ def main():
     # ranks on one device).  The driver's runs never set it.
     share_gpu = os.environ.get("CRBM_BENCH_SHARE_GPU", "0") == "1"
     device = 0 if share_gpu else local_rank
+    if share_gpu and world > 1:
+        # N processes on ONE GPU oversubscribe its hardware queues once every rank brings a partition stream of its own
+        # (six ranks: 0.075 -> 0.40 ms per step, the mapped-buffer all-reduce 7 us -> 11 ms of time slicing): the rehearsal
+        # keeps the chain launches whole.  Real multi-GPU runs (one GPU per rank) partition as a single rank does.
+        os.environ.setdefault("CRBM_CHAIN_PARTS", "1")
 
     # counters of the chain kernel on this box (children under rocprofv3, before this process touches the GPU)
     pmc, pmc_note = None, "not collected (multi-rank run, or --no-pmc)"

@@ -225,6 +225,8 @@ struct crbm_handle {
   unsigned long long* d_probe = nullptr;   // {wall ticks, shader cycles, scratch, scratch} summed over the launches of all crbm_time_gibbs calls
   unsigned long long probe_base[2] = {0, 0}, probe_last[2] = {0, 0};   // the sums before / after the last call
   bool probe_on = false;
+  unsigned long long* d_timeline = nullptr;   // CRBM_GIBBS_TIMELINE: first / last tick of block 0 of every launch of a crbm_time_gibbs call
+  int timeline_cap = 0, timeline_next = 0;
   unsigned long long ipc_timeout_ticks = 0;   // bound of an update launch's wait for its peers, in ticks of the GPU's wall clock
   std::string err;
 };
@@ -487,6 +489,7 @@ int prepare_gibbs(crbm_handle* h, int steps, ReduceArgs* model_reduce, GibbsArgs
   a.rng = rng_view(h, h->gibbs_step, h->chain_offset);
   a.ones = h->d_nset;
   a.clock = h->probe_on ? h->d_probe : nullptr;
+  a.timeline = nullptr;
   a.debug = env_int("CRBM_GIBBS_DEBUG", 0);
   h->nset_slots = h->gibbs_grid * (h->gibbs_threads / 64);
   a.nblocks = h->gibbs_grid;
@@ -515,6 +518,14 @@ void part_worker_main(PartWorker* w) {
   (void)hipSetDevice(w->device);
   std::unique_lock<std::mutex> lock(w->mu);
   for (;;) {
+    // launches come in bursts: poll for a couple of milliseconds before going to sleep (a sleeping thread picks its
+    // first job up 20-35 us late, and that is how late the partition's first launch of a burst then starts)
+    const auto spin_until_t = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
+    while (!w->stop && w->jobs.empty() && std::chrono::steady_clock::now() < spin_until_t) {
+      lock.unlock();
+      for (int i = 0; i < 64; ++i) __builtin_ia32_pause();
+      lock.lock();
+    }
     w->cv.wait(lock, [&] { return w->stop || !w->jobs.empty(); });
     if (w->jobs.empty()) return;       // stop, nothing left
     PartJob job = w->jobs.front();
@@ -557,7 +568,7 @@ int join_parts(crbm_handle* h) {
     const int rc = drain_part_workers(h);
     if (rc) return rc;
   }
-  for (int p = 0; p < h->chain_parts; ++p) {
+  for (int p = 1; p < h->chain_parts; ++p) {          // (partition 0 is the main stream itself)
     HIPCHK(hipEventRecord(h->part_done[p], h->part_stream[p]));
     HIPCHK(hipStreamWaitEvent(h->stream, h->part_done[p], 0));
   }
@@ -573,7 +584,7 @@ int launch_gibbs_parts(crbm_handle* h, int steps) {
     if (!h->main_idle_hint && hipStreamQuery(h->stream) != hipSuccess) {     // ... unless it is idle: nothing to wait for, no cross-stream dependency to resolve
       (void)hipGetLastError();
       HIPCHK(hipEventRecord(h->ev_parts_fork, h->stream));
-      for (int p = 0; p < h->chain_parts; ++p) HIPCHK(hipStreamWaitEvent(h->part_stream[p], h->ev_parts_fork, 0));
+      for (int p = 1; p < h->chain_parts; ++p) HIPCHK(hipStreamWaitEvent(h->part_stream[p], h->ev_parts_fork, 0));
     }
     h->main_idle_hint = false;
     h->forked = true;
@@ -614,6 +625,7 @@ int launch_gibbs_parts(crbm_handle* h, int steps) {
     ap.rng.seq_offset = a.rng.seq_offset + (uint32_t)c0;
     ap.ones = a.ones + (size_t)p * grid * waves;
     if (p > 0) ap.clock = nullptr;
+    if (h->d_timeline && h->timeline_next < h->timeline_cap) ap.timeline = h->d_timeline + 2 * (size_t)(h->timeline_next++);
     ap.nblocks = (int)grid;
     if (p > 0) {          // the partition's own thread enqueues it
       PartWorker* w = h->part_worker[p];
@@ -659,6 +671,7 @@ int launch_gibbs(crbm_handle* h, int steps, hipStream_t s = nullptr, ReduceArgs*
   const unsigned grid = (unsigned)h->gibbs_grid, threads = (unsigned)h->gibbs_threads;
   if (solo) { h->gl = gl_keep; h->gibbs_threads = threads_keep; h->gibbs_grid = grid_keep; }
   if (rc) return rc;
+  if (plain && h->d_timeline && h->timeline_next < h->timeline_cap) a.timeline = h->d_timeline + 2 * (size_t)(h->timeline_next++);
   hipFunction_t fn = model_reduce ? h->jk.gibbs_sparse_stats : (h->variant ? h->jk.gibbs_sparse : h->jk.gibbs);
   HIPCHK(jit_launch(fn, a, grid, 1, threads, lds, s));
   h->gibbs_step += (uint32_t)steps;
@@ -1336,10 +1349,11 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
     TRY(hipEventCreateWithFlags(&hh->ev_parts_fork, hipEventDisableTiming));
     TRY(hipEventCreate(&hh->ev_cal0));
     TRY(hipEventCreate(&hh->ev_cal1));
-    for (int p = 0; p < hh->chain_parts; ++p) {
+    hh->part_stream[0] = hh->stream;          // partition 0 rides on the handle's own stream: one hardware queue fewer
+    for (int p = 1; p < hh->chain_parts; ++p) {
       TRY(hipStreamCreateWithFlags(&hh->part_stream[p], hipStreamNonBlocking));
       TRY(hipEventCreate(&hh->part_done[p]));     // with timestamps: crbm_time_gibbs reads them
-      if (p > 0) {
+      {
         PartWorker* w = new PartWorker();
         w->device = hh->device;
         w->stream = hh->part_stream[p];
@@ -1408,7 +1422,7 @@ int crbm_destroy(crbm_handle* h) {
       delete w;
       h->part_worker[p] = nullptr;
     }
-    if (h->part_stream[p]) { (void)hipStreamSynchronize(h->part_stream[p]); (void)hipStreamDestroy(h->part_stream[p]); }
+    if (p > 0 && h->part_stream[p]) { (void)hipStreamSynchronize(h->part_stream[p]); (void)hipStreamDestroy(h->part_stream[p]); }
     if (h->part_done[p]) (void)hipEventDestroy(h->part_done[p]);
   }
   if (h->ev_parts_fork) (void)hipEventDestroy(h->ev_parts_fork);
@@ -1418,7 +1432,7 @@ int crbm_destroy(crbm_handle* h) {
   for (int r = 0; r < IPC_MAX_RANKS; ++r)
     if (h->ipc_peer[r] && h->ipc_peer[r] != h->ipc_buf) (void)hipIpcCloseMemHandle(h->ipc_peer[r]);
   if (h->ipc_buf) (void)hipFree(h->ipc_buf);
-  void* ptrs[] = {h->dW2, h->db2, h->dc2, h->dvW2, h->dvb2, h->dvc2, h->dW, h->db, h->dc, h->dvW, h->dvb, h->dvc, h->d_hm, h->d_hmp, h->d_vf, h->d_flags, h->d_ones, h->d_nset, h->d_sums, h->d_ticket, h->d_tables, h->d_tf_solo, h->d_probe};
+  void* ptrs[] = {h->dW2, h->db2, h->dc2, h->dvW2, h->dvb2, h->dvc2, h->dW, h->db, h->dc, h->dvW, h->dvb, h->dvc, h->d_hm, h->d_hmp, h->d_vf, h->d_flags, h->d_ones, h->d_nset, h->d_sums, h->d_ticket, h->d_tables, h->d_tf_solo, h->d_probe, h->d_timeline};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   h->stage.release(); h->stage2.release(); h->out_a.release(); h->out_b.release(); h->out_c.release();
@@ -1737,6 +1751,40 @@ int crbm_time_gibbs(crbm_handle* h, int32_t k, int32_t launches, float* total_ms
   //  nothing touches the GPU here before the opening event)
   h->probe_base[0] = h->probe_last[0]; h->probe_base[1] = h->probe_last[1];
   h->probe_on = true;
+  const bool want_timeline = env_int("CRBM_GIBBS_TIMELINE", 0) != 0 && launches <= 4096;
+  if (want_timeline) {
+    const int need = launches * std::max(1, h->chain_parts);
+    if (need > h->timeline_cap) {
+      if (h->d_timeline) (void)hipFree(h->d_timeline);
+      h->d_timeline = nullptr;
+      HIPCHK(hipMalloc((void**)&h->d_timeline, (size_t)need * 16));
+      h->timeline_cap = need;
+    }
+    HIPCHK(hipMemset(h->d_timeline, 0, (size_t)h->timeline_cap * 16));
+    h->timeline_next = 0;
+  } else {
+    h->timeline_cap = h->d_timeline ? h->timeline_cap : 0;
+    h->timeline_next = h->timeline_cap;      // no slots handed out
+  }
+  struct TimelineDump {
+    crbm_handle* h; bool on;
+    ~TimelineDump() {
+      if (!on || !h->d_timeline) return;
+      (void)hipDeviceSynchronize();
+      std::vector<unsigned long long> t((size_t)h->timeline_next * 2);
+      if (hipMemcpy(t.data(), h->d_timeline, t.size() * 8, hipMemcpyDeviceToHost) != hipSuccess || t.empty()) return;
+      unsigned long long t0 = ~0ull;
+      for (size_t i = 0; i < t.size(); i += 2) if (t[i]) t0 = std::min(t0, t[i]);
+      const double us = 1000.0 / h->wall_khz;
+      fprintf(stderr, "chain launches (block 0: start-end in us from the first start; %d partition(s), launch order):", h->chain_parts);
+      for (size_t i = 0; i < t.size(); i += 2) {
+        if (i == 2 * 60 && t.size() > 2 * 120) { fprintf(stderr, " ..."); i = t.size() - 2 * 60; }
+        fprintf(stderr, " %.1f-%.1f", (t[i] - t0) * us, (t[i + 1] - t0) * us);
+      }
+      fprintf(stderr, "\n");
+      h->timeline_next = h->timeline_cap;
+    }
+  } timeline_dump{h, want_timeline};
   struct ProbeOff { crbm_handle* h; ~ProbeOff() { h->probe_on = false; } } probe_off{h};
   h->main_idle_hint = hipStreamQuery(h->stream) == hipSuccess;   // (the opening event below does not count as work to wait for)
   (void)hipGetLastError();
@@ -1765,8 +1813,11 @@ int crbm_time_gibbs(crbm_handle* h, int32_t k, int32_t launches, float* total_ms
       const int rc = drain_part_workers(h);
       if (rc) return rc;
     }
-    for (int p = 0; p < h->chain_parts; ++p) HIPCHK(hipEventRecord(h->part_done[p], h->part_stream[p]));
-    for (int p = 0; p < h->chain_parts; ++p) {
+    HIPCHK(hipEventRecord(h->ev1, h->stream));                       // partition 0 = the main stream
+    for (int p = 1; p < h->chain_parts; ++p) HIPCHK(hipEventRecord(h->part_done[p], h->part_stream[p]));
+    HIPCHK(spin_until(h->ev1));
+    HIPCHK(hipEventElapsedTime(&worst, h->ev0, h->ev1));
+    for (int p = 1; p < h->chain_parts; ++p) {
       float ms = 0.f;
       HIPCHK(spin_until(h->part_done[p]));
       HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->part_done[p]));

@@ -1215,6 +1215,7 @@ struct GibbsArgs {
   uint32_t* ones;      // [gridDim.x * waves per block] set bits of the final hidden state per wave (activity monitor), may be null
   unsigned long long* clock = nullptr;   // null, or {sum of wall ticks, sum of shader cycles, scratch, scratch}: block 0 adds the duration of
                                // this launch in both clocks (their ratio is the shader clock WHILE the kernel ran: crbm_time_gibbs)
+  unsigned long long* timeline = nullptr;   // measurement aid: null, or two words: block 0's first and last wall-clock tick of this launch
   int32_t debug;       // profiling only: 1 skips the table copy, 2 the state load, 4 the state store
   // STATS variant only: the model half of the gradient statistics rides in the last h|v pass
   int32_t nblocks;     // blocks [0, nblocks) of the launch run the chain (0: the whole grid)
@@ -1315,6 +1316,7 @@ __device__ void gibbs_body(const GibbsArgs& a, int bid = -1) {   // bid: block o
     a.clock[2] = realtime_ticks();
     a.clock[3] = shader_cycles();
   }
+  if (a.timeline && bid == 0 && threadIdx.x == 0) a.timeline[0] = realtime_ticks();
   const int nblk = a.nblocks > 0 ? a.nblocks : (int)gridDim.x;
   int nset = 0;
   // statistics state (STATS): the wave's LDS slice, accumulator tiles, letter counts
@@ -1739,6 +1741,7 @@ __device__ void gibbs_body(const GibbsArgs& a, int bid = -1) {   // bid: block o
     a.clock[0] += realtime_ticks() - a.clock[2];
     a.clock[1] += shader_cycles() - a.clock[3];
   }
+  if (a.timeline && bid == 0 && threadIdx.x == 0) a.timeline[1] = realtime_ticks();
   if constexpr (STATS) stats_mfma_finish<C, false>(a.sg, smem, 0, bid, sacc, vcount);
 }
 
