@@ -745,7 +745,8 @@ int prepare_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool 
   // 78).  Stand-alone: as many blocks as are resident at once; riding in the training launch: three per CU
   // beside the four chain blocks (measured optimum, fewer partial rows to combine and reduce).
   const int per_cu = own ? std::max(1, std::min(2048 / st.threads, (160 * 1024) / std::max(1, lds))) : 3;
-  const long cap = h->stats_rows > 0 ? h->stats_rows : (long)h->num_cu * per_cu;
+  // (riding beside the chain blocks: three 256-thread blocks per CU, the same number of waves with larger blocks)
+  const long cap = h->stats_rows > 0 ? h->stats_rows : own ? (long)h->num_cu * per_cu : std::max<long>(1, (long)h->num_cu * 3 * 256 / st.threads);
   const long upw = std::max<long>(1, (nunits + cap * wpr - 1) / (cap * wpr));        // units per wave
   const int gx = (int)std::max<long>(1, (nunits + upw * wpr - 1) / (upw * wpr));
   HIPCHK(pbuf.ensure((size_t)gx * st.row));
@@ -1102,7 +1103,10 @@ GibbsGeom choose_gibbs_geometry(const ModelShape& ms, int Lf, int B, int num_cu,
     // (config #5: 158 us per launch with three 256-thread blocks of 3 chains per CU, 145 with two 512-thread
     // blocks of 8, 143.6 with one 1024-thread block of 16 -- 147 when the queue overflows at 62 entries).
     const bool big_ok = solo ? true : (!ms.FUSE_STATS && best_occupancy <= 0.5);
-    if (threads > 256 && (!big_ok || env_int("CRBM_GIBBS_MAX_THREADS", 1024) < threads)) continue;
+    // (experiment: CRBM_FUSED_THREADS=512 with CRBM_JIT_DEFINES=-DCRBM_FUSED_TB=512 gives the fused training launch larger blocks)
+    const int fusedT = (!solo && ms.FUSE_STATS) ? env_int("CRBM_FUSED_THREADS", 0) : 0;
+    if (fusedT > 0 && threads != fusedT) continue;
+    if (fusedT == 0 && threads > 256 && (!big_ok || env_int("CRBM_GIBBS_MAX_THREADS", 1024) < threads)) continue;
     if (forceT > 0 && threads != forceT) continue;
     for (int S = 1; S <= std::min(B, 64); ++S) {
       if (forceS > 0 && S != forceS) continue;

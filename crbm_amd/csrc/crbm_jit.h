@@ -85,6 +85,7 @@ inline std::string jit_stub(int K, int M, int DS, int G, int GS, int POOL, int g
            "#ifndef CRBM_GIBBS_ATTR\n#define CRBM_GIBBS_ATTR %s\n#endif\n"
            "#ifndef CRBM_GIBBS_STATS_ATTR\n#define CRBM_GIBBS_STATS_ATTR %s\n#endif\n"
            "#ifndef CRBM_STATS_BYTE_LUT\n#define CRBM_STATS_BYTE_LUT true\n#endif\n"
+           "#ifndef CRBM_FUSED_TB\n#define CRBM_FUSED_TB 256\n#endif\n"
            "using ModelCfg = crbm::Cfg<%d, %d, %d, %d, %d>;\n"
            "using SoloCfg = crbm::Cfg<%d, %d, %d, %d, %d>;\n"
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_build_tables(crbm::TablesArgs a) { crbm::build_tables_body<ModelCfg>(a); }\n"
@@ -93,8 +94,8 @@ inline std::string jit_stub(int K, int M, int DS, int G, int GS, int POOL, int g
            "extern \"C\" __global__ void __launch_bounds__(1024) crbm_update_tables_ipc(crbm::UpdateIpcArgs a) { crbm::update_tables_ipc_body<ModelCfg>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_hgv(crbm::HgvArgs a) { crbm::hgv_body<ModelCfg>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(%d) CRBM_GIBBS_ATTR crbm_gibbs_sparse(crbm::GibbsArgs a) { crbm::gibbs_body<SoloCfg, true>(a); }\n"
-           "extern \"C\" __global__ void __launch_bounds__(256) CRBM_GIBBS_STATS_ATTR crbm_gibbs_sparse_stats(crbm::GibbsArgs a) { if constexpr (ModelCfg::FUSE_STATS) crbm::gibbs_body<ModelCfg, true, true>(a); }\n"
-           "extern \"C\" __global__ void __launch_bounds__(256) CRBM_GIBBS_STATS_ATTR crbm_train_local(crbm::TrainLocalArgs a) { crbm::train_local_body<ModelCfg>(a); }\n"
+           "extern \"C\" __global__ void __launch_bounds__(CRBM_FUSED_TB) CRBM_GIBBS_STATS_ATTR crbm_gibbs_sparse_stats(crbm::GibbsArgs a) { if constexpr (ModelCfg::FUSE_STATS) crbm::gibbs_body<ModelCfg, true, true>(a); }\n"
+           "extern \"C\" __global__ void __launch_bounds__(CRBM_FUSED_TB) CRBM_GIBBS_STATS_ATTR crbm_train_local(crbm::TrainLocalArgs a) { crbm::train_local_body<ModelCfg>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(%d) crbm_gibbs(crbm::GibbsArgs a) { if constexpr (ModelCfg::DENSE) crbm::gibbs_body<ModelCfg, ModelCfg::DENSE ? false : true>(a); }\n"
            "using RoleData = crbm::StatsRole<ModelCfg, true>;\nusing RoleModel = crbm::StatsRole<ModelCfg, false>;\n"
            "extern \"C\" __global__ void __launch_bounds__(RoleData::THREADS) crbm_stats_mfma_data(crbm::StatsMfmaArgs a) { crbm::stats_mfma_body<ModelCfg, true, CRBM_STATS_BYTE_LUT>(a); }\n"
