@@ -33,9 +33,29 @@ def emu_env():
     return env
 
 
-@pytest.mark.parametrize("which", ["encode_pack", "hgv", "vgh", "gibbs", "stats_mfma", "train_step", "two_ranks", "pooling",
-                                   "free_energy", "hit_summary", "large_models", "big"])
-def test_kernels_on_cpu_threads_with_sanitizers(emu_env, which):
-    r = subprocess.run([sys.executable, os.path.join(EMU, "run_emu.py"), which], env=emu_env,
-                       capture_output=True, text=True, timeout=1500)
+CASES = ["encode_pack", "hgv", "vgh", "gibbs", "stats_mfma", "train_step", "two_ranks", "pooling",
+         "free_energy", "hit_summary", "large_models", "big"]
+
+
+@pytest.fixture(scope="module")
+def emu_runs(emu_env):
+    """All harness cases, four at a time (each is a process full of mostly sleeping threads: the kernels' GPU threads
+    are OS threads here); the tests below each look at one result."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    def run(which):
+        try:
+            return subprocess.run([sys.executable, os.path.join(EMU, "run_emu.py"), which], env=emu_env,
+                                  capture_output=True, text=True, timeout=1500)
+        except subprocess.TimeoutExpired as e:
+            return e
+    order = sorted(CASES, key=lambda w: {"big": 0, "large_models": 1, "hit_summary": 2}.get(w, 3))   # longest first
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        return dict(zip(order, ex.map(run, order)))
+
+
+@pytest.mark.parametrize("which", CASES)
+def test_kernels_on_cpu_threads_with_sanitizers(emu_runs, which):
+    r = emu_runs[which]
+    assert not isinstance(r, subprocess.TimeoutExpired), "emulator case %s timed out" % which
     assert r.returncode == 0 and "EMU ALL OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

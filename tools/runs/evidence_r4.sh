@@ -13,6 +13,11 @@ for cfg in cfg4 cfg5; do
   timeout -k 10 300 python bench.py --config $cfg --steps 1000 --warmup 100 --no-cpu-baseline > $O/bench_${cfg}.json 2> $O/bench_${cfg}.err; echo "bench $cfg rc=$?"
 done
 timeout -k 10 200 python3 tools/ramp_probe.py cfg2 > $O/ramp_probe.txt 2>&1
+python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"
+timeout -k 10 200 python tools/bench_fit.py cfg2 40 > $O/fit_cfg2.txt 2>&1; echo "fit rc=$?"; tail -5 $O/fit_cfg2.txt
+timeout -k 10 200 python tools/bench_sweep.py > $O/sweep_1M_cfg2model.json 2>&1; echo "sweep rc=$?"
+CRBM_GIBBS_TIMELINE=1 timeout -k 10 200 python3 bench.py --steps 20 --warmup 5 --no-pmc --no-cpu-baseline --no-train --no-other-configs > $O/timeline_20.json 2> $O/timeline_20.txt
+bash tools/runs/r4_rehearse.sh > $O/rehearse.txt 2>&1; cp gpurun_out/r4_rehearse/*.json $O/ 2>/dev/null
 KS=0,1,2,4,16 timeout -k 10 120 python tools/gibbs_k_scan.py cfg2 > $O/gibbs_steps_per_launch_scan.txt 2>&1
 cd /tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-pmc --no-other-configs > $O/bench_cfg2_under_rocprof.json 2> $O/bench_cfg2_under_rocprof.err; echo "prof rc=$?"
