@@ -36,6 +36,16 @@ cp("bench_cfg5_4rank_one_gpu_rehearsal.json", "bench_cfg5_4rank_one_gpu_rehearsa
 cp("floor_scan.txt", "gibbs_launch_floor_scan.txt")
 cp("lds_conflict_phases.txt", "stats_lds_conflicts_by_phase.txt")
 cp("trace_train.txt", "train_step_kernel_trace.txt")
+# round 4
+cp("ramp_probe.txt", "ramp_probe.txt")
+cp("fit_cfg2.txt", "fit_cfg2.txt")
+cp("sweep_1M_cfg2model.json", "sweep_1M_cfg2model.json")
+cp("smoke.log", "smoke.log")
+cp("timeline_20.txt", "chain_launch_timeline_20_steps.txt")
+cp("bench_2rank.json", "bench_cfg2_2rank_one_gpu_rehearsal.json")
+cp("bench_6rank.json", "bench_cfg2_6rank_one_gpu_rehearsal.json")
+cp("bench_cfg5_4rank.json", "bench_cfg5_4rank_one_gpu_rehearsal.json")
+cp("bench_2rank_torchrun.json", "bench_cfg2_2rank_torchrun_one_gpu_rehearsal.json")
 
 # Counters of the chain kernel per config (what bench.py quotes when it cannot collect them itself): mean per launch
 # of every counter of the passes of tools/prof_gibbs.py (FETCH_SIZE and WRITE_SIZE in passes of their own)
@@ -53,8 +63,15 @@ for cfg in ("cfg2", "cfg4", "cfg5"):
                 ids = ids[len(ids) // 4:]
                 vals[name] = sum(acc[name][i] for i in ids) / len(ids)
     if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+        parts = 1
+        try:      # partitions of a chain launch at this config: the counters are per LAUNCH (one partition)
+            line = json.loads(open(os.path.join(src, "bench_%s.json" % cfg)).read().strip().splitlines()[-1])
+            parts = int(line["launch"].get("chain_parts", 1))
+        except Exception:
+            pass
         out[cfg] = {
             "counters": vals,
+            "chain_parts": parts,
             "hbm_bytes_per_launch": int((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024),
             "correction": "gfx950 FETCH_SIZE reports 1/2 of a wide coalesced streaming read (MI355X_MICROARCH.md, HBM): doubled",
             "source": "rocprofv3 --pmc passes of python3 tools/prof_gibbs.py %s on another box (tools/runs/evidence.sh; "
