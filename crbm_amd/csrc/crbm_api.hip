@@ -1168,6 +1168,10 @@ PartPlan plan_chain_parts(const ModelShape& ms, int Lf, int B, int num_cu) {
   if (tiles_part < 1) return one;
   PartPlan p{parts, tiles_part * g.S, g};
   p.geom.grid = std::min(tiles_part, num_cu * blocks_cu);
+  // (Measured and NOT adopted: twice the chains per tile where the partition's tiles do not divide over its resident blocks
+  //  -- config #5: 2048 tiles of 2 chains on 768 blocks.  Forced for every kernel of the handle, CRBM_GIBBS_S=4, it runs
+  //  128.6 instead of 135.2 us per step; chosen here for the partitioned launch alone 150.7: the kernel is compiled with the
+  //  occupancy hint of the handle's regular geometry, three blocks per CU, and the larger tiles leave two.)
   return p;
 }
 
