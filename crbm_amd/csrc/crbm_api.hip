@@ -298,9 +298,11 @@ int big_launch_hgv(crbm_handle* h, const uint32_t* d_letters, int n, int L, int 
   a.m = big_model(h);
   a.letters = d_letters;
   a.n = n; a.L = L; a.Lh = L - h->M + 1; a.LW = letter_words(L);
-  int ks = 32;                                               // motifs per staged slab: a divisor of 32 whose filters fit 96 KB
-  while (ks > 1 && (size_t)ks * h->M * 16 > 96 * 1024) ks >>= 1;
+  const int pool = h->ms.POOL;
+  int ks = pool > 1 ? 8 : 32;                                // motifs per staged slab: a divisor of 32 whose filters fit 96 KB
+  while (ks > 1 && (size_t)ks * h->M * 16 > 96 * 1024) ks >>= 1;   // (pooled: at most 8, the capacity of big_hgv_pooled_kernel)
   a.KS = ks;
+  a.pool = pool;
   // rows per tile: enough tiles to cover the chip a few times over (every tile stages the filters once per slab), at most
   // what the LDS takes of packed letters and ~4096 positions
   a.TS = std::max(1, std::min(std::min((n + 4 * h->num_cu - 1) / (4 * h->num_cu), (32 * 1024) / (a.LW * 4)), std::max(1, 4096 / a.Lh)));
@@ -311,7 +313,8 @@ int big_launch_hgv(crbm_handle* h, const uint32_t* d_letters, int n, int L, int 
   const size_t lds = ((size_t)ks * h->M * 4 + 32) * 4 + (size_t)a.TS * a.LW * 4;
   ARGCHK(lds <= 160 * 1024, "motif_length too large for the h|v kernel");
   const int ntiles = (n + a.TS - 1) / a.TS;
-  hipLaunchKernelGGL(big_hgv_kernel, dim3(std::max(1, std::min(ntiles, h->num_cu * 8))), dim3(256), lds, st, a);
+  if (pool > 1) hipLaunchKernelGGL(big_hgv_pooled_kernel, dim3(std::max(1, std::min(ntiles, h->num_cu * 8))), dim3(256), lds, st, a);
+  else hipLaunchKernelGGL(big_hgv_kernel, dim3(std::max(1, std::min(ntiles, h->num_cu * 8))), dim3(256), lds, st, a);
   HIPCHK(hipGetLastError());
   return CRBM_OK;
 }
@@ -351,14 +354,16 @@ int big_launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bo
   a.n = n; a.L = L; a.Lh = L - M + 1; a.LW = letter_words(L);
   a.want_sparsity = data_half ? 1 : 0;
   a.R = std::max(1, std::min(n, std::max(1, (h->num_cu * 8) / K)));
+  a.pool = h->ms.POOL;
   a.CH = std::max(64, std::min(4096, a.Lh));
+  a.CH = std::max(a.pool, a.CH - a.CH % a.pool);            // chunks start on pooling-group boundaries
   a.row = 3 * KAM + 3 * K + 4;
   a.off_vh0 = 0; a.off_vh1 = KAM; a.off_h0 = 2 * KAM; a.off_h1 = 2 * KAM + K;
   a.off_sw = 2 * KAM + 2 * K; a.off_sb = 3 * KAM + 2 * K; a.off_v = 3 * KAM + 3 * K;
   HIPCHK(pbuf.ensure((size_t)a.R * a.row));
   a.partials = pbuf.p;
   ARGCHK(4 * M <= BIG_ST * 256, "motif_length too large for the statistics kernel");
-  const size_t lds = (((size_t)4 * M + 3) & ~(size_t)3) * 4 + (size_t)3 * a.CH * 4 + 64 + (size_t)a.CH + M;
+  const size_t lds = (((size_t)4 * M + 3) & ~(size_t)3) * 4 + (size_t)(a.pool > 1 ? 5 : 3) * a.CH * 4 + 64 + (size_t)a.CH + M;
   ARGCHK(lds <= 160 * 1024, "motif_length too large for the statistics kernel");
   hipLaunchKernelGGL(big_stats_kernel, dim3(K, a.R), dim3(256), lds, st, a);
   HIPCHK(hipGetLastError());
@@ -384,7 +389,7 @@ int big_launch_eval(crbm_handle* h, const uint32_t* rows, int n, int L, int hits
   a.m = big_model(h);
   a.letters = rows;
   a.n = n; a.L = L; a.Lh = L - h->M + 1; a.LW = letter_words(L);
-  a.fe = fe; a.fem = fem; a.hmax = hmax; a.hmean = hmean; a.pos_fx = pos_fx; a.hits = hits;
+  a.fe = fe; a.fem = fem; a.hmax = hmax; a.hmean = hmean; a.pos_fx = pos_fx; a.hits = hits; a.pool = h->ms.POOL;
   const size_t lds = (((size_t)4 * h->M + 3) & ~(size_t)3) * 4 + 64 + (size_t)L;
   ARGCHK(lds <= 160 * 1024, "sequence too long for the evaluation kernel of a model of this size");
   hipLaunchKernelGGL(big_eval_kernel, dim3(std::max(1, std::min(n, h->num_cu * 8))), dim3(256), lds, st, a);
@@ -1178,9 +1183,9 @@ PartPlan plan_chain_parts(const ModelShape& ms, int Lf, int B, int num_cu) {
 // Does the model need the generic ("big") kernels?  Beyond 256 motifs or 64 letters the specialised templates do not
 // exist; within them the LDS decides: the chain kernel holds its tables and at least one chain, the statistics kernel a
 // column image per 16 motifs beside the gather table (at most 16 roles of 64 threads).  CRBM_FORCE_BIG=1 puts any
-// (unpooled) model on the generic path -- the tests compare the two paths on the same model with it.
+// model on the generic path -- the tests compare the two paths on the same model with it.
 bool model_needs_big(const ModelShape& ms, int Lf, int B, int num_cu) {
-  if (env_int("CRBM_FORCE_BIG", 0) && ms.POOL == 1) return true;
+  if (env_int("CRBM_FORCE_BIG", 0)) return true;
   if (ms.K > MAX_MOTIFS || ms.M > MAX_MOTIF_LENGTH) return true;
   if (choose_gibbs_geometry(ms, Lf, B, num_cu, true).lds <= 0) return true;
   for (int want_sp = 0; want_sp <= 1; ++want_sp) {
@@ -1278,11 +1283,6 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
     (void)hipGetLastError();
   }
   hh->big = (hh->K > MAX_MOTIFS || hh->M > MAX_MOTIF_LENGTH) ? true : model_needs_big(hh->ms, hh->Lf, hh->B, hh->num_cu);
-  if (hh->big && cfg->pooling > 1) {
-    g_create_error = "pooling > 1 needs a model that fits the LDS-resident kernels (at most 256 motifs of at most 64 letters whose "
-                     "tables and one chain fit 160 KB): this one is served by the generic kernels, which do not pool";
-    return bail(CRBM_ERR_INVALID);
-  }
   if (hh->big) {
     // no specialised kernels, no table images: the state layout is the same (K-bit masks, 2-bit letters)
     hh->gl = GibbsLayout();

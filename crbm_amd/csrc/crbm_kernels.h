@@ -2483,8 +2483,7 @@ __global__ void __launch_bounds__(256) vgh_dense_kernel(VghArgs a) {
 // run-time K and M, compiled ahead of time: the filters are staged through LDS a slab of motifs (or one motif) at a
 // time, hidden masks are walked word by word, everything else follows the same formulas, the same bit-packed state
 // (K-bit masks, 2-bit letters) and the same Philox counters as the specialised kernels, so a model may cross the
-// boundary between the two paths without its samples changing beyond p == u ties.  Pooling stays with the
-// specialised kernels (the reference calls it "not relevant for cRBM").
+// boundary between the two paths without its samples changing beyond p == u ties (pooled models included).
 // ===========================================================================
 struct BigModel {
   const float* W;   // (K,4,M)
@@ -2524,6 +2523,7 @@ struct BigHgvArgs {
   const uint32_t* letters;
   int32_t n, L, Lh, LW;
   int32_t TS, KS;
+  int32_t pool;                // pooling (1: independent units; > 1: big_hgv_pooled_kernel, KS <= 8)
   int32_t mode;                // 0: forward strand, 1: reverse-complement strand, 2: sigma(x + x')
   float* act;                  // (n,K,1,Lh) each, may be null
   float* prob;
@@ -2534,7 +2534,12 @@ struct BigHgvArgs {
   uint32_t kind;
 };
 
-__global__ void __launch_bounds__(256) big_hgv_kernel(BigHgvArgs a) {
+// KSM: slab capacity of the register arrays (32 unpooled; 8 pooled, which keeps five arrays per unit).
+// POOLED: the units of `pool` consecutive positions compete (convRBM.py:245-267): P_i = exp(x_i) / (pool + sum_j exp(x_j)),
+// one draw per group -- the uniform of its first position -- against the cumulative probabilities; a thread evaluates its
+// whole group itself (two passes over the group's activations: maximum, then sums), like the specialised kernels do.
+template <int KSM, bool POOLED>
+__device__ __forceinline__ void big_hgv_body(const BigHgvArgs& a) {
   HIP_DYNAMIC_SHARED(float, smem);
   const int K = a.m.K, M = a.m.M, KS = a.KS;
   float* Ws = smem;                                            // [KS][M][4]
@@ -2561,44 +2566,82 @@ __global__ void __launch_bounds__(256) big_hgv_kernel(BigHgvArgs a) {
       for (int it = threadIdx.x; it < items; it += blockDim.x) {
         const int nl = it / a.Lh, s = it - nl * a.Lh, nn = n0 + nl;
         const uint32_t* lrow = let + (size_t)nl * a.LW;
-        float x[32];
+        // x[k] = b[k] + sum_j W[k, l(pos+j), j]; rc strand: W[k, 3 - l(pos+j), M-1-j] (convRBM.py:241); mode 2: both, each with b
+        auto activations = [&](int pos, float (&x)[KSM]) {
 #pragma unroll
-        for (int k = 0; k < 32; ++k) x[k] = 0.f;
-        // x[k] = b[k] + sum_j W[k, l(s+j), j]; rc strand: W[k, 3 - l(s+j), M-1-j] (convRBM.py:241); mode 2: both, each with b
-        for (int pass = 0; pass < (a.mode == 2 ? 2 : 1); ++pass) {
-          const bool rc = a.mode == 1 || pass == 1;
-          for (int j = 0; j < M; ++j) {
-            const uint32_t l = letter_at(lrow, s + j);
-            const float* col = Ws + (size_t)((rc ? M - 1 - j : j) * 4 + (rc ? 3u - l : l));
+          for (int k = 0; k < KSM; ++k) x[k] = 0.f;
+          for (int pass = 0; pass < (a.mode == 2 ? 2 : 1); ++pass) {
+            const bool rc = a.mode == 1 || pass == 1;
+            for (int j = 0; j < M; ++j) {
+              const uint32_t l = letter_at(lrow, pos + j);
+              const float* col = Ws + (size_t)((rc ? M - 1 - j : j) * 4 + (rc ? 3u - l : l));
 #pragma unroll
-            for (int k = 0; k < 32; ++k)
-              if (k < kc) x[k] += col[(size_t)k * M * 4];
+              for (int k = 0; k < KSM; ++k)
+                if (k < kc) x[k] += col[(size_t)k * M * 4];
+            }
+#pragma unroll
+            for (int k = 0; k < KSM; ++k)
+              if (k < kc) x[k] += bs[k];
+          }
+        };
+        float x[KSM], p[KSM], cb[KSM];
+        int su = s;                                  // position whose uniform decides (the group's first when pooled)
+        if constexpr (POOLED) {
+          const int g0 = s - s % a.pool, me = s - g0;
+          su = g0;
+          float mx[KSM], den[KSM], xt[KSM];
+#pragma unroll
+          for (int k = 0; k < KSM; ++k) mx[k] = 0.f;                 // the "pool" term is pool * exp(0)
+          for (int j = 0; j < a.pool; ++j) {
+            activations(g0 + j, xt);
+#pragma unroll
+            for (int k = 0; k < KSM; ++k) mx[k] = fmaxf(mx[k], xt[k]);
           }
 #pragma unroll
-          for (int k = 0; k < 32; ++k)
-            if (k < kc) x[k] += bs[k];
+          for (int k = 0; k < KSM; ++k) { den[k] = (float)a.pool * __expf(-mx[k]); cb[k] = 0.f; p[k] = 0.f; x[k] = 0.f; }
+          for (int j = 0; j < a.pool; ++j) {
+            activations(g0 + j, xt);
+#pragma unroll
+            for (int k = 0; k < KSM; ++k) {
+              const float e = __expf(xt[k] - mx[k]);
+              den[k] += e;
+              cb[k] += j < me ? e : 0.f;
+              p[k] = j == me ? e : p[k];
+              x[k] = j == me ? xt[k] : x[k];
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < KSM; ++k) {
+            const float inv = 1.0f / den[k];
+            p[k] *= inv;
+            cb[k] *= inv;
+          }
+        } else {
+          activations(s, x);
+#pragma unroll
+          for (int k = 0; k < KSM; ++k) { p[k] = sigmoid_x(x[k]); cb[k] = 0.f; }
         }
         uint32_t bits = 0u;
         uint32_t last_g = 0xFFFFFFFFu;
         Philox4 rcs = {}, rfs = {};
         const uint32_t gn = a.rng.seq_offset + (uint32_t)nn;
 #pragma unroll
-        for (int k = 0; k < 32; ++k) {
+        for (int k = 0; k < KSM; ++k) {
           if (k < kc) {
             const int gk = k0 + k;
-            const float p = sigmoid_x(x[k]);
             const size_t idx = ((size_t)nn * K + gk) * a.Lh + s;
             if (a.act) a.act[idx] = x[k];
-            if (a.prob) a.prob[idx] = p;
+            if (a.prob) a.prob[idx] = p[k];
             if (want_sample) {
               const uint32_t g = (uint32_t)gk / 10u, i10 = (uint32_t)gk - 10u * g;
               if (g != last_g) {
-                rcs = philox4x32(gn, (uint32_t)s, rng_word2(a.kind, strand, 0, g), a.rng.step, a.rng.seed_lo, a.rng.seed_hi);
-                rfs = philox4x32(gn, (uint32_t)s, rng_word2(a.kind, strand, 1, g), a.rng.step, a.rng.seed_lo, a.rng.seed_hi);
+                rcs = philox4x32(gn, (uint32_t)su, rng_word2(a.kind, strand, 0, g), a.rng.step, a.rng.seed_lo, a.rng.seed_hi);
+                rfs = philox4x32(gn, (uint32_t)su, rng_word2(a.kind, strand, 1, g), a.rng.step, a.rng.seed_lo, a.rng.seed_hi);
                 last_g = g;
               }
               const float u = (float)(philox_field12_dyn(rcs, (int)i10) * 4096u + philox_field12_dyn(rfs, (int)i10)) * 5.9604644775390625e-8f;
-              const uint32_t hb = p > u ? 1u : 0u;
+              // unpooled: h = 1 if p > u; pooled: the first unit of the group whose cumulative probability exceeds u
+              const uint32_t hb = POOLED ? ((cb[k] + p[k] > u && cb[k] <= u) ? 1u : 0u) : (p[k] > u ? 1u : 0u);
               if (a.sample) a.sample[idx] = (float)hb;
               bits |= hb << (gk & 31);
               cnt += hb;
@@ -2614,6 +2657,9 @@ __global__ void __launch_bounds__(256) big_hgv_kernel(BigHgvArgs a) {
   }
   if (a.ones && cnt) atomicAdd(a.ones, cnt);
 }
+
+__global__ void __launch_bounds__(256) big_hgv_kernel(BigHgvArgs a) { big_hgv_body<32, false>(a); }
+__global__ void __launch_bounds__(256) big_hgv_pooled_kernel(BigHgvArgs a) { big_hgv_body<8, true>(a); }
 
 // ---- v | h of the chain from the masks (convRBM.py:277-325): y[a,p] = c[a] + sum_k sum_j W[k,a,j] h[k,p-j] (+ rc strand),
 // softmax over the four letters, one categorical draw per position.  One block per chain; a thread owns up to BIG_VR
@@ -2713,6 +2759,7 @@ struct BigStatsArgs {
   const uint32_t* letters;
   int32_t n, L, Lh, LW;
   int32_t want_sparsity, R, CH;
+  int32_t pool;                                             // pooling (CH is a multiple of it)
   float* partials;                                          // [R][row]
   int32_t row, off_vh0, off_vh1, off_h0, off_h1, off_sw, off_sb, off_v;
 };
@@ -2724,7 +2771,9 @@ __global__ void __launch_bounds__(256) big_stats_kernel(BigStatsArgs a) {
   float* P = Wk + ((AM + 3) & ~3);                          // [CH] each
   float* Pp = P + CH;
   float* Q = Pp + CH;
-  float* xch = Q + CH;                                      // [16]
+  float* X = Q + CH;                                        // [CH] each: activations of the chunk (pooled models only)
+  float* Xp = X + (a.pool > 1 ? CH : 0);
+  float* xch = Xp + (a.pool > 1 ? CH : 0);                  // [16]
   unsigned char* lb = reinterpret_cast<unsigned char*>(xch + 16);   // [CH + M]
   for (int i = threadIdx.x; i < AM; i += blockDim.x) Wk[i] = a.m.W[(size_t)k * AM + i];
   const float bk = a.m.b[k];
@@ -2751,11 +2800,34 @@ __global__ void __launch_bounds__(256) big_stats_kernel(BigStatsArgs a) {
           x += Wk[l * M + j];
           if (a.m.ds) xr += Wk[(3 - l) * M + (M - 1 - j)];
         }
+        if (a.pool > 1) { X[s] = x; Xp[s] = xr; continue; }
         const float p = sigmoid_x(x), pp = a.m.ds ? sigmoid_x(xr) : 0.f, q = a.want_sparsity ? p * (1.0f - p) : 0.f;
         P[s] = p; Pp[s] = pp; Q[s] = q;
         hsum += p; hpsum += pp; qsum += q;
       }
       __syncthreads();
+      if (a.pool > 1) {
+        // pooled units (convRBM.py:245-257): P_s = exp(x_s) / (pool + sum_group exp(x_j)); the sparsity slope is
+        // P_s (1 - sum of the group's P).  Chunks start on group boundaries.
+        for (int s = threadIdx.x; s < cl; s += blockDim.x) {
+          const int g0 = s - s % a.pool;
+          float p2[2] = {0.f, 0.f}, S2[2] = {0.f, 0.f};
+          for (int st = 0; st <= (a.m.ds ? 1 : 0); ++st) {
+            const float* xs = st ? Xp : X;
+            float mx = 0.f;
+            for (int j = 0; j < a.pool; ++j) mx = fmaxf(mx, xs[g0 + j]);
+            const float base = (float)a.pool * __expf(-mx);
+            float den = base;
+            for (int j = 0; j < a.pool; ++j) den += __expf(xs[g0 + j] - mx);
+            p2[st] = __expf(xs[s] - mx) / den;
+            S2[st] = (den - base) / den;
+          }
+          const float q = a.want_sparsity ? p2[0] * (1.0f - S2[0]) : 0.f;
+          P[s] = p2[0]; Pp[s] = p2[1]; Q[s] = q;
+          hsum += p2[0]; hpsum += p2[1]; qsum += q;
+        }
+        __syncthreads();
+      }
 #pragma unroll
       for (int t = 0; t < BIG_ST; ++t) {
         const int e = (int)threadIdx.x + t * (int)blockDim.x;
@@ -2858,6 +2930,7 @@ struct BigEvalArgs {
   float* hmean;                    // (n,K) hit mode: mean over positions
   unsigned long long* pos_fx;      // (K,Lh) hit mode: fixed-point sums over sequences (HIT_FX units), may be null
   int32_t hits;                    // 0: free energy, 1: hit summaries
+  int32_t pool;                    // pooling: the units of `pool` consecutive positions compete
 };
 
 __global__ void __launch_bounds__(256) big_eval_kernel(BigEvalArgs a) {
@@ -2883,13 +2956,49 @@ __global__ void __launch_bounds__(256) big_eval_kernel(BigEvalArgs a) {
       __syncthreads();
       const float bk = a.m.b[k];
       float part = 0.f, mx = 0.f;
-      for (int s = threadIdx.x; s < a.Lh; s += blockDim.x) {
-        float x = bk, xr = bk;
+      auto act = [&](int s, float& x, float& xr) {
+        x = bk; xr = bk;
         for (int j = 0; j < M; ++j) {
           const int l = lb[s + j];
           x += Wk[l * M + j];
           xr += Wk[(3 - l) * M + (M - 1 - j)];
         }
+      };
+      if (a.pool > 1) {
+        // a thread takes whole pooling groups: log(1 + sum_j exp(x_j)) per group (free energy, convRBM.py:664-665) or the
+        // pooled probabilities exp(x_j) / (pool + sum exp) (hits), in two passes over the group's activations
+        for (int g0 = (int)threadIdx.x * a.pool; g0 < a.Lh; g0 += (int)blockDim.x * a.pool) {
+          float m0 = 0.f, m1 = 0.f, x, xr;
+          for (int j = 0; j < a.pool; ++j) {
+            act(g0 + j, x, xr);
+            const float z = a.hits && !a.m.ds ? x + xr : x;
+            m0 = fmaxf(m0, z);
+            m1 = fmaxf(m1, xr);
+          }
+          float d0 = 0.f, d1 = 0.f;
+          for (int j = 0; j < a.pool; ++j) {
+            act(g0 + j, x, xr);
+            d0 += __expf((a.hits && !a.m.ds ? x + xr : x) - m0);
+            d1 += __expf(xr - m1);
+          }
+          if (a.hits) {
+            const float den = d0 + (float)a.pool * __expf(-m0);
+            for (int j = 0; j < a.pool; ++j) {
+              act(g0 + j, x, xr);
+              const float p = __expf((a.m.ds ? x : x + xr) - m0) / den;
+              part += p;
+              mx = fmaxf(mx, p);
+              if (a.pos_fx) atomicAdd(a.pos_fx + (size_t)k * a.Lh + g0 + j, to_fx(p));
+            }
+          } else {
+            part += m0 + __logf(d0 + __expf(-m0));
+            if (a.m.ds) part += m1 + __logf(d1 + __expf(-m1));
+          }
+        }
+      } else
+      for (int s = threadIdx.x; s < a.Lh; s += blockDim.x) {
+        float x, xr;
+        act(s, x, xr);
         if (a.hits) {
           // convRBM.py:507-514: doublestranded -> sigma(x); single-stranded -> sigma(x + x')
           const float p = sigmoid_x(a.m.ds ? x : x + xr);

@@ -442,21 +442,27 @@ static BigModel big_model_of(const float* W, const float* b, const float* c, int
 
 int emu_big_hgv(const float* W, const float* b, const float* c, int K, int M, int ds, const uint32_t* letters, int n, int L,
                 int mode, float* act, float* prob, float* sample, unsigned long long* ones, uint32_t* masks, uint64_t seed,
-                uint32_t step, uint32_t off, uint32_t kind, int TS, int KS, int grid, int threads) {
+                uint32_t step, uint32_t off, uint32_t kind, int TS, int KS, int grid, int threads, int pool) {
   BigHgvArgs a;
   a.m = big_model_of(W, b, c, K, M, ds);
+  a.pool = pool;
   a.letters = letters; a.n = n; a.L = L; a.Lh = L - M + 1; a.LW = letter_words(L);
   a.TS = TS; a.KS = KS; a.mode = mode;
   a.act = act; a.prob = prob; a.sample = sample; a.ones = ones; a.masks = masks;
   a.rng = make_rng(seed, step, off); a.kind = kind;
-  emu::launch([&] { big_hgv_kernel(a); }, dim3(grid), dim3(threads), ((size_t)KS * M * 4 + 32) * 4 + (size_t)TS * a.LW * 4);
+  const size_t lds = ((size_t)KS * M * 4 + 32) * 4 + (size_t)TS * a.LW * 4;
+  if (pool > 1) {
+    if (KS > 8) return -2;
+    emu::launch([&] { big_hgv_pooled_kernel(a); }, dim3(grid), dim3(threads), lds);
+  } else
+    emu::launch([&] { big_hgv_kernel(a); }, dim3(grid), dim3(threads), lds);
   return 0;
 }
 
 // one Gibbs step: v | h from the masks, then h | v per strand into the masks; returns the letter words per row of vout
 int emu_big_gibbs_step(const float* W, const float* b, const float* c, int K, int M, int ds, uint32_t* hm, uint32_t* hmp,
                        uint32_t* vout, int nchains, int Lf, uint64_t seed, uint32_t step, uint32_t off, int JS, int KS,
-                       int grid, int threads) {
+                       int grid, int threads, int pool) {
   const int Lv = Lf + M - 1, LWs = letter_words(Lv);
   if (!vout) return LWs;
   BigVghArgs v;
@@ -467,25 +473,26 @@ int emu_big_gibbs_step(const float* W, const float* b, const float* c, int K, in
   emu::launch([&] { big_vgh_kernel(v); }, dim3(grid), dim3(threads), (size_t)JS * 32 * 16 + (size_t)BIG_VR * threads);
   for (int strand = 0; strand <= ds; ++strand)
     emu_big_hgv(W, b, c, K, M, ds, vout, nchains, Lv, strand, nullptr, nullptr, nullptr, nullptr, strand ? hmp : hm, seed, step, off,
-                KIND_CHAIN_H, 2, KS, grid, threads);
+                KIND_CHAIN_H, 2, KS, grid, threads, pool);
   return LWs;
 }
 
 // raw sums of one half: partial rows through big_stats_kernel, then the host column reduce of the harness
 int emu_big_stats(const float* W, const float* b, const float* c, int K, int M, int ds, const uint32_t* letters, int n, int L,
-                  int LW, int want_sparsity, int R, int CH, int threads, float* sums, int skip_begin, int skip_len) {
+                  int LW, int want_sparsity, int R, int CH, int threads, float* sums, int skip_begin, int skip_len, int pool) {
   const int KAM = K * 4 * M, row = 3 * KAM + 3 * K + 4;
   std::vector<float> partials((size_t)R * row, -777.0f);      // what a launch does not write must not be read
   BigStatsArgs a;
   a.m = big_model_of(W, b, c, K, M, ds);
   a.letters = letters; a.n = n; a.L = L; a.Lh = L - M + 1; a.LW = LW;
-  a.want_sparsity = want_sparsity; a.R = R; a.CH = CH;
+  a.want_sparsity = want_sparsity; a.R = R; a.CH = CH; a.pool = pool;
+  if (CH % pool != 0) return -3;
   a.partials = partials.data();
   a.row = row; a.off_vh0 = 0; a.off_vh1 = KAM; a.off_h0 = 2 * KAM; a.off_h1 = 2 * KAM + K;
   a.off_sw = 2 * KAM + 2 * K; a.off_sb = 3 * KAM + 2 * K; a.off_v = 3 * KAM + 3 * K;
   if (4 * M > BIG_ST * threads) return -2;
   emu::launch([&] { big_stats_kernel(a); }, dim3(K, R), dim3(threads),
-              (((size_t)4 * M + 3) & ~(size_t)3) * 4 + (size_t)3 * CH * 4 + 64 + (size_t)CH + M);
+              (((size_t)4 * M + 3) & ~(size_t)3) * 4 + (size_t)(pool > 1 ? 5 : 3) * CH * 4 + 64 + (size_t)CH + M);
   host_reduce(partials.data(), R, row, K, KAM, ds, want_sparsity, skip_begin, skip_len, (float)n, sums);
   return row;
 }
@@ -500,8 +507,9 @@ int emu_big_update(const float* sums, float* W, float* b, float* c, float* vW, f
 }
 
 int emu_big_eval(const float* W, const float* b, const float* c, int K, int M, int ds, const uint32_t* letters, int n, int L,
-                 int hits, float* fe, float* fem, float* hmax, float* hmean, float* pos, int grid, int threads) {
+                 int hits, float* fe, float* fem, float* hmax, float* hmean, float* pos, int grid, int threads, int pool) {
   BigEvalArgs a;
+  a.pool = pool;
   a.m = big_model_of(W, b, c, K, M, ds);
   a.letters = letters; a.n = n; a.L = L; a.Lh = L - M + 1; a.LW = letter_words(L);
   a.fe = fe; a.fem = fem; a.hmax = hmax; a.hmean = hmean; a.hits = hits;

@@ -210,6 +210,7 @@ static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long l
 static inline int __popc(uint32_t v) { return __builtin_popcount(v); }
 static inline uint32_t __umulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
 #define __expf(x) expf(x)
+#define __logf(x) logf(x)
 static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 static inline float __builtin_amdgcn_logf(float x) { return log2f(x); }

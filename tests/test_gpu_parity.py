@@ -874,8 +874,6 @@ def test_generic_kernels_on_a_model_the_specialised_ones_take(monkeypatch, capsy
     big.epochs = 2
     big.fit(D)
     assert "Epoch 1: FE=" in capsys.readouterr().out
-    with pytest.raises(Exception, match="do not pool"):
-        CRBM(300, 10, pooling=2, fantasy_hidden_len=20).gibbsSteps(1)      # (a forced model keeps its specialised kernels when pooled)
     # the two paths sample the same chain
     monkeypatch.delenv("CRBM_FORCE_BIG")
     fast, o = make_pair(10, 15, ds=True, batchsize=4, Lf=76, cd_k=2, bshift=3.0, wscale=0.7)
@@ -895,6 +893,19 @@ def test_pooling(K, M, ds, pool, capsys):
     multinomial draw per group, free energy log(1 + sum exp), the PCD update with the pooled sparsity
     slope, and fit()'s truncation -- each against the oracle (which is pinned for pooling by
     tests/test_oracle.py: probability formula and finite differences of the penalty)."""
+    check_pooling(K, M, ds, pool, capsys)
+
+
+@pytest.mark.parametrize("K,M,ds,pool,force", [(6, 7, True, 2, True), (10, 15, False, 4, True), (70, 70, True, 3, False), (300, 6, False, 2, False)])
+def test_pooling_on_the_generic_kernels(K, M, ds, pool, force, capsys, monkeypatch):
+    """The same checks on the generic kernels: two models the specialised kernels take (CRBM_FORCE_BIG=1) and two they do
+    not (70-letter motifs, 300 motifs) -- round 3 and the first half of round 4 refused pooled models of that size."""
+    if force:
+        monkeypatch.setenv("CRBM_FORCE_BIG", "1")
+    check_pooling(K, M, ds, pool, capsys)
+
+
+def check_pooling(K, M, ds, pool, capsys):
     from crbm_amd import CRBM
     Lf, B, n = 12 * pool, 8, 9
     L = 10 * pool + M - 1
