@@ -1147,8 +1147,8 @@ GibbsGeom choose_gibbs_geometry(const ModelShape& ms, int Lf, int B, int num_cu,
 // config #2 with 256-thread blocks of 8 chains 21.7 -> 17.6 us per step of the whole batch (17.4 with four partitions);
 // with one 1024-thread block per CU per partition nothing (20.5 vs 20.6): the partitions then own disjoint CUs.
 // In the library: config #2 20.3 -> 17.8 us, config #5 137.9 -> 136.1 us, config #4 2191 -> 2180 us (not worth a second
-// geometry there); three and four partitions are SLOWER (29 / 26 us at config #2: a process has four hardware queues,
-// the handle's two other streams take two of them, and partitions that share a queue serialise).
+// geometry there); more partitions do not help (config #2: three 17.8 us against 17.4 with two, four 28 us: a process has
+// four hardware queues, and partitions that share one serialise).
 // Auto: two partitions when the small-block geometry of half the batch puts at least two blocks on a CU, still covers
 // every CU, and a launch is short (by the number of hidden units per step); CRBM_CHAIN_PARTS forces 1..4.
 struct PartPlan {
