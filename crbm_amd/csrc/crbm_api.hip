@@ -363,7 +363,7 @@ int big_launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bo
   HIPCHK(pbuf.ensure((size_t)a.R * a.row));
   a.partials = pbuf.p;
   ARGCHK(4 * M <= BIG_ST * 256, "motif_length too large for the statistics kernel");
-  const size_t lds = (((size_t)4 * M + 3) & ~(size_t)3) * 4 + (size_t)(a.pool > 1 ? 5 : 3) * a.CH * 4 + 64 + (size_t)a.CH + M;
+  const size_t lds = (((size_t)4 * M + 3) & ~(size_t)3) * 4 + (size_t)(a.pool > 1 ? 5 : 3) * a.CH * 4 + 64 + 3 * 256 * 4 + (size_t)a.CH + M;
   ARGCHK(lds <= 160 * 1024, "motif_length too large for the statistics kernel");
   hipLaunchKernelGGL(big_stats_kernel, dim3(K, a.R), dim3(256), lds, st, a);
   HIPCHK(hipGetLastError());

@@ -2774,12 +2774,14 @@ __global__ void __launch_bounds__(256) big_stats_kernel(BigStatsArgs a) {
   float* X = Q + CH;                                        // [CH] each: activations of the chunk (pooled models only)
   float* Xp = X + (a.pool > 1 ? CH : 0);
   float* xch = Xp + (a.pool > 1 ? CH : 0);                  // [16]
-  unsigned char* lb = reinterpret_cast<unsigned char*>(xch + 16);   // [CH + M]
+  float* red = xch + 16;                                    // [3][blockDim]: slices of a (letter, column) meet here
+  unsigned char* lb = reinterpret_cast<unsigned char*>(red + 3 * blockDim.x);   // [CH + M]
   for (int i = threadIdx.x; i < AM; i += blockDim.x) Wk[i] = a.m.W[(size_t)k * AM + i];
   const float bk = a.m.b[k];
   float vh[BIG_ST], vhp[BIG_ST], sw[BIG_ST];
 #pragma unroll
   for (int t = 0; t < BIG_ST; ++t) vh[t] = vhp[t] = sw[t] = 0.f;
+  const int nsl = AM <= (int)blockDim.x ? (int)blockDim.x / AM : 0;    // position slices per (letter, column); 0: 4 M > blockDim
   float hsum = 0.f, hpsum = 0.f, qsum = 0.f, cnt[4] = {0.f, 0.f, 0.f, 0.f};
   for (int nn = r; nn < a.n; nn += a.R) {
     const uint32_t* lrow = a.letters + (size_t)nn * a.LW;
@@ -2828,27 +2830,61 @@ __global__ void __launch_bounds__(256) big_stats_kernel(BigStatsArgs a) {
         }
         __syncthreads();
       }
-#pragma unroll
-      for (int t = 0; t < BIG_ST; ++t) {
-        const int e = (int)threadIdx.x + t * (int)blockDim.x;
-        if (e < AM) {
+      if (nsl > 0) {
+        // 4 M <= blockDim: thread (e, slice) takes every nsl-th position of the chunk for its (letter, column) -- branch-free
+        // (a match contributes P * 1, anything else P * 0), so that the loads of consecutive positions overlap
+        const int e = (int)threadIdx.x % AM, sl = (int)threadIdx.x / AM;
+        if (sl < nsl) {
           const int al = e / M, j = e - al * M;
           float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-          for (int s = 0; s < cl; ++s)
-            if (lb[s + j] == al) { s0 += P[s]; s1 += Pp[s]; s2 += Q[s]; }
-          vh[t] += s0; vhp[t] += s1; sw[t] += s2;
+          for (int s = sl; s < cl; s += nsl) {
+            const float mk = lb[s + j] == al ? 1.0f : 0.0f;
+            s0 = fmaf(mk, P[s], s0); s1 = fmaf(mk, Pp[s], s1); s2 = fmaf(mk, Q[s], s2);
+          }
+          vh[0] += s0; vhp[0] += s1; sw[0] += s2;
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < BIG_ST; ++t) {
+          const int e = (int)threadIdx.x + t * (int)blockDim.x;
+          if (e < AM) {
+            const int al = e / M, j = e - al * M;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+            for (int s = 0; s < cl; ++s) {
+              const float mk = lb[s + j] == al ? 1.0f : 0.0f;
+              s0 = fmaf(mk, P[s], s0); s1 = fmaf(mk, Pp[s], s1); s2 = fmaf(mk, Q[s], s2);
+            }
+            vh[t] += s0; vhp[t] += s1; sw[t] += s2;
+          }
         }
       }
     }
   }
   float* out = a.partials + (size_t)r * a.row;
+  if (nsl > 0) {
+    // the slices of a (letter, column) are added in slice order through LDS
+    __syncthreads();
+    const int e = (int)threadIdx.x % AM, sl = (int)threadIdx.x / AM;
+    const int RS = (int)blockDim.x;                         // stride of a kind (nsl * AM <= blockDim)
+    if (sl < nsl) { red[0 * RS + sl * AM + e] = vh[0]; red[1 * RS + sl * AM + e] = vhp[0]; red[2 * RS + sl * AM + e] = sw[0]; }
+    __syncthreads();
+    if ((int)threadIdx.x < AM) {
+      float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+      for (int i = 0; i < nsl; ++i) { t0 += red[0 * RS + i * AM + e]; t1 += red[1 * RS + i * AM + e]; t2 += red[2 * RS + i * AM + e]; }
+      out[a.off_vh0 + (size_t)k * AM + e] = t0;
+      if (a.m.ds) out[a.off_vh1 + (size_t)k * AM + e] = t1;
+      if (a.want_sparsity) out[a.off_sw + (size_t)k * AM + e] = t2;
+    }
+    __syncthreads();
+  } else {
 #pragma unroll
-  for (int t = 0; t < BIG_ST; ++t) {
-    const int e = (int)threadIdx.x + t * (int)blockDim.x;
-    if (e < AM) {
-      out[a.off_vh0 + (size_t)k * AM + e] = vh[t];
-      if (a.m.ds) out[a.off_vh1 + (size_t)k * AM + e] = vhp[t];
-      if (a.want_sparsity) out[a.off_sw + (size_t)k * AM + e] = sw[t];
+    for (int t = 0; t < BIG_ST; ++t) {
+      const int e = (int)threadIdx.x + t * (int)blockDim.x;
+      if (e < AM) {
+        out[a.off_vh0 + (size_t)k * AM + e] = vh[t];
+        if (a.m.ds) out[a.off_vh1 + (size_t)k * AM + e] = vhp[t];
+        if (a.want_sparsity) out[a.off_sw + (size_t)k * AM + e] = sw[t];
+      }
     }
   }
   const float H = big_block_sum(hsum, xch), Hp = big_block_sum(hpsum, xch), Sb = big_block_sum(qsum, xch);

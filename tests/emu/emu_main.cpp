@@ -492,7 +492,7 @@ int emu_big_stats(const float* W, const float* b, const float* c, int K, int M, 
   a.off_sw = 2 * KAM + 2 * K; a.off_sb = 3 * KAM + 2 * K; a.off_v = 3 * KAM + 3 * K;
   if (4 * M > BIG_ST * threads) return -2;
   emu::launch([&] { big_stats_kernel(a); }, dim3(K, R), dim3(threads),
-              (((size_t)4 * M + 3) & ~(size_t)3) * 4 + (size_t)(pool > 1 ? 5 : 3) * CH * 4 + 64 + (size_t)CH + M);
+              (((size_t)4 * M + 3) & ~(size_t)3) * 4 + (size_t)(pool > 1 ? 5 : 3) * CH * 4 + 64 + (size_t)3 * threads * 4 + (size_t)CH + M);
   host_reduce(partials.data(), R, row, K, KAM, ds, want_sparsity, skip_begin, skip_len, (float)n, sums);
   return row;
 }

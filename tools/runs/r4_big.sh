@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT; O=gpurun_out/r4_big; mkdir -p $O
-( time timeout -k 10 1000 python -m pytest tests -x -q -m gpu ) > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -8 $O/pytest.log
-timeout -k 10 900 python tools/soak_parity.py 120 77 > $O/soak_120_77.txt 2>&1; echo "soak rc=$?"; grep -v ": ok" $O/soak_120_77.txt | tail -8; grep -c ": ok" $O/soak_120_77.txt
+( time timeout -k 10 1000 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "edge_shapes or generic or beyond_the_lds or pooling" ) > $O/pytest_big.log 2>&1; echo "pytest rc=$?"; tail -4 $O/pytest_big.log
+for shape in "300 10 0 256 200" "120 40 1 256 200" "8 100 1 256 400" "300 10 0 4096 200"; do timeout -k 10 200 python tools/prof_big.py $shape 10 2>&1 | tail -2; done
