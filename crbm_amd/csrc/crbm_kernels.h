@@ -88,14 +88,9 @@ __device__ __forceinline__ void short_sleep() { __builtin_amdgcn_s_sleep(8); }
 // the waits for another process in TIME, whatever the shader clock does
 __device__ __forceinline__ uint64_t realtime_ticks() { return __builtin_amdgcn_s_memrealtime(); }
 __device__ __forceinline__ uint64_t shader_cycles() { return __builtin_amdgcn_s_memtime(); }   // counts shader clocks
-// x = hi + lo with both halves f16 (round to nearest): 22 significant bits.  Per pair of values one v_cvt_pk_f16_f32
-// (the hi halves) and two mixed-precision FMAs, lo = f16(x * 1.0 - hi) with x read as f32 and hi as the f16 half of
-// its packed register (v_fma_mixlo_f16 / v_fma_mixhi_f16 write the low / high half of the destination): 12
-// instructions per 8 values where convert-back, subtract and convert again took 23.  x - hi is exact in f32, so the
-// one rounding is the same as before and the halves are bit for bit what the plain form gives (CRBM_SPLIT_PLAIN:
-// the plain form, for A/B timing).
+// x = hi + lo with both halves f16 (round to nearest): 22 significant bits, v_cvt_pk_f16_f32 +
+// v_cvt_f32_f16 + v_pk_add_f32 per pair
 __device__ __forceinline__ void split_f16(const float (&x)[8], HalfFrag& hi, HalfFrag& lo) {
-#ifdef CRBM_SPLIT_PLAIN
   typedef _Float16 half8 __attribute__((ext_vector_type(8)));
   half8 h, l;
 #pragma unroll
@@ -105,19 +100,6 @@ __device__ __forceinline__ void split_f16(const float (&x)[8], HalfFrag& hi, Hal
   }
   hi = __builtin_bit_cast(HalfFrag, h);
   lo = __builtin_bit_cast(HalfFrag, l);
-#else
-  typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const half2v h2 = {(_Float16)x[2 * e], (_Float16)x[2 * e + 1]};
-    const uint32_t hp = __builtin_bit_cast(uint32_t, h2);
-    uint32_t lp;
-    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(lp) : "v"(x[2 * e]), "v"(hp));
-    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lp) : "v"(x[2 * e + 1]), "v"(hp));
-    hi.r[e] = hp;
-    lo.r[e] = lp;
-  }
-#endif
 }
 // D = A (16 x 32) * B (32 x 16) + C on the matrix core.  Lane l holds A[row l&15][8(l>>4) .. +7],
 // B[8(l>>4) .. +7][col l&15] and D[rows 4(l>>4) .. +3][col l&15] (checked with integer data on gfx950:
