@@ -136,6 +136,7 @@ struct PartWorker {
 struct crbm_handle {
   crbm_config cfg;
   int K = 0, M = 0, ds = 0, NW = 0, G = 0, KAM = 0;
+  int A = 4;                // letters of the alphabet (input_dims); anything but 4 runs on the generic kernels, rows of bytes
   int Lf = 0, Lv = 0, B = 0;
   int device = 0, num_cu = 256;
   hipStream_t stream = nullptr;
@@ -261,6 +262,9 @@ RngView rng_view(const crbm_handle* h, uint32_t step, uint32_t seq_offset) {
 
 int tab_bytes(const crbm_handle* h) { return h->ms.TAB * 4; }
 
+// words per packed row of L letters (2-bit letters for DNA, bytes for any other alphabet)
+int lw(const crbm_handle* h, int L) { return letter_words_any(h->A, L); }
+
 // (re)build the LDS table images after a parameter change
 int ensure_tables(crbm_handle* h) {
   if (!h->tables_dirty || h->big) return CRBM_OK;
@@ -287,7 +291,7 @@ int ensure_solo_table(crbm_handle* h) {
 BigModel big_model(const crbm_handle* h) {
   BigModel m;
   m.W = h->dW; m.b = h->db; m.c = h->dc;
-  m.K = h->K; m.M = h->M; m.ds = h->ds; m.NW = h->NW;
+  m.K = h->K; m.M = h->M; m.ds = h->ds; m.NW = h->NW; m.A = h->A;
   return m;
 }
 
@@ -297,10 +301,10 @@ int big_launch_hgv(crbm_handle* h, const uint32_t* d_letters, int n, int L, int 
   BigHgvArgs a;
   a.m = big_model(h);
   a.letters = d_letters;
-  a.n = n; a.L = L; a.Lh = L - h->M + 1; a.LW = letter_words(L);
+  a.n = n; a.L = L; a.Lh = L - h->M + 1; a.LW = lw(h, L);
   const int pool = h->ms.POOL;
   int ks = pool > 1 ? 8 : 32;                                // motifs per staged slab: a divisor of 32 whose filters fit 96 KB
-  while (ks > 1 && (size_t)ks * h->M * 16 > 96 * 1024) ks >>= 1;   // (pooled: at most 8, the capacity of big_hgv_pooled_kernel)
+  while (ks > 1 && (size_t)ks * h->M * h->A * 4 > 96 * 1024) ks >>= 1;   // (pooled: at most 8, the capacity of big_hgv_pooled_kernel)
   a.KS = ks;
   a.pool = pool;
   // rows per tile: enough tiles to cover the chip a few times over (every tile stages the filters once per slab), at most
@@ -310,7 +314,7 @@ int big_launch_hgv(crbm_handle* h, const uint32_t* d_letters, int n, int L, int 
   a.act = act; a.prob = prob; a.sample = sample; a.ones = ones; a.masks = masks;
   a.rng = rng_view(h, step, seq_offset);
   a.kind = kind;
-  const size_t lds = ((size_t)ks * h->M * 4 + 32) * 4 + (size_t)a.TS * a.LW * 4;
+  const size_t lds = ((size_t)ks * h->M * h->A + 32) * 4 + (size_t)a.TS * a.LW * 4;
   ARGCHK(lds <= 160 * 1024, "motif_length too large for the h|v kernel");
   const int ntiles = (n + a.TS - 1) / a.TS;
   if (pool > 1) hipLaunchKernelGGL(big_hgv_pooled_kernel, dim3(std::max(1, std::min(ntiles, h->num_cu * 8))), dim3(256), lds, st, a);
@@ -325,12 +329,15 @@ int big_launch_gibbs(crbm_handle* h, int steps, hipStream_t st) {
   v.m = big_model(h);
   v.hm = h->d_hm; v.hmp = h->ds ? h->d_hmp : nullptr; v.vout = h->d_vf;
   v.nchains = h->B; v.Lf = h->Lf; v.Lv = h->Lv; v.LWs = h->gl.LWs;
-  v.JS = std::max(1, std::min(h->M, (64 * 1024) / (32 * 16)));
-  const size_t lds = (size_t)v.JS * 32 * 16 + (size_t)BIG_VR * 256;
+  v.JS = std::max(1, std::min(h->M, (64 * 1024) / (32 * 4 * h->A)));
+  // DNA: activations in registers; any other alphabet: one position per thread, activations in LDS (big_vgh_any_kernel)
+  const size_t lds = h->A == 4 ? (size_t)v.JS * 32 * 16 + (size_t)BIG_VR * 256
+                               : ((size_t)v.JS * 32 * h->A + (size_t)h->A * 256) * 4 + 256;
   HIPCHK(hipMemsetAsync(h->d_ones, 0, sizeof(unsigned long long), st));
   for (int t = 0; t < steps; ++t) {
     v.rng = rng_view(h, h->gibbs_step + (uint32_t)t, h->chain_offset);
-    hipLaunchKernelGGL(big_vgh_kernel, dim3(std::max(1, std::min(h->B, h->num_cu * 8))), dim3(256), lds, st, v);
+    if (h->A == 4) hipLaunchKernelGGL(big_vgh_kernel, dim3(std::max(1, std::min(h->B, h->num_cu * 8))), dim3(256), lds, st, v);
+    else hipLaunchKernelGGL(big_vgh_any_kernel, dim3(std::max(1, std::min(h->B, h->num_cu * 8))), dim3(256), lds, st, v);
     HIPCHK(hipGetLastError());
     const bool last = t == steps - 1;      // the last step also counts the units that are on (activity monitor)
     for (int strand = 0; strand <= h->ds; ++strand) {
@@ -351,19 +358,20 @@ int big_launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bo
   BigStatsArgs a;
   a.m = big_model(h);
   a.letters = d_letters;
-  a.n = n; a.L = L; a.Lh = L - M + 1; a.LW = letter_words(L);
+  a.n = n; a.L = L; a.Lh = L - M + 1; a.LW = lw(h, L);
   a.want_sparsity = data_half ? 1 : 0;
   a.R = std::max(1, std::min(n, std::max(1, (h->num_cu * 8) / K)));
   a.pool = h->ms.POOL;
   a.CH = std::max(64, std::min(4096, a.Lh));
   a.CH = std::max(a.pool, a.CH - a.CH % a.pool);            // chunks start on pooling-group boundaries
-  a.row = 3 * KAM + 3 * K + 4;
+  a.row = 3 * KAM + 3 * K + h->A;
   a.off_vh0 = 0; a.off_vh1 = KAM; a.off_h0 = 2 * KAM; a.off_h1 = 2 * KAM + K;
   a.off_sw = 2 * KAM + 2 * K; a.off_sb = 3 * KAM + 2 * K; a.off_v = 3 * KAM + 3 * K;
   HIPCHK(pbuf.ensure((size_t)a.R * a.row));
   a.partials = pbuf.p;
-  ARGCHK(4 * M <= BIG_ST * 256, "motif_length too large for the statistics kernel");
-  const size_t lds = (((size_t)4 * M + 3) & ~(size_t)3) * 4 + (size_t)(a.pool > 1 ? 5 : 3) * a.CH * 4 + 64 + 3 * 256 * 4 + (size_t)a.CH + M;
+  ARGCHK(h->A * M <= BIG_ST * 256, "motif_length too large for the statistics kernel");
+  const size_t lds = (((size_t)h->A * M + 3) & ~(size_t)3) * 4 + (size_t)(a.pool > 1 ? 5 : 3) * a.CH * 4 + 64 + 3 * 256 * 4 +
+                     (size_t)((h->A + 3) & ~3) * 4 + (size_t)a.CH + M;
   ARGCHK(lds <= 160 * 1024, "motif_length too large for the statistics kernel");
   hipLaunchKernelGGL(big_stats_kernel, dim3(K, a.R), dim3(256), lds, st, a);
   HIPCHK(hipGetLastError());
@@ -388,9 +396,9 @@ int big_launch_eval(crbm_handle* h, const uint32_t* rows, int n, int L, int hits
   BigEvalArgs a;
   a.m = big_model(h);
   a.letters = rows;
-  a.n = n; a.L = L; a.Lh = L - h->M + 1; a.LW = letter_words(L);
+  a.n = n; a.L = L; a.Lh = L - h->M + 1; a.LW = lw(h, L);
   a.fe = fe; a.fem = fem; a.hmax = hmax; a.hmean = hmean; a.pos_fx = pos_fx; a.hits = hits; a.pool = h->ms.POOL;
-  const size_t lds = (((size_t)4 * h->M + 3) & ~(size_t)3) * 4 + 64 + (size_t)L;
+  const size_t lds = (((size_t)h->A * h->M + 3) & ~(size_t)3) * 4 + 64 + (size_t)L;
   ARGCHK(lds <= 160 * 1024, "sequence too long for the evaluation kernel of a model of this size");
   hipLaunchKernelGGL(big_eval_kernel, dim3(std::max(1, std::min(n, h->num_cu * 8))), dim3(256), lds, st, a);
   HIPCHK(hipGetLastError());
@@ -417,16 +425,17 @@ int check_flags(crbm_handle* h) {
   return CRBM_OK;
 }
 
-// host one-hot (n,1,4,L) -> packed letters on the device
+// host one-hot (n,1,A,L) -> packed letters on the device
 int encode_host(crbm_handle* h, const float* v, int n, int L, uint32_t* d_letters) {
-  const size_t count = (size_t)n * 4 * L;
+  const size_t count = (size_t)n * h->A * L;
   HIPCHK(h->stage.ensure(count));
   HIPCHK(hipMemcpyAsync(h->stage.p, v, count * sizeof(float), hipMemcpyHostToDevice, h->stream));
   EncodeArgs a;
   a.v = h->stage.p; a.letters = d_letters; a.flags = h->d_flags;
-  a.n = n; a.L = L; a.LW = letter_words(L);
+  a.n = n; a.L = L; a.LW = lw(h, L); a.A = h->A;
   const int grid = grid_for((long)n * a.LW, 256, h->num_cu * 8);
-  hipLaunchKernelGGL(encode_onehot_kernel, dim3(grid), dim3(256), 0, h->stream, a);
+  if (h->A == 4) hipLaunchKernelGGL(encode_onehot_kernel, dim3(grid), dim3(256), 0, h->stream, a);
+  else hipLaunchKernelGGL(encode_onehot_any_kernel, dim3(grid), dim3(256), 0, h->stream, a);
   HIPCHK(hipGetLastError());
   return check_flags(h);
 }
@@ -439,8 +448,9 @@ int encode_codes_host(crbm_handle* h, const uint8_t* codes, int n, int L, uint32
   EncodeCodesArgs a;
   a.codes = reinterpret_cast<const unsigned char*>(h->stage.p);
   a.letters = d_letters; a.flags = h->d_flags;
-  a.n = n; a.L = L; a.LW = letter_words(L);
-  hipLaunchKernelGGL(encode_codes_kernel, dim3(grid_for((long)n * a.LW, 256, h->num_cu * 8)), dim3(256), 0, h->stream, a);
+  a.n = n; a.L = L; a.LW = lw(h, L); a.A = h->A;
+  if (h->A == 4) hipLaunchKernelGGL(encode_codes_kernel, dim3(grid_for((long)n * a.LW, 256, h->num_cu * 8)), dim3(256), 0, h->stream, a);
+  else hipLaunchKernelGGL(encode_codes_any_kernel, dim3(grid_for((long)n * a.LW, 256, h->num_cu * 8)), dim3(256), 0, h->stream, a);
   HIPCHK(hipGetLastError());
   return check_flags(h);
 }
@@ -453,7 +463,7 @@ int launch_hgv(crbm_handle* h, const uint32_t* d_letters, int n, int L, int mode
   HgvArgs a;
   a.tables = h->d_tables;
   a.letters = d_letters;
-  a.n = n; a.L = L; a.Lh = L - h->M + 1; a.LW = letter_words(L);
+  a.n = n; a.L = L; a.Lh = L - h->M + 1; a.LW = lw(h, L);
   a.TS = tile_seqs(a.Lh, 4096);
   a.divLh = make_fastdiv((uint32_t)a.Lh);
   a.mode = mode;
@@ -736,7 +746,7 @@ int prepare_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool 
   StatsMfmaArgs& a = *out;
   a.tables = h->d_tables;
   a.letters = d_letters;
-  a.n = n; a.L = L; a.Lh = Lh; a.LW = letter_words(L);
+  a.n = n; a.L = L; a.Lh = Lh; a.LW = lw(h, L);
   const long ngroups = (long)n * st.GPC;
   const long nunits = (ngroups + 1) / 2;
   a.off_tab = st.region_floats;
@@ -806,6 +816,7 @@ void fill_update_args(crbm_handle* h, int L_data, UpdateTablesArgs& a) {
   u.L_data = L_data; u.Lf = h->Lf;
   u.data_off = h->sl.data_off; u.n_d = h->sl.n_d; u.model_off = h->sl.model_off; u.n_m = h->sl.n_m;
   u.lr = h->cfg.learning_rate; u.momentum = h->cfg.momentum; u.rho = h->cfg.rho; u.lambda_rate = h->cfg.lambda_rate;
+  u.A = h->A;
   a.tables = h->d_tables;
 }
 
@@ -824,7 +835,7 @@ int launch_update(crbm_handle* h, int L_data) {
   if (h->big) {        // element-wise and in place: no table images to rebuild, no second buffer set
     UpdateArgs& u = a.u;
     u.oW = h->dW; u.ob = h->db; u.oc = h->dc; u.ovW = h->dvW; u.ovb = h->dvb; u.ovc = h->dvc;
-    hipLaunchKernelGGL(big_update_kernel, dim3(grid_for((long)h->KAM + h->K + 4, 256, h->num_cu * 4)), dim3(256), 0, h->stream, u);
+    hipLaunchKernelGGL(big_update_kernel, dim3(grid_for((long)h->KAM + h->K + h->A, 256, h->num_cu * 4)), dim3(256), 0, h->stream, u);
     HIPCHK(hipGetLastError());
     h->params_version += 1;
     return CRBM_OK;
@@ -1065,9 +1076,10 @@ int validate_config(const crbm_config* cfg) {
   // (beyond 256 motifs / 64 letters / what the LDS holds the generic kernels take over: crbm_create)
   ARGCHK(cfg->num_motifs <= 65536, "num_motifs > 65536 is not supported");
   ARGCHK(cfg->motif_length >= 1, "Motif length must be positive.");
-  ARGCHK(cfg->motif_length <= 4 * 64 * BIG_ST / 4, "motif_length > 512 is not supported (statistics kernel: 4 * motif_length accumulators per 256-thread block)");
-  ARGCHK((long)cfg->num_motifs * cfg->motif_length <= (1L << 24), "num_motifs * motif_length too large");
-  ARGCHK(cfg->input_dims == 4, "the HIP kernels require input_dims == 4 (DNA one-hot)");
+  ARGCHK(cfg->input_dims >= 1, "input_dims must be positive.");
+  ARGCHK(cfg->input_dims <= 64, "input_dims > 64 is not supported (v|h keeps a position's activations of all letters in LDS)");
+  ARGCHK(cfg->input_dims * cfg->motif_length <= 256 * BIG_ST, "input_dims * motif_length > 2048 is not supported (statistics kernel: one accumulator per letter and filter column, 8 per thread of a 256-thread block; DNA: motif_length <= 512)");
+  ARGCHK((long)cfg->num_motifs * cfg->motif_length * cfg->input_dims <= (1L << 26), "num_motifs * input_dims * motif_length too large");
   ARGCHK(cfg->pooling >= 1 && cfg->pooling <= 64, "pooling must be between 1 and 64");
   ARGCHK(cfg->fantasy_hidden_len % cfg->pooling == 0, "pooling must divide the hidden length of the fantasy chains");
   ARGCHK(cfg->batchsize >= 1, "batchsize must be positive.");
@@ -1256,11 +1268,12 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
   crbm_handle* hh = new crbm_handle();
   hh->cfg = *cfg;
   hh->K = cfg->num_motifs; hh->M = cfg->motif_length; hh->ds = cfg->doublestranded ? 1 : 0;
-  hh->KAM = hh->K * 4 * hh->M;
+  hh->A = cfg->input_dims;
+  hh->KAM = hh->K * hh->A * hh->M;
   hh->Lf = cfg->fantasy_hidden_len; hh->Lv = hh->Lf + hh->M - 1; hh->B = cfg->batchsize;
   hh->seed = cfg->seed;
   hh->device = cfg->device;
-  hh->sl = sums_layout(hh->K, hh->M);
+  hh->sl = sums_layout(hh->K, hh->M, hh->A);
   // gather-table group size, derived shapes
   hh->G = env_int("CRBM_GROUP", 0);
   if (hh->G < 1 || hh->G > 4) hh->G = choose_group(hh->K, hh->M, hh->ds, env_int("CRBM_TABLE_BUDGET", 26 * 1024));
@@ -1282,11 +1295,12 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
     if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, hh->device) == hipSuccess && khz > 0) hh->wall_khz = khz;
     (void)hipGetLastError();
   }
-  hh->big = (hh->K > MAX_MOTIFS || hh->M > MAX_MOTIF_LENGTH) ? true : model_needs_big(hh->ms, hh->Lf, hh->B, hh->num_cu);
+  // (the specialised kernels are DNA kernels: 2-bit letters, tables over letter tuples; any other alphabet is generic)
+  hh->big = (hh->K > MAX_MOTIFS || hh->M > MAX_MOTIF_LENGTH || hh->A != 4) ? true : model_needs_big(hh->ms, hh->Lf, hh->B, hh->num_cu);
   if (hh->big) {
     // no specialised kernels, no table images: the state layout is the same (K-bit masks, 2-bit letters)
     hh->gl = GibbsLayout();
-    hh->gl.S = 1; hh->gl.Lv = hh->Lv; hh->gl.LWs = letter_words(hh->Lv);
+    hh->gl.S = 1; hh->gl.Lv = hh->Lv; hh->gl.LWs = letter_words_any(hh->A, hh->Lv);
     hh->glv[0] = hh->glv[1] = hh->gl;
     hh->variant = 1; hh->topdown_mode = 2;
     hh->GS = hh->G; hh->ms_solo = hh->ms;
@@ -1374,13 +1388,14 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
   const size_t kam = (size_t)hh->KAM, k = (size_t)hh->K;
   TRY(hipMalloc((void**)&hh->dW, kam * 4)); TRY(hipMalloc((void**)&hh->dvW, kam * 4));
   TRY(hipMalloc((void**)&hh->db, k * 4));   TRY(hipMalloc((void**)&hh->dvb, k * 4));
-  TRY(hipMalloc((void**)&hh->dc, 16));      TRY(hipMalloc((void**)&hh->dvc, 16));
+  const size_t cb = (size_t)std::max(4, hh->A) * 4;
+  TRY(hipMalloc((void**)&hh->dc, cb));      TRY(hipMalloc((void**)&hh->dvc, cb));
   TRY(hipMemset(hh->dW, 0, kam * 4)); TRY(hipMemset(hh->dvW, 0, kam * 4));
   TRY(hipMemset(hh->db, 0, k * 4));   TRY(hipMemset(hh->dvb, 0, k * 4));
-  TRY(hipMemset(hh->dc, 0, 16));      TRY(hipMemset(hh->dvc, 0, 16));
+  TRY(hipMemset(hh->dc, 0, cb));      TRY(hipMemset(hh->dvc, 0, cb));
   TRY(hipMalloc((void**)&hh->dW2, kam * 4)); TRY(hipMalloc((void**)&hh->dvW2, kam * 4));
   TRY(hipMalloc((void**)&hh->db2, k * 4));   TRY(hipMalloc((void**)&hh->dvb2, k * 4));
-  TRY(hipMalloc((void**)&hh->dc2, 16));      TRY(hipMalloc((void**)&hh->dvc2, 16));
+  TRY(hipMalloc((void**)&hh->dc2, cb));      TRY(hipMalloc((void**)&hh->dvc2, cb));
   TRY(hipMalloc((void**)&hh->d_tables, hh->big ? 64 : (size_t)hh->ms.TABLES_ALL * 4));
   if (hh->GS != hh->G) TRY(hipMalloc((void**)&hh->d_tf_solo, (size_t)hh->ms_solo.TAB * 4));
   const size_t mwords = (size_t)hh->B * hh->Lf * hh->NW;
@@ -1475,7 +1490,7 @@ int crbm_set_params(crbm_handle* h, const float* W, const float* b, const float*
   ARGCHK(W && b && c, "null argument");
   HIPCHK(hipMemcpyAsync(h->dW, W, (size_t)h->KAM * 4, hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(h->db, b, (size_t)h->K * 4, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(h->dc, c, 16, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->dc, c, (size_t)h->A * 4, hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   h->tables_dirty = true;
   h->params_version += 1;
@@ -1487,7 +1502,7 @@ int crbm_get_params(crbm_handle* h, float* W, float* b, float* c) {
   ARGCHK(W && b && c, "null argument");
   HIPCHK(hipMemcpyAsync(W, h->dW, (size_t)h->KAM * 4, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipMemcpyAsync(b, h->db, (size_t)h->K * 4, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipMemcpyAsync(c, h->dc, 16, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(c, h->dc, (size_t)h->A * 4, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   return CRBM_OK;
 }
@@ -1497,7 +1512,7 @@ int crbm_set_velocities(crbm_handle* h, const float* vW, const float* vb, const 
   ARGCHK(vW && vb && vc, "null argument");
   HIPCHK(hipMemcpyAsync(h->dvW, vW, (size_t)h->KAM * 4, hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(h->dvb, vb, (size_t)h->K * 4, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(h->dvc, vc, 16, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->dvc, vc, (size_t)h->A * 4, hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   return CRBM_OK;
 }
@@ -1507,7 +1522,7 @@ int crbm_get_velocities(crbm_handle* h, float* vW, float* vb, float* vc) {
   ARGCHK(vW && vb && vc, "null argument");
   HIPCHK(hipMemcpyAsync(vW, h->dvW, (size_t)h->KAM * 4, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipMemcpyAsync(vb, h->dvb, (size_t)h->K * 4, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipMemcpyAsync(vc, h->dvc, 16, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(vc, h->dvc, (size_t)h->A * 4, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   return CRBM_OK;
 }
@@ -1555,11 +1570,12 @@ int crbm_get_fantasy(crbm_handle* h, float* hid, float* hid_prime) {
 int crbm_get_fantasy_visible(crbm_handle* h, float* v) {
   ENTER();
   ARGCHK(v, "null argument");
-  const size_t count = (size_t)h->B * 4 * h->Lv;
+  const size_t count = (size_t)h->B * h->A * h->Lv;
   HIPCHK(h->stage.ensure(count));
   DecodeArgs a;
-  a.letters = h->d_vf; a.v = h->stage.p; a.n = h->B; a.L = h->Lv; a.LW = h->gl.LWs;
-  hipLaunchKernelGGL(decode_onehot_kernel, dim3(grid_for((long)h->B * h->Lv, 256, h->num_cu * 8)), dim3(256), 0, h->stream, a);
+  a.letters = h->d_vf; a.v = h->stage.p; a.n = h->B; a.L = h->Lv; a.LW = h->gl.LWs; a.A = h->A;
+  if (h->A == 4) hipLaunchKernelGGL(decode_onehot_kernel, dim3(grid_for((long)h->B * h->Lv, 256, h->num_cu * 8)), dim3(256), 0, h->stream, a);
+  else hipLaunchKernelGGL(decode_onehot_any_kernel, dim3(grid_for((long)h->B * h->Lv, 256, h->num_cu * 8)), dim3(256), 0, h->stream, a);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(v, h->stage.p, count * 4, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -1592,7 +1608,7 @@ int crbm_train_step(crbm_handle* h, const float* D, int32_t n, int32_t L) {
   ARGCHK(D, "null argument");
   int rc = check_data_shape(h, n, L);
   if (rc) return rc;
-  HIPCHK(h->letters.ensure((size_t)n * letter_words(L)));
+  HIPCHK(h->letters.ensure((size_t)n * lw(h, L)));
   rc = encode_host(h, D, n, L, h->letters.p);
   if (rc) return rc;
   rc = train_core(h, h->letters.p, n, L);
@@ -1613,15 +1629,15 @@ int crbm_dataset_upload(crbm_handle* h, const float* data, int32_t n, int32_t L)
   ARGCHK(data, "null argument");
   int rc = check_data_shape(h, n, L);
   if (rc) return rc;
-  const int LW = letter_words(L);
+  const int LW = lw(h, L);
   DevBuf<uint32_t>& ds = h->dataset[h->slot];
   h->dataset_n[h->slot] = 0;
   HIPCHK(ds.ensure((size_t)n * LW));
   // stream the fp32 array through the staging buffer in slabs of <= 64 MiB
-  const int slab = std::max(1, (int)std::min<long>(n, (64L << 20) / ((long)4 * L * 4)));
+  const int slab = std::max(1, (int)std::min<long>(n, (64L << 20) / ((long)h->A * L * 4)));
   for (int start = 0; start < n; start += slab) {
     const int cnt = std::min(slab, n - start);
-    rc = encode_host(h, data + (size_t)start * 4 * L, cnt, L, ds.p + (size_t)start * LW);
+    rc = encode_host(h, data + (size_t)start * h->A * L, cnt, L, ds.p + (size_t)start * LW);
     if (rc) return rc;
   }
   h->dataset_n[h->slot] = n; h->dataset_L[h->slot] = L;
@@ -1633,7 +1649,7 @@ int crbm_dataset_upload_codes(crbm_handle* h, const uint8_t* codes, int32_t n, i
   ARGCHK(codes, "null argument");
   int rc = check_data_shape(h, n, L);
   if (rc) return rc;
-  const int LW = letter_words(L);
+  const int LW = lw(h, L);
   DevBuf<uint32_t>& ds = h->dataset[h->slot];
   h->dataset_n[h->slot] = 0;
   HIPCHK(ds.ensure((size_t)n * LW));
@@ -1653,7 +1669,7 @@ int crbm_train_step_resident(crbm_handle* h, int32_t start, int32_t end) {
   ARGCHK(h->dataset_n[slot] > 0, "no resident data set (call crbm_dataset_upload)");
   ARGCHK(start >= 0 && end >= start && end <= h->dataset_n[slot], "row range out of bounds");
   ARGCHK(end > start || h->comm || h->ipc_on, "empty row range");
-  const int LW = letter_words(h->dataset_L[slot]);
+  const int LW = lw(h, h->dataset_L[slot]);
   int rc = train_core(h, h->dataset[slot].p + (size_t)start * LW, end - start, h->dataset_L[slot]);
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -1670,7 +1686,7 @@ int crbm_train_epoch_resident(crbm_handle* h, int32_t batchsize) {
   const int slot = h->slot;
   ARGCHK(h->dataset_n[slot] > 0, "no resident data set (call crbm_dataset_upload)");
   ARGCHK(batchsize >= 1, "batchsize must be positive");
-  const int total = h->dataset_n[slot], L = h->dataset_L[slot], LW = letter_words(L);
+  const int total = h->dataset_n[slot], L = h->dataset_L[slot], LW = lw(h, L);
   for (int start = 0; start < total; start += batchsize) {
     const int end = std::min(total, start + batchsize), n = end - start;
     const int lo = start + (int)(((long)n * h->rank) / h->nranks), hi = start + (int)(((long)n * (h->rank + 1)) / h->nranks);
@@ -1694,7 +1710,7 @@ int crbm_train_epoch_sharded(crbm_handle* h, int32_t batchsize, int32_t total_ro
   // and all ranks must divide the all-reduced sums by the same counts
   int rc = check_data_shape(h, 1, L);
   if (rc) return rc;
-  const int LW = letter_words(L);
+  const int LW = lw(h, L);
   long have = 0;
   for (int start = 0; start < total_rows; start += batchsize) {
     const long n = std::min(total_rows, start + batchsize) - start;
@@ -1846,7 +1862,7 @@ int crbm_time_train(crbm_handle* h, int32_t start, int32_t end, int32_t launches
   const int slot = h->slot;
   ARGCHK(h->dataset_n[slot] > 0, "no resident data set (call crbm_dataset_upload)");
   ARGCHK(start >= 0 && end > start && end <= h->dataset_n[slot] && launches >= 1 && total_ms, "bad argument");
-  const int LW = letter_words(h->dataset_L[slot]);
+  const int LW = lw(h, h->dataset_L[slot]);
   HIPCHK(hipEventRecord(h->ev0, h->stream));
   for (int i = 0; i < launches; ++i) {
     int rc = train_core(h, h->dataset[slot].p + (size_t)start * LW, end - start, h->dataset_L[slot]);
@@ -1867,7 +1883,7 @@ int crbm_h_given_v(crbm_handle* h, const float* v, int32_t n, int32_t L, int32_t
   if (rc) return rc;
   const int Lh = L - h->M + 1;
   const size_t count = (size_t)n * h->K * Lh;
-  HIPCHK(h->letters.ensure((size_t)n * letter_words(L)));
+  HIPCHK(h->letters.ensure((size_t)n * lw(h, L)));
   rc = encode_host(h, v, n, L, h->letters.p);
   if (rc) return rc;
   if (act) HIPCHK(h->out_a.ensure(count));
@@ -1890,7 +1906,7 @@ int crbm_v_given_h(crbm_handle* h, const float* hid, const float* hid_prime, int
   ARGCHK(n >= 1 && Lh >= 1, "bad shape");
   const int L = Lh + h->M - 1;
   ARGCHK((long)L * 4 < (1 << 20), "sequence too long");
-  const size_t hcount = (size_t)n * h->K * Lh, vcount = (size_t)n * 4 * L;
+  const size_t hcount = (size_t)n * h->K * Lh, vcount = (size_t)n * h->A * L;
   HIPCHK(h->stage.ensure(hcount));
   HIPCHK(hipMemcpyAsync(h->stage.p, hid, hcount * 4, hipMemcpyHostToDevice, h->stream));
   if (hid_prime) {
@@ -1910,8 +1926,14 @@ int crbm_v_given_h(crbm_handle* h, const float* hid, const float* hid_prime, int
   a.rng = rng_view(h, rng_step, h->chain_offset);
   a.kind = KIND_API_V;
   const int ntiles = (n + a.TS - 1) / a.TS;
-  hipLaunchKernelGGL(vgh_dense_kernel, dim3(std::max(1, std::min(ntiles, h->num_cu * 8))), dim3(256),
-                     (size_t)h->M * h->K * 16, h->stream, a);
+  if (h->A == 4) {
+    hipLaunchKernelGGL(vgh_dense_kernel, dim3(std::max(1, std::min(ntiles, h->num_cu * 8))), dim3(256),
+                       (size_t)h->M * h->K * 16, h->stream, a);
+  } else {      // any other alphabet: a position's activations of all letters in LDS, filters from global memory
+    VghAnyArgs aa;
+    aa.g = a; aa.A = h->A;
+    hipLaunchKernelGGL(vgh_dense_any_kernel, dim3(grid_for((long)n * L, 256, h->num_cu * 8)), dim3(256), (size_t)h->A * 256 * 4, h->stream, aa);
+  }
   HIPCHK(hipGetLastError());
   int rc;
   if (act && (rc = copy_out(h, act, h->out_a.p, vcount))) return rc;
@@ -1938,23 +1960,23 @@ namespace {
 
 // where the letters of an evaluation call come from
 struct RowSource {
-  const float* onehot = nullptr;      // host (n,1,4,L) fp32
-  const uint8_t* codes = nullptr;     // host (n,L) bytes 0..3
+  const float* onehot = nullptr;      // host (n,1,A,L) fp32
+  const uint8_t* codes = nullptr;     // host (n,L) bytes 0..A-1
   const uint32_t* resident = nullptr; // device packed rows
-  int n = 0, L = 0;
-  size_t in_bytes_per_row() const { return onehot ? (size_t)16 * L : (codes ? (size_t)L : 0); }
+  int n = 0, L = 0, A = 4;
+  size_t in_bytes_per_row() const { return onehot ? (size_t)4 * A * L : (codes ? (size_t)L : 0); }
 };
 
 // packed letters of rows [start, start+cnt) of a source; host sources go through h->letters
 int source_rows(crbm_handle* h, const RowSource& src, int start, int cnt, const uint32_t** out) {
-  const int LW = letter_words(src.L);
+  const int LW = lw(h, src.L);
   if (src.resident) {
     *out = src.resident + (size_t)start * LW;
     return CRBM_OK;
   }
   HIPCHK(h->letters.ensure((size_t)cnt * LW));
   *out = h->letters.p;
-  if (src.onehot) return encode_host(h, src.onehot + (size_t)start * 4 * src.L, cnt, src.L, h->letters.p);
+  if (src.onehot) return encode_host(h, src.onehot + (size_t)start * h->A * src.L, cnt, src.L, h->letters.p);
   return encode_codes_host(h, src.codes + (size_t)start * src.L, cnt, src.L, h->letters.p);
 }
 
@@ -1964,7 +1986,7 @@ int resident_source(crbm_handle* h, int start, int end, RowSource* src) {
   ARGCHK(start >= 0 && end > start && end <= h->dataset_n[slot], "row range out of bounds");
   src->L = h->dataset_L[slot];
   src->n = end - start;
-  src->resident = h->dataset[slot].p + (size_t)start * letter_words(src->L);
+  src->resident = h->dataset[slot].p + (size_t)start * lw(h, src->L);
   return CRBM_OK;
 }
 
@@ -1992,7 +2014,7 @@ int sweep_slab(const RowSource& src, size_t out_bytes_per_row) {
 }
 // enqueue staging + encoding of rows [start, start+cnt) on the set's stream (no flag check: sweep_finish)
 int sweep_rows(crbm_handle* h, const RowSource& src, int start, int cnt, const SweepSet& set, const uint32_t** out) {
-  const int L = src.L, LW = letter_words(L);
+  const int L = src.L, LW = lw(h, L);
   if (src.resident) {
     *out = src.resident + (size_t)start * LW;
     return CRBM_OK;
@@ -2001,13 +2023,14 @@ int sweep_rows(crbm_handle* h, const RowSource& src, int start, int cnt, const S
   *out = set.letters->p;
   const int grid = grid_for((long)cnt * LW, 256, h->num_cu * 8);
   if (src.onehot) {
-    const size_t count = (size_t)cnt * 4 * L;
+    const size_t count = (size_t)cnt * h->A * L;
     HIPCHK(set.stage->ensure(count));
-    HIPCHK(hipMemcpyAsync(set.stage->p, src.onehot + (size_t)start * 4 * L, count * sizeof(float), hipMemcpyHostToDevice, set.st));
+    HIPCHK(hipMemcpyAsync(set.stage->p, src.onehot + (size_t)start * h->A * L, count * sizeof(float), hipMemcpyHostToDevice, set.st));
     EncodeArgs a;
     a.v = set.stage->p; a.letters = set.letters->p; a.flags = h->d_flags;
-    a.n = cnt; a.L = L; a.LW = LW;
-    hipLaunchKernelGGL(encode_onehot_kernel, dim3(grid), dim3(256), 0, set.st, a);
+    a.n = cnt; a.L = L; a.LW = LW; a.A = h->A;
+    if (h->A == 4) hipLaunchKernelGGL(encode_onehot_kernel, dim3(grid), dim3(256), 0, set.st, a);
+    else hipLaunchKernelGGL(encode_onehot_any_kernel, dim3(grid), dim3(256), 0, set.st, a);
   } else {
     const size_t bytes = (size_t)cnt * L;
     HIPCHK(set.stage->ensure((bytes + 3) / 4));
@@ -2015,8 +2038,9 @@ int sweep_rows(crbm_handle* h, const RowSource& src, int start, int cnt, const S
     EncodeCodesArgs a;
     a.codes = reinterpret_cast<const unsigned char*>(set.stage->p);
     a.letters = set.letters->p; a.flags = h->d_flags;
-    a.n = cnt; a.L = L; a.LW = LW;
-    hipLaunchKernelGGL(encode_codes_kernel, dim3(grid), dim3(256), 0, set.st, a);
+    a.n = cnt; a.L = L; a.LW = LW; a.A = h->A;
+    if (h->A == 4) hipLaunchKernelGGL(encode_codes_kernel, dim3(grid), dim3(256), 0, set.st, a);
+    else hipLaunchKernelGGL(encode_codes_any_kernel, dim3(grid), dim3(256), 0, set.st, a);
   }
   HIPCHK(hipGetLastError());
   return CRBM_OK;
@@ -2067,7 +2091,7 @@ int launch_free_energy(crbm_handle* h, const uint32_t* rows, int n, int L, const
   FeArgs a;
   a.tables = h->d_tables;
   a.letters = rows;
-  a.n = n; a.L = L; a.Lh = L - h->M + 1; a.LW = letter_words(L);
+  a.n = n; a.L = L; a.Lh = L - h->M + 1; a.LW = lw(h, L);
   a.fe = set.oa->p; a.fem = set.ob->p;
   const unsigned gx = (unsigned)std::max(1, std::min((n + 3) / 4, h->num_cu * 8));
   HIPCHK(jit_launch(h->jk.free_energy, a, gx, 1, 256, (unsigned)tab_bytes(h), set.st));
@@ -2185,7 +2209,7 @@ int hit_summary_any(crbm_handle* h, const RowSource& src, float* hmax, float* hm
     }
     HitArgs a;
     a.tables = h->d_tables; a.letters = rows;
-    a.n = cnt; a.L = L; a.Lh = Lh; a.LW = letter_words(L);
+    a.n = cnt; a.L = L; a.Lh = Lh; a.LW = lw(h, L);
     a.hmax = hmax ? set.oa->p : nullptr;
     a.hsum = (hmean && nchunks == 1) ? set.ob->p : nullptr;
     a.hsum_fx = (hmean && nchunks > 1) ? reinterpret_cast<unsigned long long*>(set.ob->p) : nullptr;
@@ -2220,8 +2244,10 @@ int hit_summary_any(crbm_handle* h, const RowSource& src, float* hmax, float* hm
   return CRBM_OK;
 }
 
-static RowSource host_onehot(const float* v, int n, int L) { RowSource s; s.onehot = v; s.n = n; s.L = L; return s; }
-static RowSource host_codes(const uint8_t* c, int n, int L) { RowSource s; s.codes = c; s.n = n; s.L = L; return s; }
+static RowSource host_onehot_(const float* v, int n, int L, int A) { RowSource s; s.onehot = v; s.n = n; s.L = L; s.A = A; return s; }
+static RowSource host_codes_(const uint8_t* c, int n, int L, int A) { RowSource s; s.codes = c; s.n = n; s.L = L; s.A = A; return s; }
+#define host_onehot(v, n, L) host_onehot_(v, n, L, h->A)
+#define host_codes(c, n, L) host_codes_(c, n, L, h->A)
 
 }  // namespace
 
@@ -2319,19 +2345,20 @@ int crbm_eval_params(crbm_handle* h, float* twn, float* ic, float* medic) {
   std::vector<float> W((size_t)h->KAM);
   HIPCHK(hipMemcpyAsync(W.data(), h->dW, W.size() * 4, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
-  // convRBM.py:475-485 on 4*K*M numbers: host arithmetic in double
+  // convRBM.py:475-485 on A*K*M numbers: host arithmetic in double
+  const int A = h->A;
   double sq = 0.0, entsum = 0.0, medsum = 0.0;
-  std::vector<double> ent((size_t)M);
+  std::vector<double> ent((size_t)M), w((size_t)A);
   for (int k = 0; k < K; ++k) {
     for (int j = 0; j < M; ++j) {
-      double w[4], mx = -1e300, z = 0.0, e = 0.0;
-      for (int a = 0; a < 4; ++a) {
-        w[a] = W[(size_t)(k * 4 + a) * M + j];
+      double mx = -1e300, z = 0.0, e = 0.0;
+      for (int a = 0; a < A; ++a) {
+        w[a] = W[(size_t)(k * A + a) * M + j];
         sq += w[a] * w[a];
         mx = std::max(mx, w[a]);
       }
-      for (int a = 0; a < 4; ++a) z += std::exp(w[a] - mx);
-      for (int a = 0; a < 4; ++a) {
+      for (int a = 0; a < A; ++a) z += std::exp(w[a] - mx);
+      for (int a = 0; a < A; ++a) {
         const double p = std::exp(w[a] - mx) / z;
         if (p > 0.0) e -= p * std::log2(p);
       }
@@ -2342,8 +2369,9 @@ int crbm_eval_params(crbm_handle* h, float* twn, float* ic, float* medic) {
     medsum += ent[(size_t)(M / 2)];
   }
   *twn = (float)std::sqrt(sq / (double)h->KAM);
-  *ic = (float)(2.0 - entsum / ((double)K * M));
-  *medic = (float)(2.0 - medsum / (double)K);
+  const double full = std::log2((double)A);     // log2 of the alphabet size (:481-484); 2 bits for DNA
+  *ic = (float)(full - entsum / ((double)K * M));
+  *medic = (float)(full - medsum / (double)K);
   return CRBM_OK;
 }
 
@@ -2394,8 +2422,8 @@ int crbm_comm_broadcast_state(crbm_handle* h, int32_t root) {
   ENTER();
   if (!h->comm) return CRBM_OK;
   ARGCHK(root >= 0 && root < h->nranks, "root out of range");
-  struct { float* p; size_t n; } bufs[] = {{h->dW, (size_t)h->KAM}, {h->db, (size_t)h->K}, {h->dc, 4},
-                                           {h->dvW, (size_t)h->KAM}, {h->dvb, (size_t)h->K}, {h->dvc, 4}};
+  struct { float* p; size_t n; } bufs[] = {{h->dW, (size_t)h->KAM}, {h->db, (size_t)h->K}, {h->dc, (size_t)h->A},
+                                           {h->dvW, (size_t)h->KAM}, {h->dvb, (size_t)h->K}, {h->dvc, (size_t)h->A}};
   for (auto& b : bufs) {
     ncclResult_t r = g_rccl.Broadcast(b.p, b.p, b.n, ncclFloat, root, h->comm, h->stream);
     if (r != ncclSuccess) return fail(h, CRBM_ERR_RCCL, std::string("ncclBroadcast: ") + g_rccl.GetErrorString(r));
@@ -2486,7 +2514,7 @@ int crbm_train_local(crbm_handle* h, const float* D, int32_t n, int32_t L, float
   if (rc) return rc;
   ARGCHK(n >= 0, "n must be non-negative");
   if (n > 0) {   // n == 0: a rank that owns no row of a short last mini-batch contributes zeros
-    HIPCHK(h->letters.ensure((size_t)n * letter_words(L)));
+    HIPCHK(h->letters.ensure((size_t)n * lw(h, L)));
     rc = encode_host(h, D, n, L, h->letters.p);
     if (rc) return rc;
   }

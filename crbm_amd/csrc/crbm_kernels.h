@@ -1964,6 +1964,7 @@ struct UpdateArgs {
   int32_t L_data, Lf;
   int32_t data_off, n_d, model_off, n_m;   // offsets into sums
   float lr, momentum, rho, lambda_rate;
+  int32_t A;                                  // letters (big_update_kernel; the specialised update is compiled for 4)
 };
 
 // `nw`: when not null, the new W, b, c are also left there ([KAM][K][4], LDS of the caller);
@@ -2278,6 +2279,7 @@ struct EncodeArgs {
   uint32_t* letters;
   uint32_t* flags;
   int32_t n, L, LW;
+  int32_t A;          // letters (the *_any kernels; the 2-bit kernels are DNA)
 };
 
 __global__ void encode_onehot_kernel(EncodeArgs a) {
@@ -2304,6 +2306,34 @@ __global__ void encode_onehot_kernel(EncodeArgs a) {
   }
 }
 
+// one-hot fp32 (n,1,A,L) of any alphabet -> rows of bytes [n][LW] (four letters per word)
+__global__ void encode_onehot_any_kernel(EncodeArgs a) {
+  const long total = (long)a.n * a.LW;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int nn = (int)(i / a.LW);
+    const int w = (int)(i - (long)nn * a.LW);
+    uint32_t word = 0;
+    bool bad = false;
+    const float* base = a.v + (size_t)nn * a.A * a.L;
+    for (int t = 0; t < 4; ++t) {
+      const int p = w * 4 + t;
+      if (p < a.L) {
+        int ones = 0, zeros = 0;
+        uint32_t l = 0u;
+        for (int al = 0; al < a.A; ++al) {
+          const float v = base[(size_t)al * a.L + p];
+          if (v == 1.f) { if (!ones) l = (uint32_t)al; ++ones; }
+          zeros += v == 0.f;
+        }
+        bad |= (ones != 1) | (zeros != a.A - 1);
+        word |= l << (8 * t);
+      }
+    }
+    a.letters[i] = word;
+    if (bad) atomicOr(a.flags, 1u);
+  }
+}
+
 // letter codes (one byte per base: 0..3 = A,C,G,T as in sequences.py:9-17) -> packed
 // letters [n][LW]; flags[0] |= 1 on any other code.
 struct EncodeCodesArgs {
@@ -2311,6 +2341,7 @@ struct EncodeCodesArgs {
   uint32_t* letters;
   uint32_t* flags;
   int32_t n, L, LW;
+  int32_t A;
 };
 
 __global__ void encode_codes_kernel(EncodeCodesArgs a) {
@@ -2334,12 +2365,47 @@ __global__ void encode_codes_kernel(EncodeCodesArgs a) {
   }
 }
 
+// letter codes of any alphabet (one byte per letter, 0 .. A-1) -> rows of bytes [n][LW]; flags[0] |= 1 on any other code
+__global__ void encode_codes_any_kernel(EncodeCodesArgs a) {
+  const long total = (long)a.n * a.LW;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int nn = (int)(i / a.LW);
+    const int w = (int)(i - (long)nn * a.LW);
+    uint32_t word = 0;
+    bool bad = false;
+    const unsigned char* base = a.codes + (size_t)nn * a.L;
+    for (int t = 0; t < 4; ++t) {
+      const int p = w * 4 + t;
+      if (p < a.L) {
+        const uint32_t c = base[p];
+        bad |= c >= (uint32_t)a.A;
+        word |= (bad ? 0u : c) << (8 * t);
+      }
+    }
+    a.letters[i] = word;
+    if (bad) atomicOr(a.flags, 1u);
+  }
+}
+
 // packed letters -> one-hot fp32 (n,1,4,L)
 struct DecodeArgs {
   const uint32_t* letters;
   float* v;
   int32_t n, L, LW;
+  int32_t A;
 };
+
+// rows of bytes -> one-hot fp32 (n,1,A,L)
+__global__ void decode_onehot_any_kernel(DecodeArgs a) {
+  const long total = (long)a.n * a.L;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int nn = (int)(i / a.L);
+    const int p = (int)(i - (long)nn * a.L);
+    const uint32_t l = reinterpret_cast<const unsigned char*>(a.letters + (size_t)nn * a.LW)[p];
+    float* base = a.v + (size_t)nn * a.A * a.L + p;
+    for (int al = 0; al < a.A; ++al) base[(size_t)al * a.L] = l == (uint32_t)al ? 1.f : 0.f;
+  }
+}
 
 __global__ void decode_onehot_kernel(DecodeArgs a) {
   const long total = (long)a.n * a.L;
@@ -2476,6 +2542,70 @@ __global__ void __launch_bounds__(256) vgh_dense_kernel(VghArgs a) {
 }
 
 
+// The same for an alphabet of A != 4 letters: a thread keeps the A activations of its position in LDS
+// (yl[letter][thread]); filters straight from global memory (an API / test pass).
+struct VghAnyArgs {
+  VghArgs g;
+  int32_t A;
+};
+
+__global__ void __launch_bounds__(256) vgh_dense_any_kernel(VghAnyArgs aa) {
+  HIP_DYNAMIC_SHARED(float, smem);
+  const VghArgs& a = aa.g;
+  const int K = a.K, M = a.M, A = aa.A, CH = (int)blockDim.x, tid = (int)threadIdx.x;
+  float* yl = smem;   // [A][CH]
+  const long items = (long)a.n * a.L;
+  for (long i0 = (long)blockIdx.x * CH; i0 < items; i0 += (long)gridDim.x * CH) {
+    const long i = i0 + tid;
+    if (i >= items) continue;
+    const int nn = (int)(i / a.L), p = (int)(i - (long)nn * a.L);
+    for (int al = 0; al < A; ++al) yl[al * CH + tid] = a.c[al];
+    const int jlo = max(0, p - a.Lh + 1), jhi = min(M - 1, p);
+    for (int k = 0; k < K; ++k) {
+      const float* hrow = a.hid + ((size_t)nn * K + k) * a.Lh;
+      const float* hprow = a.hidp ? a.hidp + ((size_t)nn * K + k) * a.Lh : nullptr;
+      for (int j = jlo; j <= jhi; ++j) {
+        const float hv = hrow[p - j];
+        const float hp = hprow ? hprow[p - j] : 0.f;
+        for (int al = 0; al < A; ++al) {
+          float y = fmaf(a.W[((size_t)k * A + al) * M + j], hv, yl[al * CH + tid]);
+          if (hprow) y = fmaf(a.W[((size_t)k * A + (A - 1 - al)) * M + (M - 1 - j)], hp, y);   // rc(W)[k,a,j] = W[k,A-1-a,M-1-j]
+          yl[al * CH + tid] = y;
+        }
+      }
+    }
+    const size_t o = (size_t)nn * A * a.L + p;
+    float mx = yl[tid];
+    for (int al = 0; al < A; ++al) {
+      const float y = yl[al * CH + tid];
+      if (a.act) a.act[o + (size_t)al * a.L] = y;
+      mx = fmaxf(mx, y);
+    }
+    float sum = 0.f;
+    for (int al = 0; al < A; ++al) {
+      const float e = __expf(yl[al * CH + tid] - mx);
+      yl[al * CH + tid] = e;
+      sum += e;
+    }
+    if (a.prob) {
+      const float inv = 1.0f / sum;
+      for (int al = 0; al < A; ++al) a.prob[o + (size_t)al * a.L] = yl[al * CH + tid] * inv;
+    }
+    if (a.sample) {
+      const Philox4 r = philox4x32(a.rng.seq_offset + (uint32_t)nn, (uint32_t)(p >> 2),
+                                      rng_word2(a.kind, 0, 0, 0), a.rng.step, a.rng.seed_lo, a.rng.seed_hi);
+      const float t = u01(philox_pick(r, p & 3)) * sum;
+      float cum = 0.f;
+      int l = 0;
+      for (int al = 0; al < A - 1; ++al) {
+        cum += yl[al * CH + tid];
+        l += t >= cum ? 1 : 0;
+      }
+      for (int al = 0; al < A; ++al) a.sample[o + (size_t)al * a.L] = l == al ? 1.f : 0.f;
+    }
+  }
+}
+
 // ===========================================================================
 // The "big" path: models the LDS-resident kernels above do not take -- more than 256 motifs, motifs longer than 64
 // letters, or tables that exceed the LDS (120 x 40 double-stranded, 300 x 10, 8 x 100 ...).  The reference accepts any
@@ -2486,13 +2616,18 @@ __global__ void __launch_bounds__(256) vgh_dense_kernel(VghArgs a) {
 // boundary between the two paths without its samples changing beyond p == u ties (pooled models included).
 // ===========================================================================
 struct BigModel {
-  const float* W;   // (K,4,M)
+  const float* W;   // (K,A,M)
   const float* b;   // (K)
-  const float* c;   // (4)
+  const float* c;   // (A)
   int32_t K, M, ds, NW;
+  int32_t A;        // letters of the alphabet (input_dims, convRBM.py:68): 4 = DNA, rows of 2-bit letters; anything else: rows of bytes
 };
 
-__device__ __forceinline__ uint32_t letter_at(const uint32_t* row, int p) { return (row[p >> 4] >> (2 * (p & 15))) & 3u; }
+// letter p of a packed row: 16 two-bit letters per word (A == 4), else one byte per letter
+__device__ __forceinline__ uint32_t letter_at(const BigModel& m, const uint32_t* row, int p) {
+  if (m.A == 4) return (row[p >> 4] >> (2 * (p & 15))) & 3u;
+  return reinterpret_cast<const unsigned char*>(row)[p];
+}
 __device__ __forceinline__ float sigmoid_x(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 // block-wide sum in a fixed order (waves through DPP, then wave totals through LDS); all threads get the total
@@ -2542,8 +2677,9 @@ template <int KSM, bool POOLED>
 __device__ __forceinline__ void big_hgv_body(const BigHgvArgs& a) {
   HIP_DYNAMIC_SHARED(float, smem);
   const int K = a.m.K, M = a.m.M, KS = a.KS;
-  float* Ws = smem;                                            // [KS][M][4]
-  float* bs = Ws + (size_t)KS * M * 4;                         // [32]
+  const int A = a.m.A;
+  float* Ws = smem;                                            // [KS][M][A]
+  float* bs = Ws + (size_t)KS * M * A;                         // [32]
   uint32_t* let = reinterpret_cast<uint32_t*>(bs + 32);        // [TS][LW]
   const bool want_sample = a.sample || a.ones || a.masks;
   const uint32_t strand = a.mode == 1 ? 1u : 0u;
@@ -2557,27 +2693,27 @@ __device__ __forceinline__ void big_hgv_body(const BigHgvArgs& a) {
     for (int k0 = 0; k0 < K; k0 += KS) {
       const int kc = min(KS, K - k0);
       __syncthreads();
-      for (int i = threadIdx.x; i < kc * M * 4; i += blockDim.x) {
-        const int k = i / (4 * M), j = (i >> 2) % M, al = i & 3;
-        Ws[i] = a.m.W[((size_t)(k0 + k) * 4 + al) * M + j];
+      for (int i = threadIdx.x; i < kc * M * A; i += blockDim.x) {
+        const int k = i / (A * M), j = (i / A) % M, al = i % A;
+        Ws[i] = a.m.W[((size_t)(k0 + k) * A + al) * M + j];
       }
       if ((int)threadIdx.x < kc) bs[threadIdx.x] = a.m.b[k0 + threadIdx.x];
       __syncthreads();
       for (int it = threadIdx.x; it < items; it += blockDim.x) {
         const int nl = it / a.Lh, s = it - nl * a.Lh, nn = n0 + nl;
         const uint32_t* lrow = let + (size_t)nl * a.LW;
-        // x[k] = b[k] + sum_j W[k, l(pos+j), j]; rc strand: W[k, 3 - l(pos+j), M-1-j] (convRBM.py:241); mode 2: both, each with b
+        // x[k] = b[k] + sum_j W[k, l(pos+j), j]; rc strand: W[k, A-1 - l(pos+j), M-1-j] (convRBM.py:241); mode 2: both, each with b
         auto activations = [&](int pos, float (&x)[KSM]) {
 #pragma unroll
           for (int k = 0; k < KSM; ++k) x[k] = 0.f;
           for (int pass = 0; pass < (a.mode == 2 ? 2 : 1); ++pass) {
             const bool rc = a.mode == 1 || pass == 1;
             for (int j = 0; j < M; ++j) {
-              const uint32_t l = letter_at(lrow, pos + j);
-              const float* col = Ws + (size_t)((rc ? M - 1 - j : j) * 4 + (rc ? 3u - l : l));
+              const uint32_t l = letter_at(a.m, lrow, pos + j);
+              const float* col = Ws + (size_t)((rc ? M - 1 - j : j) * A + (int)(rc ? (uint32_t)(A - 1) - l : l));
 #pragma unroll
               for (int k = 0; k < KSM; ++k)
-                if (k < kc) x[k] += col[(size_t)k * M * 4];
+                if (k < kc) x[k] += col[(size_t)k * M * A];
             }
 #pragma unroll
             for (int k = 0; k < KSM; ++k)
@@ -2750,10 +2886,85 @@ __global__ void __launch_bounds__(256) big_vgh_kernel(BigVghArgs a) {
   }
 }
 
+// The same for an alphabet of A != 4 letters (input_dims, convRBM.py:68-71, :277-325): a thread owns ONE position of a
+// chunk of blockDim positions and keeps its A activations in LDS (yl[letter][thread]); the sample is written one byte
+// per letter.  The categorical draw is the reference's: the first letter whose cumulative probability exceeds u.
+__global__ void __launch_bounds__(256) big_vgh_any_kernel(BigVghArgs a) {
+  HIP_DYNAMIC_SHARED(float, smem);
+  const int K = a.m.K, M = a.m.M, NW = a.m.NW, JS = a.JS, A = a.m.A;
+  const int CH = (int)blockDim.x, tid = (int)threadIdx.x;
+  float* Wt = smem;                                                   // [JS][32][A]: W[k, 0..A-1, j] of the slab
+  float* yl = Wt + (size_t)JS * 32 * A;                               // [A][CH]
+  unsigned char* lb = reinterpret_cast<unsigned char*>(yl + (size_t)A * CH);   // [CH] letters of a chunk
+  for (int chain = blockIdx.x; chain < a.nchains; chain += gridDim.x) {
+    const uint32_t gn = a.rng.seq_offset + (uint32_t)chain;
+    for (int c0 = 0; c0 < a.Lv; c0 += CH) {
+      const int p = c0 + tid;
+      for (int al = 0; al < A; ++al) yl[al * CH + tid] = a.m.c[al];
+      for (int w = 0; w < NW; ++w)
+        for (int j0 = 0; j0 < M; j0 += JS) {
+          const int jc = min(JS, M - j0), kc = min(32, K - 32 * w);
+          __syncthreads();
+          for (int i = tid; i < jc * 32 * A; i += CH) {
+            const int al = i % A, k = (i / A) & 31, j = i / (32 * A);
+            Wt[i] = k < kc ? a.m.W[((size_t)(32 * w + k) * A + al) * M + (j0 + j)] : 0.f;
+          }
+          __syncthreads();
+          if (p < a.Lv)
+            for (int strand = 0; strand <= (a.hmp ? 1 : 0); ++strand) {
+              const uint32_t* hrow = (strand ? a.hmp : a.hm) + (size_t)chain * a.Lf * NW + w;
+              for (int j = 0; j < jc; ++j) {
+                const int jj = j0 + j;
+                const int s = strand ? p - (M - 1 - jj) : p - jj;       // rc(W)[k,a,j] = W[k,A-1-a,M-1-j]
+                if (s < 0 || s >= a.Lf) continue;
+                uint32_t bits = hrow[(size_t)s * NW];
+                while (bits) {
+                  const int k = __ffs(bits) - 1;
+                  bits &= bits - 1u;
+                  const float* t = Wt + (size_t)(j * 32 + k) * A;
+                  for (int al = 0; al < A; ++al) yl[al * CH + tid] += t[strand ? A - 1 - al : al];
+                }
+              }
+            }
+        }
+      if (p < a.Lv) {
+        float mx = yl[tid];
+        for (int al = 1; al < A; ++al) mx = fmaxf(mx, yl[al * CH + tid]);
+        float tot = 0.f;
+        for (int al = 0; al < A; ++al) {
+          const float e = __expf(yl[al * CH + tid] - mx);
+          yl[al * CH + tid] = e;
+          tot += e;
+        }
+        const Philox4 rr = philox4x32(gn, (uint32_t)(p >> 2), rng_word2(KIND_CHAIN_V, 0, 0, 0), a.rng.step, a.rng.seed_lo, a.rng.seed_hi);
+        const float t = u01(philox_pick(rr, p & 3)) * tot;
+        float cum = 0.f;
+        int l = 0;
+        for (int al = 0; al < A - 1; ++al) {
+          cum += yl[al * CH + tid];
+          l += t >= cum ? 1 : 0;
+        }
+        lb[tid] = (unsigned char)l;
+      }
+      __syncthreads();
+      // four letters per word (CH is a multiple of 4: the chunks start on word boundaries); the row's pad words stay zero
+      const int nw = (min(CH, a.Lv - c0) + 3) / 4;
+      for (int wi = tid; wi < nw; wi += CH) {
+        uint32_t word = 0u;
+        for (int t = 0; t < 4; ++t)
+          if (c0 + 4 * wi + t < a.Lv) word |= (uint32_t)lb[4 * wi + t] << (8 * t);
+        a.vout[(size_t)chain * a.LWs + (c0 >> 2) + wi] = word;
+      }
+      __syncthreads();
+    }
+    for (int wi = (a.Lv + 3) / 4 + tid; wi < a.LWs; wi += CH) a.vout[(size_t)chain * a.LWs + wi] = 0u;
+  }
+}
+
 // ---- gradient statistics (convRBM.py:327-371) and the sparsity sums (:440-451), raw sums into partial rows of the layout
 // the column reduction expects.  Block (k, r): motif k, rows r, r + R, ...; the motif's filter, a chunk of letters and
 // the probabilities of the chunk's positions sit in LDS; thread t accumulates VH[k, a, j] for (a, j) = t / M, t % M.
-constexpr int BIG_ST = 8;                                   // (a, j) slots per thread: 4 M <= BIG_ST * blockDim
+constexpr int BIG_ST = 8;                                   // (a, j) slots per thread: A M <= BIG_ST * blockDim
 struct BigStatsArgs {
   BigModel m;
   const uint32_t* letters;
@@ -2766,8 +2977,8 @@ struct BigStatsArgs {
 
 __global__ void __launch_bounds__(256) big_stats_kernel(BigStatsArgs a) {
   HIP_DYNAMIC_SHARED(float, smem);
-  const int M = a.m.M, k = blockIdx.x, r = blockIdx.y, AM = 4 * M, CH = a.CH;
-  float* Wk = smem;                                         // [4][M]
+  const int M = a.m.M, k = blockIdx.x, r = blockIdx.y, A = a.m.A, AM = A * M, CH = a.CH;
+  float* Wk = smem;                                         // [A][M]
   float* P = Wk + ((AM + 3) & ~3);                          // [CH] each
   float* Pp = P + CH;
   float* Q = Pp + CH;
@@ -2775,24 +2986,27 @@ __global__ void __launch_bounds__(256) big_stats_kernel(BigStatsArgs a) {
   float* Xp = X + (a.pool > 1 ? CH : 0);
   float* xch = Xp + (a.pool > 1 ? CH : 0);                  // [16]
   float* red = xch + 16;                                    // [3][blockDim]: slices of a (letter, column) meet here
-  unsigned char* lb = reinterpret_cast<unsigned char*>(red + 3 * blockDim.x);   // [CH + M]
+  uint32_t* cnt = reinterpret_cast<uint32_t*>(red + 3 * blockDim.x);   // [A] letter counts (blocks of motif 0)
+  unsigned char* lb = reinterpret_cast<unsigned char*>(cnt + ((A + 3) & ~3));   // [CH + M]
   for (int i = threadIdx.x; i < AM; i += blockDim.x) Wk[i] = a.m.W[(size_t)k * AM + i];
+  for (int i = threadIdx.x; i < A; i += blockDim.x) cnt[i] = 0u;
   const float bk = a.m.b[k];
   float vh[BIG_ST], vhp[BIG_ST], sw[BIG_ST];
 #pragma unroll
   for (int t = 0; t < BIG_ST; ++t) vh[t] = vhp[t] = sw[t] = 0.f;
-  const int nsl = AM <= (int)blockDim.x ? (int)blockDim.x / AM : 0;    // position slices per (letter, column); 0: 4 M > blockDim
-  float hsum = 0.f, hpsum = 0.f, qsum = 0.f, cnt[4] = {0.f, 0.f, 0.f, 0.f};
+  const int nsl = AM <= (int)blockDim.x ? (int)blockDim.x / AM : 0;    // position slices per (letter, column); 0: A M > blockDim
+  float hsum = 0.f, hpsum = 0.f, qsum = 0.f;
   for (int nn = r; nn < a.n; nn += a.R) {
     const uint32_t* lrow = a.letters + (size_t)nn * a.LW;
     for (int c0 = 0; c0 < a.Lh; c0 += CH) {
       const int cl = min(CH, a.Lh - c0), nl = cl + M - 1;     // positions of the chunk, letters they see
       __syncthreads();
       for (int i = threadIdx.x; i < nl; i += blockDim.x) {
-        const uint32_t l = letter_at(lrow, c0 + i);
+        const uint32_t l = letter_at(a.m, lrow, c0 + i);
         lb[i] = (unsigned char)l;
         // every visible position once: the chunk's own positions, the last chunk also the M - 1 behind them
-        if (k == 0 && (i < cl || c0 + cl == a.Lh)) { cnt[0] += l == 0u; cnt[1] += l == 1u; cnt[2] += l == 2u; cnt[3] += l == 3u; }
+        // (integer counts: the same total whatever the order)
+        if (k == 0 && (i < cl || c0 + cl == a.Lh)) atomicAdd(&cnt[l], 1u);
       }
       __syncthreads();
       for (int s = threadIdx.x; s < cl; s += blockDim.x) {
@@ -2800,7 +3014,7 @@ __global__ void __launch_bounds__(256) big_stats_kernel(BigStatsArgs a) {
         for (int j = 0; j < M; ++j) {
           const int l = lb[s + j];
           x += Wk[l * M + j];
-          if (a.m.ds) xr += Wk[(3 - l) * M + (M - 1 - j)];
+          if (a.m.ds) xr += Wk[(A - 1 - l) * M + (M - 1 - j)];
         }
         if (a.pool > 1) { X[s] = x; Xp[s] = xr; continue; }
         const float p = sigmoid_x(x), pp = a.m.ds ? sigmoid_x(xr) : 0.f, q = a.want_sparsity ? p * (1.0f - p) : 0.f;
@@ -2894,17 +3108,14 @@ __global__ void __launch_bounds__(256) big_stats_kernel(BigStatsArgs a) {
     if (a.want_sparsity) out[a.off_sb + k] = Sb;
   }
   if (k == 0) {
-#pragma unroll
-    for (int l = 0; l < 4; ++l) {
-      const float t = big_block_sum(cnt[l], xch);
-      if (threadIdx.x == 0) out[a.off_v + l] = t;
-    }
+    __syncthreads();
+    for (int l = threadIdx.x; l < A; l += blockDim.x) out[a.off_v + l] = (float)cnt[l];
   }
 }
 
 // ---- the update (convRBM.py:358-371, :415-436, :440-451), element-wise and in place, any number of blocks
 __global__ void __launch_bounds__(256) big_update_kernel(UpdateArgs a) {
-  const int K = a.K, M = a.M, KAM = K * 4 * M;
+  const int K = a.K, M = a.M, A = a.A, KAM = K * A * M;
   const float* S = a.sums;
   const float n_d = S[a.n_d], n_m = S[a.n_m];
   const float cnt_d = n_d * (float)(a.L_data - M + 1), cnt_m = n_m * (float)a.Lf;
@@ -2912,11 +3123,11 @@ __global__ void __launch_bounds__(256) big_update_kernel(UpdateArgs a) {
   const int d_sw = d_vh + 2 * KAM + 2 * K, d_sb = d_sw + KAM, d_v = d_sb + K;
   const int m_vh = a.model_off, m_vhp = m_vh + KAM, m_h = m_vh + 2 * KAM, m_hp = m_h + K, m_v = m_hp + K;
   const float q = a.rho;
-  const int total = KAM + K + 4;
+  const int total = KAM + K + A;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     if (i < KAM) {
-      const int k = i / (4 * M), al = (i / M) & 3, j = i % M;
-      const int ri = (k * 4 + (3 - al)) * M + (M - 1 - j);
+      const int k = i / (A * M), al = (i / M) % A, j = i % M;
+      const int ri = (k * A + (A - 1 - al)) * M + (M - 1 - j);
       float gd = S[d_vh + i] / cnt_d, gm = S[m_vh + i] / cnt_m;
       if (a.ds) {
         gd = 0.5f * (gd + S[d_vhp + ri] / cnt_d);
@@ -2945,8 +3156,8 @@ __global__ void __launch_bounds__(256) big_update_kernel(UpdateArgs a) {
     } else {
       const int al = i - KAM - K;
       const float nd = n_d * (float)a.L_data, nm = n_m * (float)(a.Lf + M - 1);
-      const float gd = S[d_v + al] / nd + S[d_v + 3 - al] / nd;     // a += a[::-1]  (:345)
-      const float gm = S[m_v + al] / nm + S[m_v + 3 - al] / nm;
+      const float gd = S[d_v + al] / nd + S[d_v + A - 1 - al] / nd;     // a += a[::-1]  (:345)
+      const float gm = S[m_v + al] / nm + S[m_v + A - 1 - al] / nm;
       const float v = a.momentum * a.vc[al] + a.lr * (gd - gm);
       a.ovc[al] = v;
       a.oc[al] = a.c[al] + v;
@@ -2971,8 +3182,8 @@ struct BigEvalArgs {
 
 __global__ void __launch_bounds__(256) big_eval_kernel(BigEvalArgs a) {
   HIP_DYNAMIC_SHARED(float, smem);
-  const int K = a.m.K, M = a.m.M, AM = 4 * M;
-  float* Wk = smem;                                                  // [4][M]
+  const int K = a.m.K, M = a.m.M, A = a.m.A, AM = A * M;
+  float* Wk = smem;                                                  // [A][M]
   float* xch = Wk + ((AM + 3) & ~3);                                 // [16]
   unsigned char* lb = reinterpret_cast<unsigned char*>(xch + 16);    // [L]
   for (int nn = blockIdx.x; nn < a.n; nn += gridDim.x) {
@@ -2980,7 +3191,7 @@ __global__ void __launch_bounds__(256) big_eval_kernel(BigEvalArgs a) {
     __syncthreads();
     float csl = 0.f;
     for (int p = threadIdx.x; p < a.L; p += blockDim.x) {
-      const uint32_t l = letter_at(lrow, p);
+      const uint32_t l = letter_at(a.m, lrow, p);
       lb[p] = (unsigned char)l;
       csl += a.m.c[l];
     }
@@ -2997,7 +3208,7 @@ __global__ void __launch_bounds__(256) big_eval_kernel(BigEvalArgs a) {
         for (int j = 0; j < M; ++j) {
           const int l = lb[s + j];
           x += Wk[l * M + j];
-          xr += Wk[(3 - l) * M + (M - 1 - j)];
+          xr += Wk[(A - 1 - l) * M + (M - 1 - j)];
         }
       };
       if (a.pool > 1) {

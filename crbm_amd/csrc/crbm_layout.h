@@ -38,6 +38,9 @@ struct RngView {
 // window read (three words from the word of its first letter for M <= 32, five for
 // M <= 64: crbm_kernels.h, letter_window) never leaves the row.
 inline int letter_words(int L) { return (L + 15) / 16 + 2; }
+// Alphabets of A != 4 letters (input_dims, convRBM.py:68; generic kernels only): one byte per letter, four per word,
+// the same two pad words.
+inline int letter_words_any(int A, int L) { return A == 4 ? letter_words(L) : (L + 3) / 4 + 2; }
 // Largest motif length the letter windows hold (two 64-bit words); the number of motifs is
 // bounded by what the LDS holds (tables + one chain: choose_gibbs_geometry refuses beyond)
 // and by the statistics kernel (one role of 64 threads per 16 motifs, at most 1024 threads per block).
@@ -264,10 +267,10 @@ struct SumsLayout {
   int data_off, n_d, model_off, n_m, count;
   int model_skip_begin, model_skip_len;   // sw,sb are not carried for the model half
 };
-inline SumsLayout sums_layout(int K, int M) {
+inline SumsLayout sums_layout(int K, int M, int A = 4) {
   SumsLayout s;
-  const int KAM = K * 4 * M;
-  const int row = 3 * KAM + 3 * K + 4;
+  const int KAM = K * A * M;
+  const int row = 3 * KAM + 3 * K + A;
   s.data_off = 0;
   s.n_d = row;
   s.model_off = row + 1;

@@ -50,7 +50,7 @@ typedef enum crbm_status {
 typedef struct crbm_config {
   int32_t num_motifs;          /* K                                   :111 */
   int32_t motif_length;        /* M  (1..64)                          :112 */
-  int32_t input_dims;          /* A, must be 4                        :113 */
+  int32_t input_dims;          /* A: 4 = DNA; 1..64 otherwise (generic kernels) :113 */
   int32_t doublestranded;      /* 0/1                                 :114 */
   int32_t batchsize;           /* number of persistent fantasy chains :115 */
   int32_t cd_k;                /* Gibbs steps per update              :121 */

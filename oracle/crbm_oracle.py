@@ -166,17 +166,17 @@ def visible_uniforms(seed, step, seq_index, L, kind=KIND_CHAIN_V):
 # ----------------------------------------------------------------------------
 # helpers
 # ----------------------------------------------------------------------------
-def synthetic_onehot(n, L, seed=1234, dtype=np.float32):
-    """(n,1,4,L) one-hot array, letters i.i.d. uniform."""
+def synthetic_onehot(n, L, seed=1234, dtype=np.float32, A=4):
+    """(n,1,A,L) one-hot array, letters i.i.d. uniform (A = input_dims, 4 for DNA)."""
     rng = np.random.default_rng(seed)
-    letters = rng.integers(0, 4, size=(n, L))
-    return onehot_of(letters, dtype)
+    letters = rng.integers(0, A, size=(n, L))
+    return onehot_of(letters, dtype, A)
 
 
-def onehot_of(letters, dtype=np.float32):
+def onehot_of(letters, dtype=np.float32, A=4):
     letters = np.asarray(letters)
     n, L = letters.shape
-    out = np.zeros((n, 1, 4, L), dtype=dtype)
+    out = np.zeros((n, 1, A, L), dtype=dtype)
     out[np.arange(n)[:, None], 0, letters, np.arange(L)[None, :]] = 1
     return out
 
@@ -339,7 +339,7 @@ class OracleCRBM:
         N, _, A, L = prob.shape
         cum = np.cumsum(prob[:, 0], axis=1)                    # (N,A,L)
         idx = np.sum(cum[:, :A - 1, :] <= u[:, None, :], axis=1)   # (N,L)
-        return onehot_of(idx, np.float64)
+        return onehot_of(idx, np.float64, A)
 
     def _computeVgivenH(self, h, hprime=None, u=None):
         """convRBM.py:317-325."""

@@ -90,14 +90,49 @@ int emu_case_info(int id, int* out) {   // K, M, DS, G, TABLES, NW, DENSE, POOL
 }
 
 int emu_encode(const float* v, uint32_t* letters, uint32_t* flags, int n, int L, int grid) {
-  EncodeArgs a{v, letters, flags, n, L, letter_words(L)};
+  EncodeArgs a{v, letters, flags, n, L, letter_words(L), 4};
   emu::launch([&] { encode_onehot_kernel(a); }, dim3(grid), dim3(64), 0);
   return 0;
 }
 
 int emu_decode(const uint32_t* letters, float* v, int n, int L, int LW, int grid) {
-  DecodeArgs a{letters, v, n, L, LW};
+  DecodeArgs a{letters, v, n, L, LW, 4};
   emu::launch([&] { decode_onehot_kernel(a); }, dim3(grid), dim3(64), 0);
+  return 0;
+}
+
+// any alphabet (A != 4: rows of bytes); codes != null: letter codes instead of one-hot floats
+int emu_encode_any(const float* v, const unsigned char* codes, uint32_t* letters, uint32_t* flags, int n, int L, int A, int grid) {
+  if (codes) {
+    EncodeCodesArgs a{codes, letters, flags, n, L, letter_words_any(A, L), A};
+    if (A == 4) emu::launch([&] { encode_codes_kernel(a); }, dim3(grid), dim3(64), 0);
+    else emu::launch([&] { encode_codes_any_kernel(a); }, dim3(grid), dim3(64), 0);
+    return 0;
+  }
+  EncodeArgs a{v, letters, flags, n, L, letter_words_any(A, L), A};
+  if (A == 4) emu::launch([&] { encode_onehot_kernel(a); }, dim3(grid), dim3(64), 0);
+  else emu::launch([&] { encode_onehot_any_kernel(a); }, dim3(grid), dim3(64), 0);
+  return 0;
+}
+
+int emu_decode_any(const uint32_t* letters, float* v, int n, int L, int LW, int A, int grid) {
+  DecodeArgs a{letters, v, n, L, LW, A};
+  if (A == 4) emu::launch([&] { decode_onehot_kernel(a); }, dim3(grid), dim3(64), 0);
+  else emu::launch([&] { decode_onehot_any_kernel(a); }, dim3(grid), dim3(64), 0);
+  return 0;
+}
+
+// dense v | h of any alphabet (vgh_dense_any_kernel)
+int emu_vgh_any(const float* W, const float* c, int K, int M, int A, const float* hid, const float* hidp, int n, int Lh,
+                float* act, float* prob, float* sample, uint64_t seed, uint32_t step, uint32_t off, int grid, int threads) {
+  VghAnyArgs aa;
+  VghArgs& a = aa.g;
+  a.W = W; a.c = c; a.K = K; a.M = M; a.hid = hid; a.hidp = hidp; a.n = n; a.Lh = Lh; a.L = Lh + M - 1;
+  a.TS = 1; a.divL = make_fastdiv((uint32_t)a.L);
+  a.act = act; a.prob = prob; a.sample = sample;
+  a.rng = make_rng(seed, step, off); a.kind = KIND_API_V;
+  aa.A = A;
+  emu::launch([&] { vgh_dense_any_kernel(aa); }, dim3(grid), dim3(threads), (size_t)A * threads * 4);
   return 0;
 }
 
@@ -434,23 +469,23 @@ int emu_hit_summary(int id, const float* tables, const uint32_t* letters, int n,
 
 
 // ---- the generic ("big") kernels: run-time K and M -------------------------------------------------------------------
-static BigModel big_model_of(const float* W, const float* b, const float* c, int K, int M, int ds) {
+static BigModel big_model_of(const float* W, const float* b, const float* c, int K, int M, int ds, int A) {
   BigModel m;
-  m.W = W; m.b = b; m.c = c; m.K = K; m.M = M; m.ds = ds; m.NW = (K + 31) / 32;
+  m.W = W; m.b = b; m.c = c; m.K = K; m.M = M; m.ds = ds; m.NW = (K + 31) / 32; m.A = A;
   return m;
 }
 
 int emu_big_hgv(const float* W, const float* b, const float* c, int K, int M, int ds, const uint32_t* letters, int n, int L,
                 int mode, float* act, float* prob, float* sample, unsigned long long* ones, uint32_t* masks, uint64_t seed,
-                uint32_t step, uint32_t off, uint32_t kind, int TS, int KS, int grid, int threads, int pool) {
+                uint32_t step, uint32_t off, uint32_t kind, int TS, int KS, int grid, int threads, int pool, int A) {
   BigHgvArgs a;
-  a.m = big_model_of(W, b, c, K, M, ds);
+  a.m = big_model_of(W, b, c, K, M, ds, A);
   a.pool = pool;
-  a.letters = letters; a.n = n; a.L = L; a.Lh = L - M + 1; a.LW = letter_words(L);
+  a.letters = letters; a.n = n; a.L = L; a.Lh = L - M + 1; a.LW = letter_words_any(A, L);
   a.TS = TS; a.KS = KS; a.mode = mode;
   a.act = act; a.prob = prob; a.sample = sample; a.ones = ones; a.masks = masks;
   a.rng = make_rng(seed, step, off); a.kind = kind;
-  const size_t lds = ((size_t)KS * M * 4 + 32) * 4 + (size_t)TS * a.LW * 4;
+  const size_t lds = ((size_t)KS * M * A + 32) * 4 + (size_t)TS * a.LW * 4;
   if (pool > 1) {
     if (KS > 8) return -2;
     emu::launch([&] { big_hgv_pooled_kernel(a); }, dim3(grid), dim3(threads), lds);
@@ -462,72 +497,77 @@ int emu_big_hgv(const float* W, const float* b, const float* c, int K, int M, in
 // one Gibbs step: v | h from the masks, then h | v per strand into the masks; returns the letter words per row of vout
 int emu_big_gibbs_step(const float* W, const float* b, const float* c, int K, int M, int ds, uint32_t* hm, uint32_t* hmp,
                        uint32_t* vout, int nchains, int Lf, uint64_t seed, uint32_t step, uint32_t off, int JS, int KS,
-                       int grid, int threads, int pool) {
-  const int Lv = Lf + M - 1, LWs = letter_words(Lv);
+                       int grid, int threads, int pool, int A) {
+  const int Lv = Lf + M - 1, LWs = letter_words_any(A, Lv);
   if (!vout) return LWs;
   BigVghArgs v;
-  v.m = big_model_of(W, b, c, K, M, ds);
+  v.m = big_model_of(W, b, c, K, M, ds, A);
   v.hm = hm; v.hmp = ds ? hmp : nullptr; v.vout = vout;
   v.nchains = nchains; v.Lf = Lf; v.Lv = Lv; v.LWs = LWs; v.JS = JS;
   v.rng = make_rng(seed, step, off);
-  emu::launch([&] { big_vgh_kernel(v); }, dim3(grid), dim3(threads), (size_t)JS * 32 * 16 + (size_t)BIG_VR * threads);
+  if (A == 4) emu::launch([&] { big_vgh_kernel(v); }, dim3(grid), dim3(threads), (size_t)JS * 32 * 16 + (size_t)BIG_VR * threads);
+  else emu::launch([&] { big_vgh_any_kernel(v); }, dim3(grid), dim3(threads), ((size_t)JS * 32 * A + (size_t)A * threads) * 4 + threads);
   for (int strand = 0; strand <= ds; ++strand)
     emu_big_hgv(W, b, c, K, M, ds, vout, nchains, Lv, strand, nullptr, nullptr, nullptr, nullptr, strand ? hmp : hm, seed, step, off,
-                KIND_CHAIN_H, 2, KS, grid, threads, pool);
+                KIND_CHAIN_H, 2, KS, grid, threads, pool, A);
   return LWs;
 }
 
 // raw sums of one half: partial rows through big_stats_kernel, then the host column reduce of the harness
 int emu_big_stats(const float* W, const float* b, const float* c, int K, int M, int ds, const uint32_t* letters, int n, int L,
-                  int LW, int want_sparsity, int R, int CH, int threads, float* sums, int skip_begin, int skip_len, int pool) {
-  const int KAM = K * 4 * M, row = 3 * KAM + 3 * K + 4;
+                  int LW, int want_sparsity, int R, int CH, int threads, float* sums, int skip_begin, int skip_len, int pool, int A) {
+  const int KAM = K * A * M, row = 3 * KAM + 3 * K + A;
   std::vector<float> partials((size_t)R * row, -777.0f);      // what a launch does not write must not be read
   BigStatsArgs a;
-  a.m = big_model_of(W, b, c, K, M, ds);
+  a.m = big_model_of(W, b, c, K, M, ds, A);
   a.letters = letters; a.n = n; a.L = L; a.Lh = L - M + 1; a.LW = LW;
   a.want_sparsity = want_sparsity; a.R = R; a.CH = CH; a.pool = pool;
   if (CH % pool != 0) return -3;
   a.partials = partials.data();
   a.row = row; a.off_vh0 = 0; a.off_vh1 = KAM; a.off_h0 = 2 * KAM; a.off_h1 = 2 * KAM + K;
   a.off_sw = 2 * KAM + 2 * K; a.off_sb = 3 * KAM + 2 * K; a.off_v = 3 * KAM + 3 * K;
-  if (4 * M > BIG_ST * threads) return -2;
+  if (A * M > BIG_ST * threads) return -2;
   emu::launch([&] { big_stats_kernel(a); }, dim3(K, R), dim3(threads),
-              (((size_t)4 * M + 3) & ~(size_t)3) * 4 + (size_t)(pool > 1 ? 5 : 3) * CH * 4 + 64 + (size_t)3 * threads * 4 + (size_t)CH + M);
+              (((size_t)A * M + 3) & ~(size_t)3) * 4 + (size_t)(pool > 1 ? 5 : 3) * CH * 4 + 64 + (size_t)3 * threads * 4 +
+                  (size_t)((A + 3) & ~3) * 4 + (size_t)CH + M);
   host_reduce(partials.data(), R, row, K, KAM, ds, want_sparsity, skip_begin, skip_len, (float)n, sums);
   return row;
 }
 
 int emu_big_update(const float* sums, float* W, float* b, float* c, float* vW, float* vb, float* vc, int K, int M, int ds,
-                   int L_data, int Lf, float lr, float momentum, float rho, float lambda_rate, int grid, int threads) {
-  const SumsLayout sl = sums_layout(K, M);
+                   int L_data, int Lf, float lr, float momentum, float rho, float lambda_rate, int grid, int threads, int A) {
+  const SumsLayout sl = sums_layout(K, M, A);
   UpdateArgs u{sums, W, b, c, vW, vb, vc, W, b, c, vW, vb, vc, K, M, ds, L_data, Lf,
-               sl.data_off, sl.n_d, sl.model_off, sl.n_m, lr, momentum, rho, lambda_rate};
+               sl.data_off, sl.n_d, sl.model_off, sl.n_m, lr, momentum, rho, lambda_rate, A};
   emu::launch([&] { big_update_kernel(u); }, dim3(grid), dim3(threads), 0);
   return 0;
 }
 
 int emu_big_eval(const float* W, const float* b, const float* c, int K, int M, int ds, const uint32_t* letters, int n, int L,
-                 int hits, float* fe, float* fem, float* hmax, float* hmean, float* pos, int grid, int threads, int pool) {
+                 int hits, float* fe, float* fem, float* hmax, float* hmean, float* pos, int grid, int threads, int pool, int A) {
   BigEvalArgs a;
   a.pool = pool;
-  a.m = big_model_of(W, b, c, K, M, ds);
-  a.letters = letters; a.n = n; a.L = L; a.Lh = L - M + 1; a.LW = letter_words(L);
+  a.m = big_model_of(W, b, c, K, M, ds, A);
+  a.letters = letters; a.n = n; a.L = L; a.Lh = L - M + 1; a.LW = letter_words_any(A, L);
   a.fe = fe; a.fem = fem; a.hmax = hmax; a.hmean = hmean; a.hits = hits;
   std::vector<unsigned long long> pos_fx((size_t)K * a.Lh, 0ull);
   a.pos_fx = (hits && pos) ? pos_fx.data() : nullptr;
-  emu::launch([&] { big_eval_kernel(a); }, dim3(grid), dim3(threads), (((size_t)4 * M + 3) & ~(size_t)3) * 4 + 64 + (size_t)L);
+  emu::launch([&] { big_eval_kernel(a); }, dim3(grid), dim3(threads), (((size_t)A * M + 3) & ~(size_t)3) * 4 + 64 + (size_t)L);
   if (hits && pos)
     for (size_t i = 0; i < pos_fx.size(); ++i) pos[i] = (float)((double)pos_fx[i] / (double)HIT_FX);
   return 0;
 }
 
-int emu_sums_layout(int K, int M, int* out) {
-  const SumsLayout s = sums_layout(K, M);
+int emu_sums_layout_any(int K, int M, int A, int* out);
+int emu_sums_layout(int K, int M, int* out) { return emu_sums_layout_any(K, M, 4, out); }
+int emu_sums_layout_any(int K, int M, int A, int* out) {
+  const SumsLayout s = sums_layout(K, M, A);
   out[0] = s.data_off; out[1] = s.n_d; out[2] = s.model_off; out[3] = s.n_m; out[4] = s.count;
   out[5] = s.model_skip_begin; out[6] = s.model_skip_len;
   return 0;
 }
 
 int emu_letter_words(int L) { return letter_words(L); }
+int emu_letter_words_any(int A, int L) { return letter_words_any(A, L); }
 
 }  // extern "C"

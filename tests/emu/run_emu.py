@@ -32,7 +32,7 @@ def f32(x):
 
 
 def model_arrays(o):
-    return f32(o.W.reshape(o.num_motifs, 4, o.motif_length)), f32(o.b.ravel()), f32(o.c.ravel())
+    return f32(o.W.reshape(o.num_motifs, o.input_dims, o.motif_length)), f32(o.b.ravel()), f32(o.c.ravel())
 
 
 def case_info(cid):
@@ -51,11 +51,14 @@ def build_tables(cid, o):
 
 
 def encode(data):
-    n, L = data.shape[0], data.shape[3]
-    LW = lib.emu_letter_words(L)
+    n, A, L = data.shape[0], data.shape[2], data.shape[3]
+    LW = lib.emu_letter_words_any(A, L)
     letters = np.zeros((n, LW), dtype=np.uint32)
     flags = np.zeros(4, dtype=np.uint32)
-    lib.emu_encode(fp(f32(data)), up(letters), up(flags), n, L, 3)
+    if A == 4:
+        lib.emu_encode(fp(f32(data)), up(letters), up(flags), n, L, 3)
+    else:                                   # any other alphabet: rows of bytes
+        lib.emu_encode_any(fp(f32(data)), None, up(letters), up(flags), n, L, A, 3)
     return letters, int(flags[0])
 
 
@@ -93,11 +96,11 @@ def close_vh(got, want, rtol=2e-5):
     np.testing.assert_allclose(got, want, rtol=rtol, atol=1e-6 + 4e-7 * 4 * float(np.abs(want).max()))
 
 
-def make_oracle(K, M, ds, seed=0, batch=4, Lf=20, cd_k=2, wscale=1.0, **kw):
+def make_oracle(K, M, ds, seed=0, batch=4, Lf=20, cd_k=2, wscale=1.0, A=4, **kw):
     rng = np.random.default_rng(100 + K * 31 + M)
-    o = OracleCRBM(K, M, doublestranded=ds, batchsize=batch, cd_k=cd_k, fantasy_hidden_len=Lf, seed=seed,
-                   W=rng.standard_normal((K, 1, 4, M)) * wscale, **kw)
-    o.c = f32(rng.standard_normal((1, 4)) * 0.2).astype(np.float64)
+    o = OracleCRBM(K, M, doublestranded=ds, batchsize=batch, cd_k=cd_k, fantasy_hidden_len=Lf, seed=seed, input_dims=A,
+                   W=rng.standard_normal((K, 1, A, M)) * wscale, **kw)
+    o.c = f32(rng.standard_normal((1, A)) * 0.2).astype(np.float64)
     o.b = f32(o.b + 6.0 + rng.standard_normal((1, K)) * 0.5).astype(np.float64)   # livelier hidden units
     return o
 
@@ -753,15 +756,47 @@ def test_big():
     strands and their sum, a Gibbs step from the masks (tie-aware), the raw sums of both halves, the update, free
     energy and hit summaries -- each against the oracle, under the sanitizers.  Shapes: a 70-letter motif (more than two
     letter-window words), 37 motifs on two strands (a slab that is not a whole mask word: KS = 8), one motif, and two
-    pooled models (groups of 3 on two strands, groups of 2 on one)."""
-    for (K, M, ds, KS, JS, pool) in ((37, 70, True, 8, 16, 1), (3, 5, False, 32, 5, 1), (1, 1, True, 32, 1, 1),
-                                     (11, 9, True, 8, 4, 3), (5, 12, False, 4, 12, 2)):
-        o = make_oracle(K, M, ds, seed=K + M, batch=3, Lf=24, cd_k=2, wscale=0.8 if M > 20 else 1.0, rho=0.05, pooling=pool)
+    pooled models (groups of 3 on two strands, groups of 2 on one); then alphabets other than DNA's (input_dims,
+    convRBM.py:68-71: 3 letters as in the reference's own constructor test, 20 on one strand, 5 on two with pooling, 1)."""
+    for (K, M, ds, KS, JS, pool, A) in ((37, 70, True, 8, 16, 1, 4), (3, 5, False, 32, 5, 1, 4), (1, 1, True, 32, 1, 1, 4),
+                                        (11, 9, True, 8, 4, 3, 4), (5, 12, False, 4, 12, 2, 4),
+                                        (6, 4, True, 32, 2, 1, 3), (9, 7, False, 8, 3, 1, 20), (4, 6, True, 4, 6, 2, 5),
+                                        (2, 3, False, 32, 3, 1, 1)):
+        o = make_oracle(K, M, ds, seed=K + M, batch=3, Lf=24, cd_k=2, wscale=0.8 if M > 20 else 1.0, rho=0.05, pooling=pool, A=A)
         W, b, c = model_arrays(o)
         n, L = 4, M - 1 + 24
-        d = synthetic_onehot(n, L, seed=K)
-        letters, _ = encode(d)
-        LW = lib.emu_letter_words(L)
+        d = synthetic_onehot(n, L, seed=K, A=A)
+        letters, flags = encode(d)
+        assert flags == 0
+        if A != 4:      # the byte-code form of the same rows, and a code beyond the alphabet
+            codes = np.ascontiguousarray(d[:, 0].argmax(axis=1).astype(np.uint8))
+            l2 = np.zeros_like(letters)
+            fl = np.zeros(4, dtype=np.uint32)
+            lib.emu_encode_any(None, codes.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)), up(l2), up(fl), n, L, A, 2)
+            assert fl[0] == 0 and np.array_equal(l2, letters)
+            codes[1, 2] = A
+            lib.emu_encode_any(None, codes.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)), up(l2), up(fl), n, L, A, 2)
+            assert fl[0] == 1
+            bad = d.copy()
+            bad[0, 0, :, 1] = 0.0                        # a column without a letter
+            assert encode(bad)[1] == 1
+            # dense v | h of this alphabet (the API pass) against the oracle
+            hh = np.random.default_rng(3).binomial(1, 0.15, size=(n, K, 1, L - M + 1)).astype(np.float32)
+            hp = np.random.default_rng(4).binomial(1, 0.15, size=hh.shape).astype(np.float32) if ds else None
+            act = np.zeros((n, 1, A, L), dtype=np.float32)
+            prob = np.zeros_like(act)
+            smp = np.zeros_like(act)
+            lib.emu_vgh_any(fp(W), fp(c), K, M, A, fp(hh), fp(hp) if ds else None, n, L - M + 1, fp(act), fp(prob), fp(smp),
+                            ctypes.c_uint64(o.seed), 7, 2, 2, 64)
+            np.testing.assert_allclose(act, o._topDownActivity(hh, hp), rtol=1e-5, atol=2e-5)
+            uvv = visible_uniforms(o.seed, 7, np.arange(n) + 2, L, KIND_API_V)
+            Pv, vv = o._computeVgivenH(hh, hp, uvv)
+            np.testing.assert_allclose(prob, Pv, rtol=2e-5, atol=1e-7)
+            badv = (smp != vv).any(axis=2)[:, 0]
+            if badv.any():
+                gap = np.min(np.abs(np.cumsum(Pv[:, 0], axis=1)[:, :max(A - 1, 1)] - uvv[:, None, :]), axis=1)
+                assert np.all(gap[badv] < TIE), "dense v|h of a general alphabet: sample differs away from a tie"
+        LW = lib.emu_letter_words_any(A, L)
         Lh = L - M + 1
         NW = (K + 31) // 32
 
@@ -775,7 +810,7 @@ def test_big():
             smp = np.zeros_like(act)
             ones = ctypes.c_ulonglong(0)
             assert lib.emu_big_hgv(fp(W), fp(b), fp(c), K, M, int(ds), up(letters), n, L, mode, fp(act), fp(prob), fp(smp),
-                                   ctypes.byref(ones), None, ctypes.c_uint64(o.seed), 4, 6, KIND_API_H, 2, KS, 2, 64, pool) == 0
+                                   ctypes.byref(ones), None, ctypes.c_uint64(o.seed), 4, 6, KIND_API_H, 2, KS, 2, 64, pool, A) == 0
             if mode == 2:
                 ref = o._bottomUpActivity(d) + o._bottomUpActivity(d, True)
             else:
@@ -807,18 +842,18 @@ def test_big():
             hm, _f = pack_hidden(f32(o.fantasy_h), NW)
             hmp = pack_hidden(f32(o.fantasy_h_prime), NW)[0] if ds else np.zeros_like(hm)
             lws = lib.emu_big_gibbs_step(fp(W), fp(b), fp(c), K, M, int(ds), up(hm), up(hmp), None, B, Lf, ctypes.c_uint64(o.seed), t,
-                                         o.seq_offset, JS, KS, 2, 64, pool)
+                                         o.seq_offset, JS, KS, 2, 64, pool, A)
             vout = np.zeros((B, lws), dtype=np.uint32)
             assert lib.emu_big_gibbs_step(fp(W), fp(b), fp(c), K, M, int(ds), up(hm), up(hmp), up(vout), B, Lf, ctypes.c_uint64(o.seed), t,
-                                          o.seq_offset, JS, KS, 2, 64, pool) == lws
-            gv = np.zeros((B, 1, 4, Lv), dtype=np.float32)
-            lib.emu_decode(up(vout), fp(gv), B, Lv, lws, 2)
+                                          o.seq_offset, JS, KS, 2, 64, pool, A) == lws
+            gv = np.zeros((B, 1, A, Lv), dtype=np.float32)
+            lib.emu_decode_any(up(vout), fp(gv), B, Lv, lws, A, 2)
             uv = visible_uniforms(o.seed, t, idx, Lv, KIND_CHAIN_V)
             Pv, v = o._computeVgivenH(o.fantasy_h, o.fantasy_h_prime if ds else None, uv)
             np.testing.assert_array_equal(gv.sum(axis=2), 1.0)
             badv = (gv != v).any(axis=2)[:, 0]
             if badv.any():
-                gap = np.min(np.abs(np.cumsum(Pv[:, 0], axis=1)[:, :3] - uv[:, None, :]), axis=1)
+                gap = np.min(np.abs(np.cumsum(Pv[:, 0], axis=1)[:, :max(A - 1, 1)] - uv[:, None, :]), axis=1)
                 assert np.all(gap[badv] < TIE), "big v|h: sample differs away from a tie"
             clean = ~badv.any(axis=1)
             uh = hidden_uniforms(o.seed, t, idx, K, Lf, 0, KIND_CHAIN_H)
@@ -839,28 +874,28 @@ def test_big():
         assert o.fantasy_h.sum() > 0
         # raw sums of both halves against the oracle's, the update against its finalisation
         lay = (ctypes.c_int * 7)()
-        lib.emu_sums_layout(K, M, lay)
+        lib.emu_sums_layout_any(K, M, A, lay)
         data_off, n_d, model_off, n_m, count, skip_b, skip_l = list(lay)
-        KAM = K * 4 * M
-        row = 3 * KAM + 3 * K + 4
+        KAM = K * A * M
+        row = 3 * KAM + 3 * K + A
         sums = np.zeros(count, dtype=np.float32)
         half = np.zeros(row + 1, dtype=np.float32)
         CH = 16 if pool == 1 else 4 * pool
-        assert lib.emu_big_stats(fp(W), fp(b), fp(c), K, M, int(ds), up(letters), n, L, LW, 1, 2 if K < 8 else 1, CH, 64, fp(half), -1, 0, pool) == row
+        assert lib.emu_big_stats(fp(W), fp(b), fp(c), K, M, int(ds), up(letters), n, L, LW, 1, 2 if K < 8 else 1, CH, 64, fp(half), -1, 0, pool, A) == row
         sums[data_off:data_off + row] = half[:row]
         sums[n_d] = n
         P_m, P_mp, v_m = o.gibbs_steps(1)
         vl, _ = encode(v_m)
-        vlw = lib.emu_letter_words(Lv)
-        assert lib.emu_big_stats(fp(W), fp(b), fp(c), K, M, int(ds), up(vl), B, Lv, vlw, 0, 3 if K < 8 else 1, 8 if pool == 1 else 2 * pool, 64, fp(half), skip_b, skip_l, pool) == row
+        vlw = lib.emu_letter_words_any(A, Lv)
+        assert lib.emu_big_stats(fp(W), fp(b), fp(c), K, M, int(ds), up(vl), B, Lv, vlw, 0, 3 if K < 8 else 1, 8 if pool == 1 else 2 * pool, 64, fp(half), skip_b, skip_l, pool, A) == row
         sums[model_off:model_off + row - skip_l] = half[:row - skip_l]
         sums[n_m] = B
         ref = o.local_sums(d, P_m, P_mp, v_m)
         got = {"vh_d": sums[data_off:data_off + KAM], "h_d": sums[data_off + 2 * KAM:data_off + 2 * KAM + K],
                "sw": sums[data_off + 2 * KAM + 2 * K:data_off + 3 * KAM + 2 * K], "sb": sums[data_off + 3 * KAM + 2 * K:data_off + 3 * KAM + 3 * K],
-               "v_d": sums[data_off + 3 * KAM + 3 * K:data_off + 3 * KAM + 3 * K + 4],
+               "v_d": sums[data_off + 3 * KAM + 3 * K:data_off + 3 * KAM + 3 * K + A],
                "vh_m": sums[model_off:model_off + KAM], "h_m": sums[model_off + 2 * KAM:model_off + 2 * KAM + K],
-               "v_m": sums[model_off + 2 * KAM + 2 * K:model_off + 2 * KAM + 2 * K + 4]}
+               "v_m": sums[model_off + 2 * KAM + 2 * K:model_off + 2 * KAM + 2 * K + A]}
         if ds:
             got.update({"vh_dp": sums[data_off + KAM:data_off + 2 * KAM], "h_dp": sums[data_off + 2 * KAM + K:data_off + 2 * KAM + 2 * K],
                         "vh_mp": sums[model_off + KAM:model_off + 2 * KAM], "h_mp": sums[model_off + 2 * KAM + K:model_off + 2 * KAM + 2 * K]})
@@ -870,7 +905,7 @@ def test_big():
         vW, vb, vc = (f32(x).copy() for x in (o.vW, o.vb, o.vc))
         lib.emu_big_update(fp(sums), fp(Wn), fp(bn), fp(cn), fp(vW), fp(vb), fp(vc), K, M, int(ds), L, Lf,
                            ctypes.c_float(o.learning_rate), ctypes.c_float(o.momentum), ctypes.c_float(o.rho),
-                           ctypes.c_float(o.lambda_rate), 2, 64)
+                           ctypes.c_float(o.lambda_rate), 2, 64, A)
         o.finalize_from_sums(ref, L, Lf)
         np.testing.assert_allclose(Wn.reshape(o.W.shape), o.W, rtol=1e-4, atol=2e-6)
         np.testing.assert_allclose(bn.reshape(o.b.shape), o.b, rtol=1e-4, atol=2e-6)
@@ -879,18 +914,18 @@ def test_big():
         W2, b2, c2 = model_arrays(o)
         fe = np.zeros(n, dtype=np.float32)
         fem = np.zeros((n, K), dtype=np.float32)
-        lib.emu_big_eval(fp(W2), fp(b2), fp(c2), K, M, int(ds), up(letters), n, L, 0, fp(fe), fp(fem), None, None, None, 2, 64, pool)
+        lib.emu_big_eval(fp(W2), fp(b2), fp(c2), K, M, int(ds), up(letters), n, L, 0, fp(fe), fp(fem), None, None, None, 2, 64, pool, A)
         np.testing.assert_allclose(fe, o.freeEnergy(d), rtol=1e-4, atol=1e-6)
         np.testing.assert_allclose(fem, o.freeEnergy(d, True), rtol=1e-4, atol=1e-5)
         hmax = np.zeros((n, K), dtype=np.float32)
         hmean = np.zeros((n, K), dtype=np.float32)
         pos = np.zeros((K, Lh), dtype=np.float32)
-        lib.emu_big_eval(fp(W2), fp(b2), fp(c2), K, M, int(ds), up(letters), n, L, 1, None, None, fp(hmax), fp(hmean), fp(pos), 2, 64, pool)
+        lib.emu_big_eval(fp(W2), fp(b2), fp(c2), K, M, int(ds), up(letters), n, L, 1, None, None, fp(hmax), fp(hmean), fp(pos), 2, 64, pool, A)
         Ph = o.motifHitProbs(d)
         np.testing.assert_allclose(hmax, Ph.max(axis=(2, 3)), rtol=1e-5, atol=1e-7)
         np.testing.assert_allclose(hmean, Ph.mean(axis=(2, 3)), rtol=1e-5, atol=1e-7)
         np.testing.assert_allclose(pos / n, Ph.mean(axis=(0, 2)), rtol=1e-5, atol=1e-7)
-        print("big kernels ok", (K, M, ds, pool))
+        print("big kernels ok", (K, M, ds, pool, A))
 
 
 def test_large_models():
