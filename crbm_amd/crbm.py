@@ -96,6 +96,11 @@ class CRBM(object):
             raise Exception("num_motifs > 65536 is not supported.")
         if motif_length > 512:
             raise Exception("motif_length > 512 is not supported.")
+        # any alphabet (the reference warns and runs: convRBM.py:84-87); other than DNA's four letters on the generic kernels
+        if input_dims > 64:
+            raise Exception("input_dims > 64 is not supported.")
+        if input_dims * motif_length > 2048:
+            raise Exception("input_dims * motif_length > 2048 is not supported.")
 
         # convRBM.py:111-123
         self.num_motifs = num_motifs
@@ -147,8 +152,6 @@ class CRBM(object):
         compile step (convRBM.py:175, :453-515).  No CPU fallback."""
         if self._handle is not None:
             return self._handle
-        if self.input_dims != 4:
-            raise Exception("the HIP kernels require input_dims == 4")
         lib = _lib.load()
         if self.batchsize % self.world_size != 0:
             raise Exception("batchsize must be divisible by the number of GPUs")
@@ -193,9 +196,9 @@ class CRBM(object):
     def _get_param(self, name):
         if self._handle is None:
             return self._host[name]
-        W = np.empty((self.num_motifs, 1, 4, self.motif_length), dtype=np.float32)
+        W = np.empty((self.num_motifs, 1, self.input_dims, self.motif_length), dtype=np.float32)
         b = np.empty((1, self.num_motifs), dtype=np.float32)
-        c = np.empty((1, 4), dtype=np.float32)
+        c = np.empty((1, self.input_dims), dtype=np.float32)
         self._check(self._lib.crbm_get_params(self._handle, fptr(W), fptr(b), fptr(c)))
         return {"motifs": W, "bias": b, "c": c}[name]
 
@@ -208,17 +211,16 @@ class CRBM(object):
         self._check(self._lib.crbm_set_params(self._handle, fptr(cur["motifs"]), fptr(cur["bias"]),
                                               fptr(cur["c"])))
 
-    @staticmethod
-    def _data(data):
+    def _data(self, data):
         data = as_f32(data)
-        if data.ndim != 4 or data.shape[1] != 1 or data.shape[2] != 4:
-            raise Exception("expected a one-hot array of shape (n,1,4,L), got %s" % (data.shape,))
+        if data.ndim != 4 or data.shape[1] != 1 or data.shape[2] != self.input_dims:
+            raise Exception("expected a one-hot array of shape (n,1,%d,L), got %s" % (self.input_dims, data.shape))
         return data
 
     @staticmethod
     def _is_codes(data):
-        """True for the packed input form: a 2-D uint8 array (n, L) of letter codes 0..3
-        (crbm_amd.sequences.seqsToCodes / fastaToCodes)."""
+        """True for the packed input form: a 2-D uint8 array (n, L) of letter codes 0..input_dims-1
+        (DNA: crbm_amd.sequences.seqsToCodes / fastaToCodes)."""
         return isinstance(data, np.ndarray) and data.ndim == 2 and data.dtype == np.uint8
 
     def _input(self, data):
@@ -232,7 +234,7 @@ class CRBM(object):
 
     @staticmethod
     def _data_codes(data):
-        """(n,1,4,L) one-hot float array -> (n,L) uint8 letter codes; raises unless exactly one-hot."""
+        """(n,1,A,L) one-hot float array -> (n,L) uint8 letter codes; raises unless exactly one-hot."""
         onehot = (data[:, 0] == 1.0)
         if not (np.all(onehot.sum(axis=1) == 1) and np.all((data == 0.0) | (data == 1.0))):
             raise Exception("HIP CRBM call failed (-3): visible data is not exactly one-hot")
@@ -374,7 +376,7 @@ class CRBM(object):
         if hp is not None and hp.shape != h.shape:
             raise Exception("h and hprime must have the same shape")
         n, Lh = h.shape[0], h.shape[3]
-        shape = (n, 1, 4, Lh + self.motif_length - 1)
+        shape = (n, 1, self.input_dims, Lh + self.motif_length - 1)
         outs = [np.empty(shape, dtype=np.float32) if w else None for w in want]
         self._call("crbm_v_given_h", fptr(h), fptr(hp), n, Lh, rng_step,
                                              fptr(outs[0]), fptr(outs[1]), fptr(outs[2]))
@@ -588,15 +590,15 @@ class CRBM(object):
 
     # ------------------------------------------- state the reference never saves
     def get_velocities(self):
-        vW = np.empty((self.num_motifs, 1, 4, self.motif_length), dtype=np.float32)
+        vW = np.empty((self.num_motifs, 1, self.input_dims, self.motif_length), dtype=np.float32)
         vb = np.empty((1, self.num_motifs), dtype=np.float32)
-        vc = np.empty((1, 4), dtype=np.float32)
+        vc = np.empty((1, self.input_dims), dtype=np.float32)
         self._call("crbm_get_velocities", fptr(vW), fptr(vb), fptr(vc))
         return vW, vb, vc
 
     def set_velocities(self, vW, vb, vc):
         vW, vb, vc = as_f32(vW), as_f32(vb), as_f32(vc)
-        want = ((self.num_motifs, 1, 4, self.motif_length), (1, self.num_motifs), (1, 4))
+        want = ((self.num_motifs, 1, self.input_dims, self.motif_length), (1, self.num_motifs), (1, self.input_dims))
         for name, arr, shape in zip(("vW", "vb", "vc"), (vW, vb, vc), want):
             if arr.shape != shape:          # the C side reads exactly these many floats
                 raise ValueError("%s: expected shape %s, got %s" % (name, shape, arr.shape))
@@ -628,7 +630,7 @@ class CRBM(object):
     def get_fantasy_visible(self):
         h = self._h()
         nb = self.batchsize // self.world_size
-        v = np.empty((nb, 1, 4, self.fantasy_hidden_len + self.motif_length - 1), dtype=np.float32)
+        v = np.empty((nb, 1, self.input_dims, self.fantasy_hidden_len + self.motif_length - 1), dtype=np.float32)
         self._call("crbm_get_fantasy_visible", fptr(v))
         return v
 

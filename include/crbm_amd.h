@@ -11,8 +11,9 @@
  * Conventions
  *   - plain C, no C++/torch types; all array arguments are HOST pointers to
  *     C-contiguous float32 unless the name ends in _dev;
- *   - tensors use the reference's layouts: visible (n,1,4,L), hidden
- *     (n,K,1,Lh), filters (K,1,4,M), bias (1,K), c (1,4);
+ *   - tensors use the reference's layouts: visible (n,1,A,L) with A = input_dims (4: DNA), hidden
+ *     (n,K,1,Lh), filters (K,1,A,M), bias (1,K), c (1,A); the packed sums of a training step carry
+ *     K*A*M weights per block and A letter counts (crbm_sums_count());
  *   - every function returns 0 on success, a negative crbm_status otherwise,
  *     and never throws; crbm_last_error() returns the message;
  *   - calls are synchronous w.r.t. the host unless the name ends in _async;
@@ -113,7 +114,7 @@ int crbm_train_step(crbm_handle* h, const float* D, int32_t n, int32_t L);
  * passes slice bounds). */
 int crbm_dataset_upload(crbm_handle* h, const float* data, int32_t n, int32_t L);
 /* Same from letter codes, one byte per base (0..3 = A,C,G,T: the map of
- * sequences.py:9-17), shape (n,L): 16x less host->device traffic than the
+ * sequences.py:9-17; 0..input_dims-1 for any other alphabet), shape (n,L): 16x less host->device traffic than the
  * float one-hot array that sequences.py:101-117 builds. */
 int crbm_dataset_upload_codes(crbm_handle* h, const uint8_t* codes, int32_t n, int32_t L);
 /* A handle holds CRBM_DATASET_SLOTS resident data sets (fit() keeps the
@@ -172,7 +173,7 @@ int crbm_eval_data(crbm_handle* h, const float* v, int32_t n, int32_t L, float* 
 int crbm_eval_params(crbm_handle* h, float* twn, float* ic, float* medic);
 
 /* ---- data-set scale sweeps --------------------------------
- * The same evaluations fed with one byte per base (`_codes`, (n,L), 0..3) or
+ * The same evaluations fed with one byte per base (`_codes`, (n,L), 0..input_dims-1) or
  * with rows [start,end) of the selected resident data set (`_resident`), so
  * that the fp32 one-hot array of sequences.py:101-117 never has to exist.
  * Output pointers of the free-energy calls may be NULL (at least one is set). */

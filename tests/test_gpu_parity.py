@@ -21,14 +21,18 @@ RTOL = 1e-4
 
 def make_pair(K, M, ds=True, batchsize=8, cd_k=2, Lf=200, seed=5, wscale=1.0, bshift=0.0, **kw):
     """A crbm_amd.CRBM and an OracleCRBM with identical parameters and sampler."""
+    import warnings
     from crbm_amd import CRBM
+    A = kw.get("input_dims", 4)
     rng = np.random.default_rng(1000 + 7 * K + M)
-    W = (rng.standard_normal((K, 1, 4, M)) * wscale).astype(np.float32)
-    m = CRBM(K, M, doublestranded=ds, batchsize=batchsize, cd_k=cd_k, fantasy_hidden_len=Lf, seed=seed, **kw)
+    W = (rng.standard_normal((K, 1, A, M)) * wscale).astype(np.float32)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", UserWarning)          # "input_dims != 4 was not comprehensively tested" (convRBM.py:84-87)
+        m = CRBM(K, M, doublestranded=ds, batchsize=batchsize, cd_k=cd_k, fantasy_hidden_len=Lf, seed=seed, **kw)
     o = OracleCRBM(K, M, doublestranded=ds, batchsize=batchsize, cd_k=cd_k, fantasy_hidden_len=Lf, seed=seed,
-                   W=W, **{k: v for k, v in kw.items() if k in ("rho", "lambda_rate", "learning_rate", "momentum", "pooling")})
+                   W=W, **{k: v for k, v in kw.items() if k in ("rho", "lambda_rate", "learning_rate", "momentum", "pooling", "input_dims")})
     b = (o.b + bshift).astype(np.float32)
-    c = (rng.standard_normal((1, 4)) * 0.1).astype(np.float32)
+    c = (rng.standard_normal((1, A)) * 0.1).astype(np.float32)
     m.motifs.set_value(W)
     m.bias.set_value(b)
     m.c.set_value(c)
@@ -73,7 +77,7 @@ def assert_chain_steps(model, o, steps):
         np.testing.assert_array_equal(gv.sum(axis=2), 1.0)                       # one 1 per position
         badv = (gv != v).any(axis=2)[:, 0]                                       # (B, Lv)
         if badv.any():
-            cum = np.cumsum(Pv[:, 0], axis=1)[:, :3]                             # the three inner thresholds
+            cum = np.cumsum(Pv[:, 0], axis=1)[:, :max(Pv.shape[2] - 1, 1)]       # the inner thresholds (three for DNA)
             gap = np.min(np.abs(cum - uv[:, None, :]), axis=1)
             assert np.all(gap[badv] < TIE), "visible sample differs away from a tie"
             ties += int(badv.sum())
@@ -839,10 +843,10 @@ def test_edge_shapes(K, M, ds, L, n):
     check_model_against_oracle(K, M, ds, L, n)
 
 
-def check_model_against_oracle(K, M, ds, L, n):
+def check_model_against_oracle(K, M, ds, L, n, **kw):
     Lf = max(1, L - M + 1)
-    model, o = make_pair(K, M, ds=ds, batchsize=4, Lf=Lf, cd_k=2, bshift=3.0, wscale=0.7)
-    D = synthetic_onehot(n, L, seed=K + M)
+    model, o = make_pair(K, M, ds=ds, batchsize=4, Lf=Lf, cd_k=2, bshift=3.0, wscale=0.7, **kw)
+    D = synthetic_onehot(n, L, seed=K + M, A=kw.get("input_dims", 4))
     np.testing.assert_allclose(model._bottomUpActivity(D), o._bottomUpActivity(D), rtol=1e-5, atol=2e-5)
     np.testing.assert_allclose(model._bottomUpActivity(D, True), o._bottomUpActivity(D, True), rtol=1e-5, atol=2e-5)
     np.testing.assert_allclose(model.motifHitProbs(D), o.motifHitProbs(D), rtol=RTOL, atol=1e-7)
@@ -855,9 +859,59 @@ def check_model_against_oracle(K, M, ds, L, n):
     np.testing.assert_allclose(s["position_mean"], P.mean(axis=(0, 2)), rtol=RTOL, atol=1e-7)
     assert_chain_steps(model, o, 2)                    # sample for sample, ties only
     model.set_fantasy(o.fantasy_h.astype(np.float32), o.fantasy_h_prime.astype(np.float32) if ds else None)
-    twin = lambda: make_pair(K, M, ds=ds, batchsize=4, Lf=Lf, cd_k=2, bshift=3.0, wscale=0.7)
+    twin = lambda: make_pair(K, M, ds=ds, batchsize=4, Lf=Lf, cd_k=2, bshift=3.0, wscale=0.7, **kw)
     assert_train_steps(model, o, [D, D], twin, atol=5e-6)
     return model
+
+
+@pytest.mark.parametrize("A,K,M,ds,L,n,pool", [(3, 1, 1, True, 30, 5, 1), (3, 6, 5, True, 60, 7, 1), (20, 12, 9, False, 80, 6, 1),
+                                               (5, 7, 6, True, 47, 5, 2), (1, 3, 4, False, 40, 4, 1), (25, 40, 12, False, 70, 5, 1),
+                                               (64, 5, 8, True, 50, 4, 1)])
+def test_other_alphabets(A, K, M, ds, L, n, pool, capsys):
+    """input_dims != 4: the reference warns ("not comprehensively tested") and runs (convRBM.py:84-87; its own constructor
+    test builds a 3-letter model, tests/testcrbm.py:30-31).  Here such models run on the generic kernels with one byte per
+    letter: activations on both strands (rc(W) = W[:, ::-1, ::-1] over A letters), hit probabilities and summaries, free
+    energies, the chain sample for sample (ties only), PCD steps, fit() with its status line, the byte-code input form,
+    save/load -- each against the oracle.  20 and 25 letters: protein alphabets; 64: the largest the v|h kernel takes."""
+    import warnings
+    from crbm_amd import CRBM
+    kw = dict(input_dims=A)
+    if pool > 1:
+        kw["pooling"] = pool
+    model = check_model_against_oracle(K, M, ds, L, n, **kw)
+    o2 = OracleCRBM(K, M, doublestranded=ds, input_dims=A, W=model.motifs.get_value(), **({"pooling": pool} if pool > 1 else {}))
+    o2.b, o2.c = model.bias.get_value().astype(np.float64), model.c.get_value().astype(np.float64)
+    np.testing.assert_allclose(model._evaluateParams(), o2.evaluateParams(), rtol=1e-4, atol=1e-6)
+    pf = model.getPFMs()
+    assert pf[0].shape == (A, M)
+    np.testing.assert_allclose(np.sum(pf[0], axis=0), 1.0, rtol=1e-12)
+    # letter codes (one byte per letter) are the same input as the one-hot array
+    D = synthetic_onehot(9, L, seed=77, A=A)
+    codes = np.ascontiguousarray(D[:, 0].argmax(axis=1).astype(np.uint8))
+    np.testing.assert_array_equal(model.freeEnergy(codes), model.freeEnergy(D))
+    np.testing.assert_array_equal(model.motifHitProbs(codes), model.motifHitProbs(D))
+    if A < 255:
+        bad = codes.copy()
+        bad[0, 0] = A
+        with pytest.raises(Exception, match="one-hot"):
+            model.freeEnergy(bad)
+    with pytest.raises(Exception, match="shape"):
+        model.freeEnergy(synthetic_onehot(3, L, seed=1, A=A + 1))
+    model.epochs = 2
+    model.fit(D, D[:4])
+    out = capsys.readouterr().out
+    assert "Epoch 1: FE=" in out and np.isfinite(model.motifs.get_value()).all()
+    # save / load keeps the alphabet (convRBM.py:177-236)
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "m.pkl")
+        model.saveModel(path)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", UserWarning)
+            again = CRBM.loadModel(path)
+    assert again.input_dims == A
+    np.testing.assert_array_equal(again.motifs.get_value(), model.motifs.get_value())
+    np.testing.assert_array_equal(again.freeEnergy(D), model.freeEnergy(D))
 
 
 def test_generic_kernels_on_a_model_the_specialised_ones_take(monkeypatch, capsys):

@@ -178,9 +178,17 @@ def test_limits_are_refused_at_construction():
         CRBM(4, 513)
     CRBM(257, 5)
     CRBM(4, 65)
-    CRBM(256, 64, pooling=4)                  # fine until a GPU is needed (pooling with the generic kernels is refused there)
+    CRBM(256, 64, pooling=4)
     CRBM(100, 15)
     CRBM(20, 40)
+    # alphabets other than DNA's (convRBM.py:84-87 warns and runs): up to 64 letters, letters x motif_length <= 2048
+    with pytest.warns(UserWarning):
+        m = CRBM(8, 12, input_dims=20)
+    assert m.motifs.get_value().shape == (8, 1, 20, 12) and m.c.get_value().shape == (1, 20)
+    with pytest.warns(UserWarning), pytest.raises(Exception, match="input_dims > 64"):
+        CRBM(4, 5, input_dims=65)
+    with pytest.warns(UserWarning), pytest.raises(Exception, match=r"input_dims \* motif_length > 2048"):
+        CRBM(4, 103, input_dims=20)
 
 
 def test_shape_checks_before_the_c_side_reads(monkeypatch):

@@ -43,12 +43,19 @@ if __name__ == "__main__":
         else:
             os.environ.pop("CRBM_STATS", None)
         bshift, wscale = float(rng.uniform(2, 7)), float(rng.uniform(0.3, 1.5))
+        A = 4
+        if case % 5 == 4:                                # every fifth: an alphabet other than DNA's (generic kernels, byte rows)
+            A = [1, 2, 3, 5, 8, 20, 33, 64][int(rng.integers(0, 8))]
+            M = min(M, 2048 // A, 40)
+            K = min(K, 60)
+            L = M - 1 + max(1, (L - M + 1) // pool) * pool
+        akw = {"input_dims": A} if A != 4 else {}
         if only is not None and case != only:
             continue
         t0 = time.time()
         try:
-            m, o = T.make_pair(K, M, ds=ds, batchsize=B, cd_k=k, Lf=Lf, bshift=bshift, wscale=wscale, pooling=pool)
-            D = synthetic_onehot(n, L, seed=case)
+            m, o = T.make_pair(K, M, ds=ds, batchsize=B, cd_k=k, Lf=Lf, bshift=bshift, wscale=wscale, pooling=pool, **akw)
+            D = synthetic_onehot(n, L, seed=case, A=A)
             m._trainingFct(D)
             o.train_step(D)
             if only is not None:      # diagnosis of a single case: how many samples of the chain differ?
@@ -66,7 +73,7 @@ if __name__ == "__main__":
                 # With a few dozen chains one differing sample moves the model statistics by 1/(chains * Lf):
                 # legitimate only if every differing sample of the chain sits on a p == u tie.  Replay the
                 # chain of a fresh pair one step at a time from identical states (raises on anything else).
-                m2, o2 = T.make_pair(K, M, ds=ds, batchsize=B, cd_k=k, Lf=Lf, bshift=bshift, wscale=wscale, pooling=pool)
+                m2, o2 = T.make_pair(K, M, ds=ds, batchsize=B, cd_k=k, Lf=Lf, bshift=bshift, wscale=wscale, pooling=pool, **akw)
                 ties = T.assert_chain_steps(m2, o2, k)
                 if ties < 1:
                     raise
@@ -84,7 +91,7 @@ if __name__ == "__main__":
         except Exception as e:   # report every failing shape, keep going
             bad += 1
             status = "FAIL %s" % (str(e)[:300].replace("\n", " "))
-        print("case %d K=%d M=%d ds=%d pool=%d Lf=%d B=%d n=%d L=%d k=%d td=%s stats=%s: %s (%.1fs)" % (
-            case, K, M, ds, pool, Lf, B, n, L, k, variant or "default", stats or "one", status, time.time() - t0), flush=True)
+        print("case %d K=%d M=%d A=%d ds=%d pool=%d Lf=%d B=%d n=%d L=%d k=%d td=%s stats=%s: %s (%.1fs)" % (
+            case, K, M, A, ds, pool, Lf, B, n, L, k, variant or "default", stats or "one", status, time.time() - t0), flush=True)
     print("SOAK DONE, failures:", bad)
     sys.exit(1 if bad else 0)
