@@ -304,7 +304,7 @@ int big_launch_hgv(crbm_handle* h, const uint32_t* d_letters, int n, int L, int 
   a.n = n; a.L = L; a.Lh = L - h->M + 1; a.LW = lw(h, L);
   const int pool = h->ms.POOL;
   int ks = pool > 1 ? 8 : 32;                                // motifs per staged slab: a divisor of 32 whose filters fit 96 KB
-  while (ks > 1 && (size_t)ks * h->M * h->A * 4 > 96 * 1024) ks >>= 1;   // (pooled: at most 8, the capacity of big_hgv_pooled_kernel)
+  while (ks > 1 && (size_t)big_hgv_ksp(ks) * h->M * h->A * 4 > 96 * 1024) ks >>= 1;   // (pooled: at most 8, the capacity of big_hgv_pooled_kernel)
   a.KS = ks;
   a.pool = pool;
   // rows per tile: enough tiles to cover the chip a few times over (every tile stages the filters once per slab), at most
@@ -314,11 +314,15 @@ int big_launch_hgv(crbm_handle* h, const uint32_t* d_letters, int n, int L, int 
   a.act = act; a.prob = prob; a.sample = sample; a.ones = ones; a.masks = masks;
   a.rng = rng_view(h, step, seq_offset);
   a.kind = kind;
-  const size_t lds = ((size_t)ks * h->M * h->A + 32) * 4 + (size_t)a.TS * a.LW * 4;
+  const size_t lds = ((size_t)big_hgv_ksp(ks) * h->M * h->A + 32) * 4 + (size_t)a.TS * a.LW * 4;
   ARGCHK(lds <= 160 * 1024, "motif_length too large for the h|v kernel");
   const int ntiles = (n + a.TS - 1) / a.TS;
-  if (pool > 1) hipLaunchKernelGGL(big_hgv_pooled_kernel, dim3(std::max(1, std::min(ntiles, h->num_cu * 8))), dim3(256), lds, st, a);
-  else hipLaunchKernelGGL(big_hgv_kernel, dim3(std::max(1, std::min(ntiles, h->num_cu * 8))), dim3(256), lds, st, a);
+  // few tiles (small batches): one block per (tile, mask word) -- every slab lies inside one mask word, so blocks of
+  // different words never touch the same output
+  a.split = (h->NW > 1 && ntiles < 4 * h->num_cu) ? 1 : 0;
+  const dim3 grid(std::max(1, std::min(ntiles, h->num_cu * 8)), a.split ? h->NW : 1);
+  if (pool > 1) hipLaunchKernelGGL(big_hgv_pooled_kernel, grid, dim3(256), lds, st, a);
+  else hipLaunchKernelGGL(big_hgv_kernel, grid, dim3(256), lds, st, a);
   HIPCHK(hipGetLastError());
   return CRBM_OK;
 }
@@ -370,7 +374,7 @@ int big_launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bo
   HIPCHK(pbuf.ensure((size_t)a.R * a.row));
   a.partials = pbuf.p;
   ARGCHK(h->A * M <= BIG_ST * 256, "motif_length too large for the statistics kernel");
-  const size_t lds = (((size_t)h->A * M + 3) & ~(size_t)3) * 4 + (size_t)(a.pool > 1 ? 5 : 3) * a.CH * 4 + 64 + 3 * 256 * 4 +
+  const size_t lds = (((size_t)h->A * M + 3) & ~(size_t)3) * 4 + (size_t)(a.pool > 1 ? 5 : 3) * a.CH * 4 + 64 + 12 * 256 * 4 +
                      (size_t)((h->A + 3) & ~3) * 4 + (size_t)a.CH + M;
   ARGCHK(lds <= 160 * 1024, "motif_length too large for the statistics kernel");
   hipLaunchKernelGGL(big_stats_kernel, dim3(K, a.R), dim3(256), lds, st, a);

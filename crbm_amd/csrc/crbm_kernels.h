@@ -2658,6 +2658,7 @@ struct BigHgvArgs {
   const uint32_t* letters;
   int32_t n, L, Lh, LW;
   int32_t TS, KS;
+  int32_t split;               // 1: blockIdx.y = mask word, the block takes the slabs of that word only (few tiles: more blocks)
   int32_t pool;                // pooling (1: independent units; > 1: big_hgv_pooled_kernel, KS <= 8)
   int32_t mode;                // 0: forward strand, 1: reverse-complement strand, 2: sigma(x + x')
   float* act;                  // (n,K,1,Lh) each, may be null
@@ -2669,6 +2670,8 @@ struct BigHgvArgs {
   uint32_t kind;
 };
 
+// floats per (column, letter) row of a slab of KS motifs in LDS
+__host__ __device__ inline int big_hgv_ksp(int KS) { return ((KS + 3) & ~3) + 4; }
 // KSM: slab capacity of the register arrays (32 unpooled; 8 pooled, which keeps five arrays per unit).
 // POOLED: the units of `pool` consecutive positions compete (convRBM.py:245-267): P_i = exp(x_i) / (pool + sum_j exp(x_j)),
 // one draw per group -- the uniform of its first position -- against the cumulative probabilities; a thread evaluates its
@@ -2678,8 +2681,11 @@ __device__ __forceinline__ void big_hgv_body(const BigHgvArgs& a) {
   HIP_DYNAMIC_SHARED(float, smem);
   const int K = a.m.K, M = a.m.M, KS = a.KS;
   const int A = a.m.A;
-  float* Ws = smem;                                            // [KS][M][A]
-  float* bs = Ws + (size_t)KS * M * A;                         // [32]
+  // the slab's filters as Ws[column][letter][motif], motifs contiguous (four per LDS read); rows padded by four floats so
+  // that the rows of different letters start in different banks
+  const int KSP = big_hgv_ksp(KS);
+  float* Ws = smem;                                            // [M][A][KSP]
+  float* bs = Ws + (size_t)KSP * M * A;                        // [32]
   uint32_t* let = reinterpret_cast<uint32_t*>(bs + 32);        // [TS][LW]
   const bool want_sample = a.sample || a.ones || a.masks;
   const uint32_t strand = a.mode == 1 ? 1u : 0u;
@@ -2690,12 +2696,13 @@ __device__ __forceinline__ void big_hgv_body(const BigHgvArgs& a) {
     __syncthreads();
     for (int i = threadIdx.x; i < ns * a.LW; i += blockDim.x) let[i] = a.letters[(size_t)n0 * a.LW + i];
     const int items = ns * a.Lh;
-    for (int k0 = 0; k0 < K; k0 += KS) {
+    const int kbeg = a.split ? 32 * (int)blockIdx.y : 0, kend = a.split ? min(K, kbeg + 32) : K;
+    for (int k0 = kbeg; k0 < kend; k0 += KS) {
       const int kc = min(KS, K - k0);
       __syncthreads();
-      for (int i = threadIdx.x; i < kc * M * A; i += blockDim.x) {
-        const int k = i / (A * M), j = (i / A) % M, al = i % A;
-        Ws[i] = a.m.W[((size_t)(k0 + k) * A + al) * M + j];
+      for (int i = threadIdx.x; i < KSP * M * A; i += blockDim.x) {
+        const int k = i % KSP, al = (i / KSP) % A, j = i / (KSP * A);
+        Ws[i] = k < kc ? a.m.W[((size_t)(k0 + k) * A + al) * M + j] : 0.f;
       }
       if ((int)threadIdx.x < kc) bs[threadIdx.x] = a.m.b[k0 + threadIdx.x];
       __syncthreads();
@@ -2710,10 +2717,13 @@ __device__ __forceinline__ void big_hgv_body(const BigHgvArgs& a) {
             const bool rc = a.mode == 1 || pass == 1;
             for (int j = 0; j < M; ++j) {
               const uint32_t l = letter_at(a.m, lrow, pos + j);
-              const float* col = Ws + (size_t)((rc ? M - 1 - j : j) * A + (int)(rc ? (uint32_t)(A - 1) - l : l));
+              const float4* col = reinterpret_cast<const float4*>(Ws + (size_t)((rc ? M - 1 - j : j) * A + (int)(rc ? (uint32_t)(A - 1) - l : l)) * KSP);
 #pragma unroll
-              for (int k = 0; k < KSM; ++k)
-                if (k < kc) x[k] += col[(size_t)k * M * A];
+              for (int q = 0; q < KSM / 4; ++q)
+                if (4 * q < kc) {            // wave-uniform; motifs beyond kc are zero in the slab
+                  const float4 t = col[q];
+                  x[4 * q] += t.x; x[4 * q + 1] += t.y; x[4 * q + 2] += t.z; x[4 * q + 3] += t.w;
+                }
             }
 #pragma unroll
             for (int k = 0; k < KSM; ++k)
@@ -2985,8 +2995,8 @@ __global__ void __launch_bounds__(256) big_stats_kernel(BigStatsArgs a) {
   float* X = Q + CH;                                        // [CH] each: activations of the chunk (pooled models only)
   float* Xp = X + (a.pool > 1 ? CH : 0);
   float* xch = Xp + (a.pool > 1 ? CH : 0);                  // [16]
-  float* red = xch + 16;                                    // [3][blockDim]: slices of a (letter, column) meet here
-  uint32_t* cnt = reinterpret_cast<uint32_t*>(red + 3 * blockDim.x);   // [A] letter counts (blocks of motif 0)
+  float* red = xch + 16;                                    // [12][blockDim]: the slices' sums meet here (3 kinds x 4 letters, or 3 kinds)
+  uint32_t* cnt = reinterpret_cast<uint32_t*>(red + 12 * blockDim.x);  // [A] letter counts (blocks of motif 0)
   unsigned char* lb = reinterpret_cast<unsigned char*>(cnt + ((A + 3) & ~3));   // [CH + M]
   for (int i = threadIdx.x; i < AM; i += blockDim.x) Wk[i] = a.m.W[(size_t)k * AM + i];
   for (int i = threadIdx.x; i < A; i += blockDim.x) cnt[i] = 0u;
@@ -2995,6 +3005,12 @@ __global__ void __launch_bounds__(256) big_stats_kernel(BigStatsArgs a) {
 #pragma unroll
   for (int t = 0; t < BIG_ST; ++t) vh[t] = vhp[t] = sw[t] = 0.f;
   const int nsl = AM <= (int)blockDim.x ? (int)blockDim.x / AM : 0;    // position slices per (letter, column); 0: A M > blockDim
+  // DNA with at most blockDim filter columns: a thread owns a COLUMN and a slice of positions and keeps one accumulator per
+  // letter and kind -- one letter read and three probability reads per (column, position) instead of per (letter, column,
+  // position): the loop is bound by its LDS reads (300 x 10 on 4096 chains: 6.05 -> 2.2 ms per half)
+  const bool by_column = A == 4 && M <= (int)blockDim.x;
+  const int ncs = by_column ? (int)blockDim.x / M : 0;                  // position slices per column
+  float c_vh[4] = {0.f, 0.f, 0.f, 0.f}, c_vhp[4] = {0.f, 0.f, 0.f, 0.f}, c_sw[4] = {0.f, 0.f, 0.f, 0.f};
   float hsum = 0.f, hpsum = 0.f, qsum = 0.f;
   for (int nn = r; nn < a.n; nn += a.R) {
     const uint32_t* lrow = a.letters + (size_t)nn * a.LW;
@@ -3044,7 +3060,19 @@ __global__ void __launch_bounds__(256) big_stats_kernel(BigStatsArgs a) {
         }
         __syncthreads();
       }
-      if (nsl > 0) {
+      if (by_column) {
+        const int j = (int)threadIdx.x % M, sl = (int)threadIdx.x / M;
+        if (sl < ncs)
+          for (int s = sl; s < cl; s += ncs) {
+            const int l = lb[s + j];
+            const float p = P[s], pp = Pp[s], q = Q[s];
+#pragma unroll
+            for (int al = 0; al < 4; ++al) {
+              const float mk = l == al ? 1.0f : 0.0f;
+              c_vh[al] = fmaf(mk, p, c_vh[al]); c_vhp[al] = fmaf(mk, pp, c_vhp[al]); c_sw[al] = fmaf(mk, q, c_sw[al]);
+            }
+          }
+      } else if (nsl > 0) {
         // 4 M <= blockDim: thread (e, slice) takes every nsl-th position of the chunk for its (letter, column) -- branch-free
         // (a match contributes P * 1, anything else P * 0), so that the loads of consecutive positions overlap
         const int e = (int)threadIdx.x % AM, sl = (int)threadIdx.x / AM;
@@ -3075,7 +3103,26 @@ __global__ void __launch_bounds__(256) big_stats_kernel(BigStatsArgs a) {
     }
   }
   float* out = a.partials + (size_t)r * a.row;
-  if (nsl > 0) {
+  if (by_column) {
+    // the slices of a column are added in slice order through LDS: red[kind * 4 + letter][slice * M + column]
+    __syncthreads();
+    const int j = (int)threadIdx.x % M, sl = (int)threadIdx.x / M, RS = (int)blockDim.x;
+    if (sl < ncs)
+#pragma unroll
+      for (int al = 0; al < 4; ++al) {
+        red[(0 + al) * RS + sl * M + j] = c_vh[al]; red[(4 + al) * RS + sl * M + j] = c_vhp[al]; red[(8 + al) * RS + sl * M + j] = c_sw[al];
+      }
+    __syncthreads();
+    for (int e = (int)threadIdx.x; e < AM; e += (int)blockDim.x) {
+      const int al = e / M, jj = e - al * M;
+      float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+      for (int i = 0; i < ncs; ++i) { t0 += red[(0 + al) * RS + i * M + jj]; t1 += red[(4 + al) * RS + i * M + jj]; t2 += red[(8 + al) * RS + i * M + jj]; }
+      out[a.off_vh0 + (size_t)k * AM + e] = t0;
+      if (a.m.ds) out[a.off_vh1 + (size_t)k * AM + e] = t1;
+      if (a.want_sparsity) out[a.off_sw + (size_t)k * AM + e] = t2;
+    }
+    __syncthreads();
+  } else if (nsl > 0) {
     // the slices of a (letter, column) are added in slice order through LDS
     __syncthreads();
     const int e = (int)threadIdx.x % AM, sl = (int)threadIdx.x / AM;

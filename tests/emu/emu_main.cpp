@@ -483,14 +483,16 @@ int emu_big_hgv(const float* W, const float* b, const float* c, int K, int M, in
   a.pool = pool;
   a.letters = letters; a.n = n; a.L = L; a.Lh = L - M + 1; a.LW = letter_words_any(A, L);
   a.TS = TS; a.KS = KS; a.mode = mode;
+  a.split = (K > 32 && (n % 2) == 0) ? 1 : 0;      // both forms are exercised: blockIdx.y = mask word where a model has several
   a.act = act; a.prob = prob; a.sample = sample; a.ones = ones; a.masks = masks;
   a.rng = make_rng(seed, step, off); a.kind = kind;
-  const size_t lds = ((size_t)KS * M * A + 32) * 4 + (size_t)TS * a.LW * 4;
+  const size_t lds = ((size_t)big_hgv_ksp(KS) * M * A + 32) * 4 + (size_t)TS * a.LW * 4;
+  const dim3 g(grid, a.split ? (K + 31) / 32 : 1);
   if (pool > 1) {
     if (KS > 8) return -2;
-    emu::launch([&] { big_hgv_pooled_kernel(a); }, dim3(grid), dim3(threads), lds);
+    emu::launch([&] { big_hgv_pooled_kernel(a); }, g, dim3(threads), lds);
   } else
-    emu::launch([&] { big_hgv_kernel(a); }, dim3(grid), dim3(threads), lds);
+    emu::launch([&] { big_hgv_kernel(a); }, g, dim3(threads), lds);
   return 0;
 }
 
@@ -528,7 +530,7 @@ int emu_big_stats(const float* W, const float* b, const float* c, int K, int M, 
   a.off_sw = 2 * KAM + 2 * K; a.off_sb = 3 * KAM + 2 * K; a.off_v = 3 * KAM + 3 * K;
   if (A * M > BIG_ST * threads) return -2;
   emu::launch([&] { big_stats_kernel(a); }, dim3(K, R), dim3(threads),
-              (((size_t)A * M + 3) & ~(size_t)3) * 4 + (size_t)(pool > 1 ? 5 : 3) * CH * 4 + 64 + (size_t)3 * threads * 4 +
+              (((size_t)A * M + 3) & ~(size_t)3) * 4 + (size_t)(pool > 1 ? 5 : 3) * CH * 4 + 64 + (size_t)12 * threads * 4 +
                   (size_t)((A + 3) & ~3) * 4 + (size_t)CH + M);
   host_reduce(partials.data(), R, row, K, KAM, ds, want_sparsity, skip_begin, skip_len, (float)n, sums);
   return row;
