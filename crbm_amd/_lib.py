@@ -97,6 +97,7 @@ SIGNATURES = {
     "crbm_free_energy_codes": (_I32, [_H, _U8P, _I32, _I32, _F, _F]),
     "crbm_free_energy_resident": (_I32, [_H, _I32, _I32, _F, _F]),
     "crbm_eval_data_resident": (_I32, [_H, _I32, _I32, _F, _F]),
+    "crbm_eval_epoch_resident": (_I32, [_H, _I32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "crbm_hit_summary": (_I32, [_H, _F, _I32, _I32, _F, _F, _F]),
     "crbm_hit_summary_codes": (_I32, [_H, _U8P, _I32, _I32, _F, _F, _F]),
     "crbm_hit_summary_resident": (_I32, [_H, _I32, _I32, _F, _F, _F]),

@@ -232,14 +232,6 @@ class CRBM(object):
         data = self._data(data)
         return "", (fptr(data), data.shape[0], data.shape[3]), data.shape[0], data.shape[3], data
 
-    @staticmethod
-    def _data_codes(data):
-        """(n,1,A,L) one-hot float array -> (n,L) uint8 letter codes; raises unless exactly one-hot."""
-        onehot = (data[:, 0] == 1.0)
-        if not (np.all(onehot.sum(axis=1) == 1) and np.all((data == 0.0) | (data == 1.0))):
-            raise Exception("HIP CRBM call failed (-3): visible data is not exactly one-hot")
-        return np.ascontiguousarray(np.argmax(onehot, axis=1).astype(np.uint8))
-
     # ------------------------------------------------------------- persistence
     def saveModel(self, filename):
         """convRBM.py:177-204 -- same pickle tuple."""
@@ -466,16 +458,19 @@ class CRBM(object):
         self._call("crbm_gibbs_steps", int(k))
 
     def _upload(self, data, slot):
-        """Make a data set resident in HBM (packed 2-bit) in the given slot; returns (n, L).
-        Ships one byte per base instead of the float one-hot array: 16x less PCIe traffic."""
+        """Make a data set resident in HBM (packed letters) in the given slot; returns (n, L).  Letter codes travel as they
+        are (one byte per base); a float one-hot array is streamed to the device in slabs and encoded -- and checked to be
+        exactly one-hot -- there: the PCIe copy of 16 bytes per base is an order of magnitude cheaper than any pass over the
+        array on the host (config #1: 3 ms of NumPy for 0.2 ms of copy)."""
+        self._call("crbm_dataset_select", slot)
         if self._is_codes(data):
             codes = np.ascontiguousarray(data)
-        else:
-            codes = self._data_codes(self._data(data))   # refuses anything that is not exactly one-hot
-        self._call("crbm_dataset_select", slot)
-        self._call("crbm_dataset_upload_codes", codes.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)),
-                   codes.shape[0], codes.shape[1])
-        return codes.shape
+            self._call("crbm_dataset_upload_codes", codes.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)),
+                       codes.shape[0], codes.shape[1])
+            return codes.shape
+        data = self._data(data)
+        self._call("crbm_dataset_upload", fptr(data), data.shape[0], data.shape[3])
+        return (data.shape[0], data.shape[3])
 
     def _truncate(self, data):
         """convRBM.py:586-599: truncate so that (L-M+1) % pooling == 0."""
@@ -538,22 +533,17 @@ class CRBM(object):
                 self._call("crbm_train_epoch_resident", self.batchsize)
             if not evaluates:
                 continue
-            meanfe = 0.0
-            meannmh = 0.0
-            nb = 0
+            # convRBM.py:616-625 on the resident test set: the loop over its mini-batches (mean free energy and mean
+            # sampled activity per batch, averaged over the batches) runs inside the library with one synchronisation
+            # -- 50 round trips per epoch at the reference's defaults were 4 of the 6 ms an epoch of config #1 took
             self._call("crbm_dataset_select", test_slot)
-            mfe, nmh = ctypes.c_float(), ctypes.c_float()
-            for [start, end] in self._iterateBatchIndices(ntest, self.batchsize):
-                # convRBM.py:619-625 on rows of the resident test set
-                self._call("crbm_eval_data_resident", start, end, ctypes.byref(mfe), ctypes.byref(nmh))
-                meanfe = meanfe + mfe.value
-                meannmh = meannmh + nmh.value
-                nb = nb + 1
+            mfe, nmh = ctypes.c_double(), ctypes.c_double()
+            self._call("crbm_eval_epoch_resident", self.batchsize, ctypes.byref(mfe), ctypes.byref(nmh))
             self._call("crbm_dataset_select", 0)
             [twn_, ic_, medic_] = self._evaluateParams()
             print(("Epoch {:d}: ".format(epoch) +
-                   "FE={:1.3f} ".format(meanfe / nb) +
-                   "NumH={:1.4f} ".format(meannmh / nb) +
+                   "FE={:1.3f} ".format(mfe.value) +
+                   "NumH={:1.4f} ".format(nmh.value) +
                    "WNorm={:2.2f} ".format(float(twn_)) +
                    "IC={:1.3f} medIC={:1.3f}".format(float(ic_), float(medic_))))
         if evaluates:
@@ -633,6 +623,13 @@ class CRBM(object):
         v = np.empty((nb, 1, self.input_dims, self.fantasy_hidden_len + self.motif_length - 1), dtype=np.float32)
         self._call("crbm_get_fantasy_visible", fptr(v))
         return v
+
+    def get_rng(self):
+        """(seed, gibbs_step, eval_step): the sampler's seed and its two step counters (counter word 3 of the chain draws and
+        of the evaluation draws)."""
+        seed, gstep, estep = ctypes.c_uint64(), ctypes.c_uint32(), ctypes.c_uint32()
+        self._call("crbm_get_rng", ctypes.byref(seed), ctypes.byref(gstep), ctypes.byref(estep))
+        return seed.value, gstep.value, estep.value
 
     def set_rng(self, seed=None, gibbs_step=0, eval_step=0):
         if seed is not None:

@@ -165,6 +165,7 @@ struct crbm_handle {
   DevBuf<float> out_a2, out_b2;
   DevBuf<uint32_t> dataset[CRBM_DATASET_SLOTS];   // resident data sets (slot 0: training, slot 1: test by convention)
   DevBuf<float> partials, partials2;
+  DevBuf<unsigned long long> eval_ones;            // sampled ones per mini-batch (crbm_eval_epoch_resident)
   float* d_sums = nullptr;
   int dataset_n[CRBM_DATASET_SLOTS] = {0, 0}, dataset_L[CRBM_DATASET_SLOTS] = {0, 0};
   int slot = 0;
@@ -2307,6 +2308,52 @@ int crbm_eval_data(crbm_handle* h, const float* v, int32_t n, int32_t L, float* 
   ENTER();
   ARGCHK(v && mfe && nmh, "null argument");
   return eval_data_any(h, host_onehot(v, n, L), mfe, nmh);
+}
+
+// The per-epoch evaluation of fit() (convRBM.py:616-625) in one call: the selected resident set is walked in mini-batches
+// of `batchsize` rows exactly as a loop over crbm_eval_data_resident would -- batch b draws its hidden sample with sampler
+// step eval_step + b and rows indexed from 0 -- but every launch is enqueued before the one read-back.  Returns the MEAN
+// OVER BATCHES of the batches' mean free energy and of their mean sampled hidden activity (what the reference's status
+// line prints: a short last batch weighs as much as a full one), each batch value rounded to float as the per-batch
+// entry point returns it.
+int crbm_eval_epoch_resident(crbm_handle* h, int32_t batchsize, double* mean_fe, double* mean_nmh) {
+  ENTER();
+  ARGCHK(mean_fe && mean_nmh, "null argument");
+  ARGCHK(batchsize >= 1, "batchsize must be positive");
+  const int slot = h->slot;
+  ARGCHK(h->dataset_n[slot] > 0, "no resident data set (call crbm_dataset_upload)");
+  const int n = h->dataset_n[slot], L = h->dataset_L[slot], LW = lw(h, L), Lh = L - h->M + 1;
+  int rc = check_data_shape(h, n, L);
+  if (rc) return rc;
+  const int nb = (n + batchsize - 1) / batchsize;
+  HIPCHK(h->eval_ones.ensure((size_t)nb));
+  HIPCHK(hipMemsetAsync(h->eval_ones.p, 0, (size_t)nb * sizeof(unsigned long long), h->stream));
+  const uint32_t* rows = h->dataset[slot].p;
+  rc = launch_free_energy(h, rows, n, L, sweep_set(h, 0));        // a row's free energy does not depend on its batch
+  if (rc) return rc;
+  for (int b = 0; b < nb; ++b) {
+    const int start = b * batchsize, cnt = std::min(batchsize, n - start);
+    rc = launch_hgv(h, rows + (size_t)start * LW, cnt, L, 0, nullptr, nullptr, nullptr, h->eval_ones.p + b, KIND_EVAL_H,
+                    h->eval_step + (uint32_t)b, 0u);
+    if (rc) return rc;
+  }
+  h->eval_step += (uint32_t)nb;
+  std::vector<float> fe((size_t)n);
+  std::vector<unsigned long long> ones((size_t)nb);
+  HIPCHK(hipMemcpyAsync(fe.data(), h->out_a.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(ones.data(), h->eval_ones.p, (size_t)nb * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  double sfe = 0.0, snmh = 0.0;
+  for (int b = 0; b < nb; ++b) {
+    const int start = b * batchsize, cnt = std::min(batchsize, n - start);
+    double tot = 0.0;
+    for (int i = 0; i < cnt; ++i) tot += fe[(size_t)start + i];
+    sfe += (double)(float)(tot / cnt);                                              // convRBM.py:636-638 per batch
+    snmh += (double)(float)((double)ones[(size_t)b] / ((double)cnt * h->K * Lh));     // :469-472
+  }
+  *mean_fe = sfe / nb;
+  *mean_nmh = snmh / nb;
+  return CRBM_OK;
 }
 
 int crbm_eval_data_resident(crbm_handle* h, int32_t start, int32_t end, float* mfe, float* nmh) {

@@ -182,6 +182,11 @@ int crbm_hit_probs_resident(crbm_handle* h, int32_t start, int32_t end, float* o
 int crbm_free_energy_codes(crbm_handle* h, const uint8_t* codes, int32_t n, int32_t L, float* fe, float* fe_per_motif);
 int crbm_free_energy_resident(crbm_handle* h, int32_t start, int32_t end, float* fe, float* fe_per_motif);
 int crbm_eval_data_resident(crbm_handle* h, int32_t start, int32_t end, float* mfe, float* nmh);
+/* The per-epoch evaluation loop of fit() (convRBM.py:616-625) over the selected resident data set in ONE call:
+ * mini-batches of `batchsize` rows exactly as a loop over crbm_eval_data_resident would take them (same sampler
+ * steps, one per batch), one host synchronisation.  Returns the mean over batches of the batches' mean free
+ * energy and mean sampled hidden activity -- the two numbers of the reference's status line. */
+int crbm_eval_epoch_resident(crbm_handle* h, int32_t batchsize, double* mean_fe, double* mean_nmh);
 /* The three reductions of theano_getHitProbs' output that the reference's
  * analysis code uses, without materialising (n,K,1,Lh):
  *   hit_max  (n,K)  = P.max(axis=(2,3))    utils.py:154, :242-244

@@ -940,6 +940,32 @@ def test_generic_kernels_on_a_model_the_specialised_ones_take(monkeypatch, capsy
     assert fast.get_fantasy()[0].sum() > 0
 
 
+@pytest.mark.parametrize("force_big", [False, True])
+def test_epoch_evaluation_in_one_call_is_the_loop_over_batches(force_big, monkeypatch):
+    """fit()'s per-epoch evaluation (convRBM.py:616-625) runs as ONE library call (crbm_eval_epoch_resident): the same
+    numbers, bit for bit, as the loop over crbm_eval_data_resident it replaces -- same sampler step per batch, a short last
+    batch weighing as much as a full one -- and the sampler has moved on by one step per batch."""
+    if force_big:
+        monkeypatch.setenv("CRBM_FORCE_BIG", "1")
+    model, _ = make_pair(10, 15, ds=True, batchsize=20, Lf=60, bshift=4.0)
+    D = synthetic_onehot(130, 74, seed=8)                     # 7 mini-batches, the last one of 10 rows
+    model._upload(D, 0)
+    model._call("crbm_dataset_select", 0)
+    model.set_rng(gibbs_step=0, eval_step=5)
+    mfe, nmh = ctypes.c_float(), ctypes.c_float()
+    sfe = snmh = 0.0
+    nb = 0
+    for start in range(0, 130, 20):
+        model._call("crbm_eval_data_resident", start, min(start + 20, 130), ctypes.byref(mfe), ctypes.byref(nmh))
+        sfe, snmh, nb = sfe + mfe.value, snmh + nmh.value, nb + 1
+    assert model.get_rng()[2] == 5 + nb
+    model.set_rng(gibbs_step=0, eval_step=5)
+    a, b = ctypes.c_double(), ctypes.c_double()
+    model._call("crbm_eval_epoch_resident", 20, ctypes.byref(a), ctypes.byref(b))
+    assert a.value == sfe / nb and b.value == snmh / nb
+    assert b.value > 0 and model.get_rng()[2] == 5 + nb
+
+
 # ---- pooling > 1 (convRBM.py:245-267, :586-599, :664-665) ---------------------------------
 @pytest.mark.parametrize("K,M,ds,pool", [(6, 7, True, 2), (10, 15, False, 4), (5, 8, True, 3)])
 def test_pooling(K, M, ds, pool, capsys):
