@@ -19,7 +19,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
-HEADERS = ["crbm_kernels.h", "crbm_layout.h", "crbm_jit.h", os.path.join("..", "..", "include", "crbm_amd.h")]
+HEADERS = ["crbm_kernels.h", "crbm_kernels_generic.h", "crbm_layout.h", "crbm_jit.h", os.path.join("..", "..", "include", "crbm_amd.h")]
 
 
 def _newer(target, deps):

@@ -13,7 +13,7 @@ EMU = os.path.join(HERE, "emu")
 CSRC = os.path.join(os.path.dirname(HERE), "crbm_amd", "csrc")
 LIB = os.path.join(EMU, "libcrbm_emu.so")
 SOURCES = [os.path.join(EMU, "emu_main.cpp"), os.path.join(EMU, "shim", "hip", "hip_runtime.h"),
-           os.path.join(CSRC, "crbm_kernels.h"), os.path.join(CSRC, "crbm_layout.h")]
+           os.path.join(CSRC, "crbm_kernels.h"), os.path.join(CSRC, "crbm_kernels_generic.h"), os.path.join(CSRC, "crbm_layout.h")]
 
 
 def _gcc_file(name):
