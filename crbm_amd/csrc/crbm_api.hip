@@ -1241,7 +1241,7 @@ int crbm_precompile(const crbm_config* cfg) {
   std::string file, err;
   const int Lf_pc = cfg->fantasy_hidden_len > 0 ? cfg->fantasy_hidden_len : 200;
   const int ncu = env_int("CRBM_NUM_CU", 256);
-  if (cfg->num_motifs > MAX_MOTIFS || cfg->motif_length > MAX_MOTIF_LENGTH || model_needs_big(ms, Lf_pc, cfg->batchsize, ncu))
+  if (cfg->num_motifs > MAX_MOTIFS || cfg->motif_length > MAX_MOTIF_LENGTH || cfg->input_dims != 4 || model_needs_big(ms, Lf_pc, cfg->batchsize, ncu))
     return CRBM_OK;     // the generic kernels are compiled ahead of time: nothing to specialise
   const GibbsGeom gs = choose_gibbs_geometry(ms, Lf_pc, cfg->batchsize, ncu, true);
   int tb = gs.threads;
