@@ -17,25 +17,41 @@ for _i, _ch in enumerate("ACGT"):
     _LUT[ord(_ch.lower())] = _i
 
 
-def seqsToCodes(seqs):
-    """list of equal-length DNA strings -> uint8 array (n, L) of codes 0..3.
+PROTEIN = "ACDEFGHIKLMNPQRSTVWY"      # the 20 amino acids, alphabetical one-letter codes (an `input_dims=20` model)
+
+
+def _lut(alphabet):
+    if alphabet == "ACGT":
+        return _LUT
+    if len(set(alphabet.upper())) != len(alphabet) or not 1 <= len(alphabet) <= 64:
+        raise Exception("alphabet: 1 to 64 distinct letters")
+    lut = np.full(256, 255, dtype=np.uint8)
+    for i, ch in enumerate(alphabet):
+        lut[ord(ch.upper())] = i
+        lut[ord(ch.lower())] = i
+    return lut
+
+
+def seqsToCodes(seqs, alphabet="ACGT"):
+    """list of equal-length strings -> uint8 array (n, L) of codes 0..len(alphabet)-1 (DNA by default: 0..3 = A,C,G,T).
     Sequences containing other letters (e.g. N) raise, like the reference
-    skips them at read time (sequences.py:47-51)."""
+    skips them at read time (sequences.py:47-51).  Another `alphabet` (e.g. sequences.PROTEIN) gives the codes of a
+    model built with input_dims=len(alphabet)."""
     seqs = [s if isinstance(s, str) else str(s) for s in seqs]
     if len({len(s) for s in seqs}) > 1:
         raise Exception("all sequences must have the same length")
     raw = np.frombuffer("".join(seqs).encode("ascii"), dtype=np.uint8).reshape(len(seqs), -1)
-    codes = _LUT[raw]
-    if (codes > 3).any():
-        raise Exception("sequences may only contain A, C, G, T")
+    codes = _lut(alphabet)[raw]
+    if (codes >= len(alphabet)).any():
+        raise Exception("sequences may only contain %s" % ", ".join(alphabet))
     return codes
 
 
-def codesToOneHot(codes):
-    """(n, L) codes -> (n,1,4,L) float32 one-hot, the layout of seqToOneHot (sequences.py:101-117)."""
+def codesToOneHot(codes, input_dims=4):
+    """(n, L) codes -> (n,1,input_dims,L) float32 one-hot, the layout of seqToOneHot (sequences.py:101-117)."""
     codes = np.asarray(codes)
     n, L = codes.shape
-    out = np.zeros((n, 1, 4, L), dtype=np.float32)
+    out = np.zeros((n, 1, input_dims, L), dtype=np.float32)
     out[np.arange(n)[:, None], 0, codes, np.arange(L)[None, :]] = 1
     return out
 

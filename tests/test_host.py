@@ -111,6 +111,13 @@ def test_sequence_helpers():
         seqsToCodes(["ACGN"])
     with pytest.raises(Exception):
         seqsToCodes(["ACG", "AC"])
+    # another alphabet: the codes of an input_dims = 20 model (README "Limits")
+    from crbm_amd import sequences as sq2
+    p = seqsToCodes(["MKV", "acd"], sq2.PROTEIN)
+    np.testing.assert_array_equal(p, [[10, 8, 17], [0, 1, 2]])
+    assert codesToOneHot(p, 20).shape == (2, 1, 20, 3) and codesToOneHot(p, 20).sum() == 6
+    with pytest.raises(Exception, match="may only contain"):
+        seqsToCodes(["MKB"], sq2.PROTEIN)
 
 
 # ---- sequences.py / utils.py counterparts ---------------------------
