@@ -24,7 +24,7 @@ __device__ __forceinline__ uint32_t letter_at(const BigModel& m, const uint32_t*
   if (m.A == 4) return (row[p >> 4] >> (2 * (p & 15))) & 3u;
   return reinterpret_cast<const unsigned char*>(row)[p];
 }
-__device__ __forceinline__ float sigmoid_x(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float sigmoid_x(float x) { return fast_rcp(1.0f + __expf(-x)); }   // v_rcp_f32 (1 ulp), as sigmoid_z
 
 // block-wide sum in a fixed order (waves through DPP, then wave totals through LDS); all threads get the total
 __device__ __forceinline__ float big_block_sum(float v, float* xch) {
@@ -165,6 +165,7 @@ __device__ __forceinline__ void big_hgv_body(const BigHgvArgs& a) {
         }
         uint32_t bits = 0u;
         uint32_t last_g = 0xFFFFFFFFu;
+        bool have_fine = false;
         Philox4 rcs = {}, rfs = {};
         const uint32_t gn = a.rng.seq_offset + (uint32_t)nn;
 #pragma unroll
@@ -178,10 +179,25 @@ __device__ __forceinline__ void big_hgv_body(const BigHgvArgs& a) {
               const uint32_t g = (uint32_t)gk / 10u, i10 = (uint32_t)gk - 10u * g;
               if (g != last_g) {
                 rcs = philox4x32(gn, (uint32_t)su, rng_word2(a.kind, strand, 0, g), a.rng.step, a.rng.seed_lo, a.rng.seed_hi);
-                rfs = philox4x32(gn, (uint32_t)su, rng_word2(a.kind, strand, 1, g), a.rng.step, a.rng.seed_lo, a.rng.seed_hi);
                 last_g = g;
+                have_fine = false;
               }
-              const float u = (float)(philox_field12_dyn(rcs, (int)i10) * 4096u + philox_field12_dyn(rfs, (int)i10)) * 5.9604644775390625e-8f;
+              // u = (coarse * 4096 + fine) / 2^24 (crbm_kernels.h, sample_hidden).  The coarse field alone decides unless a
+              // threshold falls inside its bucket of 4096 (2^-12 of the unpooled units): the fine call is made only then.
+              // Exact: p * 2^24 and the integers below 2^24 are floats, the comparisons are those of p > u itself.
+              const uint32_t coarse = philox_field12_dyn(rcs, (int)i10);
+              const float lo24 = (float)(coarse * 4096u), hi24 = (float)(coarse * 4096u + 4096u);
+              const float t0 = (POOLED ? cb[k] : p[k]) * 16777216.0f, t1 = POOLED ? (cb[k] + p[k]) * 16777216.0f : t0;
+              const bool inside0 = t0 > lo24 && t0 < hi24, inside1 = POOLED && t1 > lo24 && t1 < hi24;
+              uint32_t fine = 0u;
+              if (inside0 || inside1) {
+                if (!have_fine) {
+                  rfs = philox4x32(gn, (uint32_t)su, rng_word2(a.kind, strand, 1, g), a.rng.step, a.rng.seed_lo, a.rng.seed_hi);
+                  have_fine = true;
+                }
+                fine = philox_field12_dyn(rfs, (int)i10);
+              }
+              const float u = (float)(coarse * 4096u + fine) * 5.9604644775390625e-8f;
               // unpooled: h = 1 if p > u; pooled: the first unit of the group whose cumulative probability exceeds u
               const uint32_t hb = POOLED ? ((cb[k] + p[k] > u && cb[k] <= u) ? 1u : 0u) : (p[k] > u ? 1u : 0u);
               if (a.sample) a.sample[idx] = (float)hb;
