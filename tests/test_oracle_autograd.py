@@ -187,3 +187,51 @@ def test_free_energy_is_minus_log_of_the_summed_out_hidden_layer():
             h = np.array(bits, dtype=np.float64).reshape(K, Lh)
             z += np.exp((h * x[n, :, 0, :]).sum() + vis)       # -E(v,h) = sum h x + sum v c
         np.testing.assert_allclose(o.freeEnergy(D)[n], -np.log(z) / L, rtol=1e-12)
+
+
+@pytest.mark.parametrize("K,M,ds,pool,A", [(6, 5, True, 1, 4), (7, 9, False, 1, 4), (4, 6, True, 2, 4), (5, 7, False, 3, 4), (4, 5, True, 1, 20)])
+def test_evaluation_graphs_match_the_transcription(K, M, ds, pool, A):
+    """convRBM.py:466-514 and :657-697 transcribed: free energy per data point (divided by the sequence length) and per motif
+    (not divided), the mean free energy, the status-line metrics (rms of the filters, information content against
+    log2 of the alphabet size, its median form) and the two branches of getHitProbs -- doublestranded: the forward strand's
+    probabilities; single-stranded: the probability of the SUM of both strands' activations (:507-514)."""
+    Lf = 6 * pool
+    L = M - 1 + Lf
+    rng = np.random.default_rng(3 * K + M)
+    o = OracleCRBM(K, M, doublestranded=ds, pooling=pool, input_dims=A, W=rng.standard_normal((K, 1, A, M)) * 0.9)
+    o.b = o.b + 6.0
+    o.c = rng.standard_normal((1, A)) * 0.3
+    g = GraphCRBM(o)
+    Dn = synthetic_onehot(5, L, seed=K, A=A)
+    D = torch.tensor(Dn, dtype=T64)
+
+    def fe(per_motif):
+        axes = (2, 3) if per_motif else (1, 2, 3)
+        with torch.no_grad():
+            x = g.bottomUpActivity(D)
+            x = x.reshape(*x.shape[:3], x.shape[3] // pool, pool)
+            f = -torch.sum(torch.log(1.0 + torch.sum(torch.exp(x), dim=4)), dim=axes)
+            if ds:
+                x = g.bottomUpActivity(D, True)
+                x = x.reshape(*x.shape[:3], x.shape[3] // pool, pool)
+                f = f - torch.sum(torch.log(1.0 + torch.sum(torch.exp(x), dim=4)), dim=axes)
+            vis = torch.sum(D * g.c.reshape(1, 1, -1, 1), dim=(1, 2, 3))
+            return (f - vis[:, None]) if per_motif else (f - vis) / D.shape[3]
+    np.testing.assert_allclose(o.freeEnergy(Dn), fe(False).numpy(), rtol=1e-12)
+    np.testing.assert_allclose(o.freeEnergy(Dn, True), fe(True).numpy(), rtol=1e-12)
+    np.testing.assert_allclose(o._meanFreeEnergy(Dn), float(torch.sum(fe(False)) / D.shape[0]), rtol=1e-12)
+    with torch.no_grad():
+        W = g.motifs
+        twn = torch.sqrt(torch.mean(W ** 2))
+        pwm = torch.exp(W) / torch.exp(W).sum(dim=2, keepdim=True)
+        ent = torch.sum(-pwm * torch.log2(pwm), dim=2)                       # (K,1,M)
+        ic = np.log2(W.shape[2]) - torch.mean(ent)
+        medic = np.log2(W.shape[2]) - torch.mean(torch.sort(ent, dim=2)[0][:, :, ent.shape[2] // 2])
+        if ds:
+            hits = g.bottomUpProbability(g.bottomUpActivity(D))
+        else:
+            hits = g.bottomUpProbability(g.bottomUpActivity(D) + g.bottomUpActivity(D, True))
+    np.testing.assert_allclose(o.evaluateParams(), [float(twn), float(ic), float(medic)], rtol=1e-12)
+    np.testing.assert_allclose(o.motifHitProbs(Dn), hits.numpy(), rtol=1e-12)
+    pf = o.getPFMs()
+    np.testing.assert_allclose(np.stack(pf), pwm[:, 0].numpy(), rtol=1e-12)
