@@ -912,6 +912,22 @@ def test_other_alphabets(A, K, M, ds, L, n, pool, capsys):
     assert again.input_dims == A
     np.testing.assert_array_equal(again.motifs.get_value(), model.motifs.get_value())
     np.testing.assert_array_equal(again.freeEnergy(D), model.freeEnergy(D))
+    # the full training state resumes exactly: step -> saveState -> loadState -> step equals two steps
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "s.state")
+        model._trainingFct(D)
+        model.saveState(path)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", UserWarning)
+            resumed = CRBM.loadState(path)
+        model._trainingFct(D)
+        resumed._trainingFct(D)
+    np.testing.assert_array_equal(resumed.motifs.get_value(), model.motifs.get_value())
+    np.testing.assert_array_equal(resumed.c.get_value(), model.c.get_value())
+    for x, y in zip(resumed.get_fantasy(), model.get_fantasy()):
+        if x is not None:
+            np.testing.assert_array_equal(x, y)
+    np.testing.assert_array_equal(resumed.get_fantasy_visible(), model.get_fantasy_visible())
 
 
 def test_generic_kernels_on_a_model_the_specialised_ones_take(monkeypatch, capsys):
