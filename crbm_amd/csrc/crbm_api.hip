@@ -230,6 +230,14 @@ struct crbm_handle {
   unsigned long long* d_timeline = nullptr;   // CRBM_GIBBS_TIMELINE: first / last tick of block 0 of every launch of a crbm_time_gibbs call
   int timeline_cap = 0, timeline_next = 0;
   unsigned long long ipc_timeout_ticks = 0;   // bound of an update launch's wait for its peers, in ticks of the GPU's wall clock
+  // Statistics of a generic DNA model on the matrix cores, a slab of motifs at a time (slab_launch_stats): a shadow handle
+  // of the slab model -- slab->K motifs, its specialised kernels, its partial rows and nothing else (the stream is this
+  // handle's) -- and one table image per slab, rebuilt when the parameters have changed
+  crbm_handle* slab = nullptr;
+  float* d_slab_tables = nullptr;
+  int slab_n = 0;
+  uint64_t slab_tables_version = 0;
+  std::string slab_note;               // why the slabs are off, if they are (crbm_launch_info prints nothing of it; a debugging aid)
   std::string err;
 };
 
@@ -356,8 +364,16 @@ int big_launch_gibbs(crbm_handle* h, int steps, hipStream_t st) {
   return CRBM_OK;
 }
 
+constexpr int SLAB_FALLBACK = -1000;     // slab_launch_stats: nothing launched, take the generic kernel
+int slab_launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool data_half, hipStream_t st, ReduceArgs* reduce);
+
 // raw statistic sums of (letters, n, L) into partial rows; the column reduction is handed back like launch_stats does
+// (reduce->row == 0: nothing left to reduce -- the slabbed form below has written the sums itself)
 int big_launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool data_half, hipStream_t st, ReduceArgs* reduce) {
+  if (h->slab) {
+    const int rc = slab_launch_stats(h, d_letters, n, L, data_half, st, reduce);
+    if (rc != SLAB_FALLBACK) return rc;
+  }
   DevBuf<float>& pbuf = data_half ? h->partials : h->partials2;
   const int K = h->K, M = h->M, KAM = h->KAM;
   BigStatsArgs a;
@@ -788,6 +804,124 @@ int prepare_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool 
   return CRBM_OK;
 }
 
+// The statistics of a generic DNA model (motif_length <= 64) on the matrix cores.  VH[k], H[k] and the sparsity sums of motif
+// k depend on that motif's filter alone, so the model is a row of independent sub-models of `slab->K` motifs: the
+// specialised statistics kernel of that sub-model (stats_mfma_body: gather table in LDS, P split into f16 halves,
+// v_mfma_f32_16x16x32_f16) runs once per slab on the slab's own table image -- W and b of a slab are contiguous pieces of
+// the model's (K,4,M) and (K) arrays -- and slab_reduce_kernel adds the slab's partial rows into its columns of d_sums.
+// The last slab of a model whose K is not a multiple of the slab is moved back to end at K: the motifs it shares with its
+// neighbour get the same sums twice (an accumulator's value does not depend on the column it sits in).
+int slab_launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool data_half, hipStream_t st, ReduceArgs* reduce) {
+  crbm_handle* s = h->slab;
+  const int Ks = s->K, M = h->M;
+  s->err.clear();
+  if (h->slab_tables_version != h->params_version) {
+    for (int i = 0; i < h->slab_n; ++i) {
+      const int k0 = std::min(i * Ks, h->K - Ks);
+      TablesArgs t;
+      t.W = h->dW + (size_t)k0 * 4 * M; t.b = h->db + k0; t.c = h->dc;
+      t.out = h->d_slab_tables + (size_t)i * s->ms.TABLES_ALL;
+      const unsigned grid = (unsigned)std::max(1, std::min((s->ms.TABLES_ALL + 255) / 256, h->num_cu * 4));
+      HIPCHK(jit_launch(s->jk.build_tables, t, grid, 1, 256, 0, st));
+    }
+    h->slab_tables_version = h->params_version;
+  }
+  for (int i = 0; i < h->slab_n; ++i) {
+    const int k0 = std::min(i * Ks, h->K - Ks);
+    s->d_tables = h->d_slab_tables + (size_t)i * s->ms.TABLES_ALL;
+    StatsMfmaArgs a;
+    ReduceArgs r;
+    int lds = 0, gx = 0, block = 0;
+    const int rc = prepare_stats(s, d_letters, n, L, data_half, 0, &a, &lds, &gx, &block, &r);
+    if (rc) {
+      if (i == 0 && rc == CRBM_ERR_INVALID) return SLAB_FALLBACK;   // (a data set whose rows the slab kernel's LDS does not take)
+      return fail(h, rc, "slabbed statistics: " + s->err);
+    }
+    if (jit_launch(data_half ? s->jk.stats_mfma_data : s->jk.stats_mfma_model, a, (unsigned)gx, 1, (unsigned)block, (unsigned)lds, st) != hipSuccess)
+      return fail(h, CRBM_ERR_HIP, "launch of the slab statistics kernel failed");
+    SlabReduceArgs ra;
+    ra.partials = r.partials;
+    ra.sums = h->d_sums + (data_half ? h->sl.data_off : h->sl.model_off);
+    ra.nrows = r.nrows; ra.row = r.row;
+    ra.Ks = Ks; ra.k0 = k0; ra.K = h->K; ra.M4 = 4 * M;
+    ra.ds = h->ds; ra.want_sparsity = data_half ? 1 : 0;
+    const int full_row = 3 * h->KAM + 3 * h->K + 4;
+    ra.skip_begin = data_half ? full_row : h->sl.model_skip_begin;
+    ra.skip_len = data_half ? 0 : h->sl.model_skip_len;
+    ra.n_value = (float)n;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((ra.row + 31) / 32), dim3(1024), 0, st, ra);
+    HIPCHK(hipGetLastError());
+  }
+  *reduce = ReduceArgs();
+  reduce->nrows = 0; reduce->row = 0;     // nothing left for the caller's column reduction
+  return CRBM_OK;
+}
+
+// The shadow handle of the slab model of a generic handle (crbm_create); leaves h->slab null, with the reason in
+// h->slab_note, when the model is not one for slabs.  CRBM_SLAB_STATS=0 switches them off (A/B runs, tests).
+int slab_setup(crbm_handle* h) {
+  if (!h->big) return CRBM_OK;
+  if (env_int("CRBM_SLAB_STATS", 1) == 0) { h->slab_note = "CRBM_SLAB_STATS=0"; return CRBM_OK; }
+  if (h->A != 4 || h->M > MAX_MOTIF_LENGTH) { h->slab_note = "other alphabet, or motifs beyond 64 letters"; return CRBM_OK; }
+  const int want = env_int("CRBM_SLAB_MOTIFS", 64);
+  int Ks = 0, G = 0;
+  ModelShape ms;
+  for (int cand : {std::min(h->K, std::max(1, std::min(want, MAX_MOTIFS))), 48, 32, 16}) {
+    if (cand > h->K) continue;
+    G = choose_group(cand, h->M, h->ds, env_int("CRBM_TABLE_BUDGET", 26 * 1024));
+    ms = model_shape(cand, h->M, h->ds, G, h->ms.POOL);
+    bool fit = true;
+    for (int want_sp = 0; want_sp <= 1 && fit; ++want_sp) {
+      const int tabs = ms.TAB * 4;
+      const StatsMfmaLayout st = stats_mfma_layout(ms, want_sp, h->Lf, 0, tabs, true);
+      if (st.threads > 1024 || std::max(st.region_floats * 4 + tabs, st.combine_bytes) > 160 * 1024) fit = false;
+    }
+    if (fit) { Ks = cand; break; }
+  }
+  if (!Ks) { h->slab_note = "no slab of this motif length fits the LDS"; return CRBM_OK; }
+  crbm_handle* s = new crbm_handle();
+  std::string err;
+  if (jit_load(Ks, h->M, h->ds, G, G, ms.POOL, 0, 256, &s->jk, &err) != 0) {
+    h->slab_note = "kernel specialisation of the slab failed: " + err;
+    if (s->jk.module) (void)hipModuleUnload(s->jk.module);
+    delete s;
+    return CRBM_OK;
+  }
+  s->cfg = h->cfg; s->cfg.num_motifs = Ks;
+  s->K = Ks; s->M = h->M; s->ds = h->ds; s->A = 4; s->G = G; s->GS = G; s->KAM = Ks * 4 * h->M;
+  s->ms = ms; s->ms_solo = ms; s->NW = ms.NW;
+  s->Lf = h->Lf; s->Lv = h->Lv; s->B = h->B;
+  s->device = h->device; s->num_cu = h->num_cu;
+  s->stream = h->stream;                 // borrowed: never destroyed through the shadow
+  s->big = false; s->tables_dirty = false;
+  s->sl = sums_layout(Ks, h->M);
+  s->stats_rows = h->stats_rows;
+  h->slab_n = (h->K + Ks - 1) / Ks;
+  if (hipMalloc((void**)&s->d_sums, (size_t)s->sl.count * 4) != hipSuccess ||
+      hipMalloc((void**)&h->d_slab_tables, (size_t)h->slab_n * ms.TABLES_ALL * 4) != hipSuccess) {
+    (void)hipGetLastError();
+    if (s->d_sums) (void)hipFree(s->d_sums);
+    if (h->d_slab_tables) { (void)hipFree(h->d_slab_tables); h->d_slab_tables = nullptr; }
+    (void)hipModuleUnload(s->jk.module);
+    delete s;
+    h->slab_note = "no memory for the slab tables";
+    return CRBM_OK;
+  }
+  h->slab = s;
+  return CRBM_OK;
+}
+
+void slab_destroy(crbm_handle* h) {
+  if (crbm_handle* s = h->slab) {
+    if (s->d_sums) (void)hipFree(s->d_sums);
+    s->partials.release(); s->partials2.release();
+    if (s->jk.module) (void)hipModuleUnload(s->jk.module);
+    delete s;
+    h->slab = nullptr;
+  }
+  if (h->d_slab_tables) { (void)hipFree(h->d_slab_tables); h->d_slab_tables = nullptr; }
+}
+
 // stand-alone launch; the column reduction is handed back to the caller (`defer`, to pair it with the
 // other half) or launched here
 int launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool data_half, hipStream_t s = nullptr,
@@ -807,6 +941,7 @@ int launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool d
   }
   if (rc) return rc;
   if (defer) { *defer = r; return CRBM_OK; }
+  if (r.row == 0) return CRBM_OK;        // slabbed statistics: the sums are written
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((r.row + 31) / 32), dim3(1024), 0, s, r);
   HIPCHK(hipGetLastError());
   return CRBM_OK;
@@ -858,6 +993,14 @@ uint32_t* ipc_flag_of(void* base, const crbm_handle* h, int parity, int source);
 // the column reductions of both halves in one launch; with the mapped-buffer all-reduce on, straight into this
 // rank's published buffer, flag included (reduce_publish_pair_kernel)
 int launch_reduce_pair(crbm_handle* h, ReducePair pair, bool publish) {
+  if (pair.half[0].row == 0 || pair.half[1].row == 0) {      // slabbed statistics have written their sums themselves (slab_launch_stats)
+    for (auto& half : pair.half)
+      if (half.row > 0) {
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((half.row + 31) / 32), dim3(1024), 0, h->stream, half);
+        HIPCHK(hipGetLastError());
+      }
+    return CRBM_OK;
+  }
   const dim3 grid((pair.half[0].row + 31) / 32, 2);
   if (publish && h->ipc_on) {
     // this rank's slot of the step's parity in every rank's buffer, the own one as the base the others are offsets of
@@ -1430,6 +1573,7 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
     }
   }
   hh->stats_rows = env_int("CRBM_STATS_ROWS", 0);   // 0: one resident wave of blocks
+  slab_setup(hh);                                   // generic DNA models: their statistics on the matrix cores, slab by slab
   *out = hh;
   return CRBM_OK;
 }
@@ -1460,6 +1604,7 @@ int crbm_destroy(crbm_handle* h) {
   for (int r = 0; r < IPC_MAX_RANKS; ++r)
     if (h->ipc_peer[r] && h->ipc_peer[r] != h->ipc_buf) (void)hipIpcCloseMemHandle(h->ipc_peer[r]);
   if (h->ipc_buf) (void)hipFree(h->ipc_buf);
+  slab_destroy(h);
   void* ptrs[] = {h->dW2, h->db2, h->dc2, h->dvW2, h->dvb2, h->dvc2, h->dW, h->db, h->dc, h->dvW, h->dvb, h->dvc, h->d_hm, h->d_hmp, h->d_vf, h->d_flags, h->d_ones, h->d_nset, h->d_sums, h->d_ticket, h->d_tables, h->d_tf_solo, h->d_probe, h->d_timeline};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);

@@ -733,3 +733,64 @@ __global__ void __launch_bounds__(256) big_eval_kernel(BigEvalArgs a) {
   }
 }
 
+
+// ---- Statistics of large DNA models on the matrix cores, a slab of motifs at a time -----------------------------------
+// VH[k], H[k] and the sparsity sums of motif k depend on that motif's filter alone (convRBM.py:327-371, :440-451), so a model
+// whose tables exceed the LDS is, for the statistics, a row of independent sub-models: crbm_api.hip runs the SPECIALISED
+// statistics kernel (stats_mfma_body, compiled for a slab of <= 64 motifs) once per slab on the slab's own gather table,
+// and this kernel reduces the slab's partial rows column by column -- like reduce_partials_body -- straight into the
+// slab's columns of the full model's sums ([vh K*4*M][vh' K*4*M][h K][h' K][sw K*4*M][sb K][v 4] n, the model half
+// without sw, sb).  The letter counts and n do not depend on the motifs: every slab writes the same values.
+struct SlabReduceArgs {
+  const float* partials;   // [nrows][row] partial rows of the slab model
+  float* sums;             // the full model's sums of this half (d_sums + data_off or model_off)
+  int32_t nrows, row;      // row = 3 Ks 4M + 3 Ks + 4
+  int32_t Ks, k0, K, M4;   // motifs of the slab, its first motif, motifs of the model, 4 * motif_length
+  int32_t ds, want_sparsity;
+  int32_t skip_begin, skip_len;   // columns of the FULL row that are not carried (model half: sw, sb)
+  float n_value;
+};
+
+__global__ void __launch_bounds__(1024) slab_reduce_kernel(SlabReduceArgs a) {
+  __shared__ float part[32][33];
+  const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int ngrp = (int)(blockDim.x >> 5);
+  const int r = blockIdx.x * 32 + col;
+  const int Ks = a.Ks, K = a.K, KAMs = a.Ks * a.M4, KAM = a.K * a.M4;
+  int dst = -1;          // column of the full row
+  bool valid = false;
+  if (r < a.row) {
+    if (r < KAMs) { dst = a.k0 * a.M4 + r; valid = true; }
+    else if (r < 2 * KAMs) { dst = KAM + a.k0 * a.M4 + (r - KAMs); valid = a.ds != 0; }
+    else if (r < 2 * KAMs + Ks) { dst = 2 * KAM + a.k0 + (r - 2 * KAMs); valid = true; }
+    else if (r < 2 * KAMs + 2 * Ks) { dst = 2 * KAM + K + a.k0 + (r - 2 * KAMs - Ks); valid = a.ds != 0; }
+    else if (r < 3 * KAMs + 2 * Ks) { dst = 2 * KAM + 2 * K + a.k0 * a.M4 + (r - 2 * KAMs - 2 * Ks); valid = a.want_sparsity != 0; }
+    else if (r < 3 * KAMs + 3 * Ks) { dst = 3 * KAM + 2 * K + a.k0 + (r - 3 * KAMs - 2 * Ks); valid = a.want_sparsity != 0; }
+    else { dst = 3 * KAM + 3 * K + (r - 3 * KAMs - 3 * Ks); valid = true; }
+  }
+  float tsum = 0.f;
+  if (valid) {      // eight rows in flight per thread, fixed order (reduce_partials_body)
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f, t4 = 0.f, t5 = 0.f, t6 = 0.f, t7 = 0.f;
+    int i = grp;
+    for (; i + 7 * ngrp < a.nrows; i += 8 * ngrp) {
+      const float v0 = a.partials[(size_t)i * a.row + r], v1 = a.partials[(size_t)(i + ngrp) * a.row + r];
+      const float v2 = a.partials[(size_t)(i + 2 * ngrp) * a.row + r], v3 = a.partials[(size_t)(i + 3 * ngrp) * a.row + r];
+      const float v4 = a.partials[(size_t)(i + 4 * ngrp) * a.row + r], v5 = a.partials[(size_t)(i + 5 * ngrp) * a.row + r];
+      const float v6 = a.partials[(size_t)(i + 6 * ngrp) * a.row + r], v7 = a.partials[(size_t)(i + 7 * ngrp) * a.row + r];
+      t0 += v0; t1 += v1; t2 += v2; t3 += v3; t4 += v4; t5 += v5; t6 += v6; t7 += v7;
+    }
+    for (; i < a.nrows; i += ngrp) t0 += a.partials[(size_t)i * a.row + r];
+    tsum = ((t0 + t1) + (t2 + t3)) + ((t4 + t5) + (t6 + t7));
+  }
+  part[grp][col] = tsum;
+  __syncthreads();
+  if (grp == 0 && dst >= 0) {
+    const bool skipped = dst >= a.skip_begin && dst < a.skip_begin + a.skip_len;
+    if (!skipped) {
+      float s = 0.f;
+      for (int g = 0; g < ngrp; ++g) s += part[g][col];
+      a.sums[dst < a.skip_begin ? dst : dst - a.skip_len] = s;     // (columns of a kind the model does not have: zero, as the plain reduction writes them)
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.sums[(3 * KAM + 3 * K + 4) - a.skip_len] = a.n_value;
+}

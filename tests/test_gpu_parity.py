@@ -1051,6 +1051,54 @@ def check_pooling(K, M, ds, pool, capsys):
     assert "Epoch 0: FE=" in capsys.readouterr().out
 
 
+@pytest.mark.parametrize("K,M,ds,pool", [(300, 10, False, 1), (120, 40, True, 1), (257, 1, False, 1), (150, 6, True, 2), (70, 33, True, 1)])
+def test_slabbed_statistics_of_generic_models(K, M, ds, pool, monkeypatch):
+    """Generic DNA models (motif_length <= 64) take their statistics from the specialised MFMA kernel, a slab of at most 64
+    motifs at a time (crbm_api.hip, slab_launch_stats): the packed raw sums of a training step -- both halves, through
+    crbm_train_local -- equal those of the plain generic statistics kernel (CRBM_SLAB_STATS=0) within float rounding and the
+    oracle's within the tolerance of every other statistics test.  257 = 4 x 64 + 1: the last slab is moved back to end at K.
+    (70 x 33 double-stranded runs on the specialised kernels anyway: CRBM_FORCE_BIG puts it on one slab of 64 and one of 6.)"""
+    import ctypes
+    from crbm_amd import CRBM
+    from crbm_amd._lib import fptr
+    if K == 70:
+        monkeypatch.setenv("CRBM_FORCE_BIG", "1")
+    Lf, B, n = 12 * pool, 6, 10
+    L = Lf + M - 1
+    W = (np.random.default_rng(K + M).standard_normal((K, 1, 4, M)) * 0.6).astype(np.float32)
+    D = synthetic_onehot(n, L, seed=17)
+
+    def run(slabs):
+        monkeypatch.setenv("CRBM_SLAB_STATS", "1" if slabs else "0")
+        m = CRBM(K, M, doublestranded=ds, batchsize=B, cd_k=2, pooling=pool, fantasy_hidden_len=Lf, seed=9, rho=0.02)
+        m.motifs.set_value(W)
+        m.bias.set_value((m.bias.get_value() + 3.0).astype(np.float32))
+        h_ = m._h()
+        buf = np.zeros(m._lib.crbm_sums_count(h_), dtype=np.float32)
+        m._call("crbm_train_local", fptr(D), n, L, fptr(buf))
+        return m, buf
+    m1, with_slabs = run(True)
+    m0, plain = run(False)
+    for a, b in zip(m1.get_fantasy(), m0.get_fantasy()):
+        if a is not None:
+            np.testing.assert_array_equal(a, b)                 # the chain does not depend on the statistics path
+    got, ref = _unpack_sums(with_slabs, K, M), _unpack_sums(plain, K, M)
+    for key in ref:
+        scale = float(np.abs(ref[key]).max()) if np.size(ref[key]) else 0.0
+        np.testing.assert_allclose(got[key], ref[key], rtol=RTOL, atol=1e-5 + 2e-6 * scale, err_msg=key)
+    assert np.abs(got["vh_d"]).max() > 0 and np.abs(got["sw"]).max() > 0 and got["n_d"] == n and got["n_m"] == B
+    # and the oracle, from the chain the handle sampled (ties aside, it is the oracle's own)
+    o = OracleCRBM(K, M, doublestranded=ds, batchsize=B, cd_k=2, pooling=pool, fantasy_hidden_len=Lf, seed=9, rho=0.02, W=W)
+    o.b = m1.bias.get_value().astype(np.float64)
+    P_m, P_mp, v_m = o.gibbs_steps(2)
+    h1, h1p = m1.get_fantasy()
+    if np.array_equal(h1, o.fantasy_h) and (not ds or np.array_equal(h1p, o.fantasy_h_prime)):
+        want = o.local_sums(D, P_m, P_mp, v_m)
+        for key in ("vh_d", "h_d", "sw", "sb", "v_d", "vh_m", "h_m", "v_m") + (("vh_dp", "h_dp", "vh_mp", "h_mp") if ds else ()):
+            atol = 1e-5 + (1.6e-6 * float(np.abs(want[key]).max()) if key.startswith(("vh", "sw")) else 0.0)
+            np.testing.assert_allclose(got[key], np.ravel(want[key]), rtol=RTOL, atol=atol, err_msg=key)
+
+
 def test_models_beyond_the_lds_train_on_the_generic_kernels(capsys):
     """Round 3 refused these (tables of both strands plus one chain exceed the LDS; 16 column roles of the statistics
     block): now fit() runs them -- against the oracle in test_edge_shapes, here through the reference's entry point."""
