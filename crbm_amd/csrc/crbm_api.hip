@@ -236,6 +236,7 @@ struct crbm_handle {
   crbm_handle* slab = nullptr;
   float* d_slab_tables = nullptr;
   int slab_n = 0;
+  bool slab_hgv = false;               // the chain's h|v takes the slabs too (slab a multiple of ten motifs, or one slab: sampler groups)
   uint64_t slab_tables_version = 0;
   std::string slab_note;               // why the slabs are off, if they are (crbm_launch_info prints nothing of it; a debugging aid)
   std::string err;
@@ -304,9 +305,18 @@ BigModel big_model(const crbm_handle* h) {
   return m;
 }
 
+constexpr int SLAB_FALLBACK = -1000;     // slab_launch_stats / slab_launch_hgv: nothing launched, take the generic kernel
+int slab_launch_hgv(crbm_handle* h, const uint32_t* d_letters, int n, int L, int mode, unsigned long long* ones, uint32_t* masks,
+                    uint32_t kind, uint32_t step, uint32_t seq_offset, hipStream_t st);
+int slab_launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool data_half, hipStream_t st, ReduceArgs* reduce);
+
 // h | v on packed rows: dense outputs (API), a count of sampled ones (evaluateData) or the masks of one strand (chain)
 int big_launch_hgv(crbm_handle* h, const uint32_t* d_letters, int n, int L, int mode, float* act, float* prob, float* sample,
                    unsigned long long* ones, uint32_t* masks, uint32_t kind, uint32_t step, uint32_t seq_offset, hipStream_t st) {
+  if (h->slab && h->slab_hgv && masks && !act && !prob && !sample) {      // the chain's h|v: the specialised kernel, slab by slab
+    const int rc = slab_launch_hgv(h, d_letters, n, L, mode, ones, masks, kind, step, seq_offset, st);
+    if (rc != SLAB_FALLBACK) return rc;
+  }
   BigHgvArgs a;
   a.m = big_model(h);
   a.letters = d_letters;
@@ -363,9 +373,6 @@ int big_launch_gibbs(crbm_handle* h, int steps, hipStream_t st) {
   h->launches_since_read += 1;
   return CRBM_OK;
 }
-
-constexpr int SLAB_FALLBACK = -1000;     // slab_launch_stats: nothing launched, take the generic kernel
-int slab_launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool data_half, hipStream_t st, ReduceArgs* reduce);
 
 // raw statistic sums of (letters, n, L) into partial rows; the column reduction is handed back like launch_stats does
 // (reduce->row == 0: nothing left to reduce -- the slabbed form below has written the sums itself)
@@ -811,23 +818,76 @@ int prepare_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool 
 // the model's (K,4,M) and (K) arrays -- and slab_reduce_kernel adds the slab's partial rows into its columns of d_sums.
 // The last slab of a model whose K is not a multiple of the slab is moved back to end at K: the motifs it shares with its
 // neighbour get the same sums twice (an accumulator's value does not depend on the column it sits in).
+// first motif of slab i: slabs of Ks motifs side by side; the last one of a model whose K is no multiple of Ks starts on the
+// first multiple of ten at or behind K - Ks (sampler groups are ten units wide: every unit keeps its group and field), so it
+// overlaps its neighbour and may reach up to nine motifs past K -- into the zero padding of W and b (crbm_create)
+int slab_origin(const crbm_handle* h, int i) {
+  const int Ks = h->slab->K;
+  if ((i + 1) * Ks <= h->K) return i * Ks;
+  return h->slab_hgv ? ((h->K - Ks + 9) / 10) * 10 : h->K - Ks;
+}
+
+int slab_ensure_tables(crbm_handle* h, hipStream_t st) {
+  crbm_handle* s = h->slab;
+  if (h->slab_tables_version == h->params_version) return CRBM_OK;
+  for (int i = 0; i < h->slab_n; ++i) {
+    const int k0 = slab_origin(h, i);
+    TablesArgs t;
+    t.W = h->dW + (size_t)k0 * 4 * h->M; t.b = h->db + k0; t.c = h->dc;
+    t.out = h->d_slab_tables + (size_t)i * s->ms.TABLES_ALL;
+    const unsigned grid = (unsigned)std::max(1, std::min((s->ms.TABLES_ALL + 255) / 256, h->num_cu * 4));
+    HIPCHK(jit_launch(s->jk.build_tables, t, grid, 1, 256, 0, st));
+  }
+  h->slab_tables_version = h->params_version;
+  return CRBM_OK;
+}
+
+// h | v of a chain of a generic DNA model: the specialised h|v kernel of the slab model (hgv_body: gather table in LDS, all
+// of the slab's units of a position in one lane, sign-word sampling), once per slab; every unit draws from the counter it has
+// in the whole model (HgvMasksArgs::group0) and lands in its bit of the model's mask rows (HgvMasksArgs::masks).
+int slab_launch_hgv(crbm_handle* h, const uint32_t* d_letters, int n, int L, int mode, unsigned long long* ones, uint32_t* masks,
+                    uint32_t kind, uint32_t step, uint32_t seq_offset, hipStream_t st) {
+  crbm_handle* s = h->slab;
+  const int Ks = s->K, Lh = L - h->M + 1;
+  if (tab_bytes(s) > 160 * 1024) return SLAB_FALLBACK;
+  int rc = slab_ensure_tables(h, st);
+  if (rc) return rc;
+  HIPCHK(hipMemsetAsync(masks, 0, (size_t)n * Lh * h->NW * sizeof(uint32_t), st));
+  int covered = 0;                      // motifs [0, covered) have been sampled by the slabs so far
+  for (int i = 0; i < h->slab_n; ++i) {
+    const int k0 = slab_origin(h, i);
+    HgvMasksArgs ma;
+    HgvArgs& a = ma.g;
+    a.tables = h->d_slab_tables + (size_t)i * s->ms.TABLES_ALL;
+    a.letters = d_letters;
+    a.n = n; a.L = L; a.Lh = Lh; a.LW = lw(h, L);
+    // rows per tile: ~4096 positions, fewer for small batches (enough tiles to cover the chip a few times over)
+    a.TS = std::max(1, std::min(tile_seqs(a.Lh, 4096), (n + 4 * h->num_cu - 1) / (4 * h->num_cu)));
+    a.divLh = make_fastdiv((uint32_t)a.Lh);
+    a.mode = mode;
+    a.act = nullptr; a.prob = nullptr; a.sample = nullptr; a.ones = ones;
+    a.rng = rng_view(h, step, seq_offset);
+    a.kind = kind;
+    ma.masks = masks; ma.NWfull = h->NW; ma.k0 = k0; ma.Kfull = h->K; ma.kskip = std::max(0, covered - k0);
+    ma.group0 = (uint32_t)(k0 / 10);
+    const int ntiles = (n + a.TS - 1) / a.TS;
+    const unsigned gx = (unsigned)std::max(1, std::min(ntiles, h->num_cu * 8));
+    HIPCHK(jit_launch(s->jk.hgv_masks, ma, gx, 1, 256, (unsigned)tab_bytes(s), st));
+    covered = k0 + Ks;
+  }
+  return CRBM_OK;
+}
+
 int slab_launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool data_half, hipStream_t st, ReduceArgs* reduce) {
   crbm_handle* s = h->slab;
   const int Ks = s->K, M = h->M;
   s->err.clear();
-  if (h->slab_tables_version != h->params_version) {
-    for (int i = 0; i < h->slab_n; ++i) {
-      const int k0 = std::min(i * Ks, h->K - Ks);
-      TablesArgs t;
-      t.W = h->dW + (size_t)k0 * 4 * M; t.b = h->db + k0; t.c = h->dc;
-      t.out = h->d_slab_tables + (size_t)i * s->ms.TABLES_ALL;
-      const unsigned grid = (unsigned)std::max(1, std::min((s->ms.TABLES_ALL + 255) / 256, h->num_cu * 4));
-      HIPCHK(jit_launch(s->jk.build_tables, t, grid, 1, 256, 0, st));
-    }
-    h->slab_tables_version = h->params_version;
+  {
+    const int trc = slab_ensure_tables(h, st);
+    if (trc) return trc;
   }
   for (int i = 0; i < h->slab_n; ++i) {
-    const int k0 = std::min(i * Ks, h->K - Ks);
+    const int k0 = slab_origin(h, i);
     s->d_tables = h->d_slab_tables + (size_t)i * s->ms.TABLES_ALL;
     StatsMfmaArgs a;
     ReduceArgs r;
@@ -863,12 +923,22 @@ int slab_setup(crbm_handle* h) {
   if (!h->big) return CRBM_OK;
   if (env_int("CRBM_SLAB_STATS", 1) == 0) { h->slab_note = "CRBM_SLAB_STATS=0"; return CRBM_OK; }
   if (h->A != 4 || h->M > MAX_MOTIF_LENGTH) { h->slab_note = "other alphabet, or motifs beyond 64 letters"; return CRBM_OK; }
-  const int want = env_int("CRBM_SLAB_MOTIFS", 64);
+  // a model of up to `want` motifs is one slab; a larger one takes slabs of a multiple of ten motifs (the sampler's groups)
+  const int want = std::max(10, std::min(env_int("CRBM_SLAB_MOTIFS", 60), MAX_MOTIFS));
   int Ks = 0, G = 0;
   ModelShape ms;
-  for (int cand : {std::min(h->K, std::max(1, std::min(want, MAX_MOTIFS))), 48, 32, 16}) {
-    if (cand > h->K) continue;
-    G = choose_group(cand, h->M, h->ds, env_int("CRBM_TABLE_BUDGET", 26 * 1024));
+  const int first = h->K <= want ? h->K : want / 10 * 10;
+  for (int cand : {first, 40, 30, 20, 10}) {
+    if (cand > h->K || (cand != first && cand >= first)) continue;
+    G = env_int("CRBM_SLAB_GROUP", 0);
+    if (G < 1 || G > 4) {
+      // the table budget of the specialised kernels; long motifs that it leaves with single letters take pairs where those fit
+      // twice 48 KB (60 x 40 double-stranded: 77 KB, training step 1.55 -> 1.19 ms at 2048 chains; a larger budget for ALL slabs
+      // costs the statistics kernel waves: 256 x 4 double-stranded 1.72 -> 1.99 ms)
+      const int budget = env_int("CRBM_SLAB_TABLE_BUDGET", 26 * 1024);
+      G = choose_group(cand, h->M, h->ds, budget);
+      if (G == 1) G = choose_group(cand, h->M, h->ds, std::max(budget, 48 * 1024));
+    }
     ms = model_shape(cand, h->M, h->ds, G, h->ms.POOL);
     bool fit = true;
     for (int want_sp = 0; want_sp <= 1 && fit; ++want_sp) {
@@ -897,6 +967,7 @@ int slab_setup(crbm_handle* h) {
   s->sl = sums_layout(Ks, h->M);
   s->stats_rows = h->stats_rows;
   h->slab_n = (h->K + Ks - 1) / Ks;
+  h->slab_hgv = (h->slab_n == 1 || Ks % 10 == 0) && Ks <= 64 && env_int("CRBM_SLAB_HGV", 1) != 0;   // (crbm_hgv_masks: compiled up to 64 motifs)
   if (hipMalloc((void**)&s->d_sums, (size_t)s->sl.count * 4) != hipSuccess ||
       hipMalloc((void**)&h->d_slab_tables, (size_t)h->slab_n * ms.TABLES_ALL * 4) != hipSuccess) {
     (void)hipGetLastError();
@@ -1533,7 +1604,10 @@ int crbm_create(const crbm_config* cfg, crbm_handle** out) {
     }
   }
   hh->overlap = env_int("CRBM_OVERLAP", 0) != 0;   // measured: no gain once the statistics kernel fills the chip
-  const size_t kam = (size_t)hh->KAM, k = (size_t)hh->K;
+  // (generic handles: W and b carry ten motifs of zero padding behind motif K -- the last slab of the slabbed kernels
+  //  starts on a multiple of ten and may reach past the model's end, slab_origin)
+  const size_t pad_k = hh->big ? 10 : 0;
+  const size_t kam = (size_t)hh->KAM + pad_k * hh->A * hh->M, k = (size_t)hh->K + pad_k;
   TRY(hipMalloc((void**)&hh->dW, kam * 4)); TRY(hipMalloc((void**)&hh->dvW, kam * 4));
   TRY(hipMalloc((void**)&hh->db, k * 4));   TRY(hipMalloc((void**)&hh->dvb, k * 4));
   const size_t cb = (size_t)std::max(4, hh->A) * 4;

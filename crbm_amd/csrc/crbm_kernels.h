@@ -290,12 +290,12 @@ template <class C, int WANT_P, bool DEFER = false>
 __device__ __forceinline__ void sample_hidden(const float (&z)[C::KP], uint32_t n, uint32_t s, uint32_t kind,
                                               uint32_t strand, const RngView& rng, uint32_t step,
                                               uint32_t (&mask)[C::NW], float (&p)[C::KP],
-                                              uint32_t* pending = nullptr) {
+                                              uint32_t* pending = nullptr, uint32_t group0 = 0) {   // group0: sampler group of unit 0 (a slab of a larger model: hgv_masks_body)
 #pragma unroll
   for (int w = 0; w < C::NW; ++w) mask[w] = 0u;
 #pragma unroll
   for (int g = 0; g < C::NGRP; ++g) {
-    const Philox4 rc = philox4x32(n, s, rng_word2(kind, strand, 0, (uint32_t)g), step, rng.seed_lo, rng.seed_hi);
+    const Philox4 rc = philox4x32(n, s, rng_word2(kind, strand, 0, group0 + (uint32_t)g), step, rng.seed_lo, rng.seed_hi);
     constexpr int kFull = 10;
     const int cnt = C::K - 10 * g < kFull ? C::K - 10 * g : kFull;   // units of this group
     uint32_t not_one = 0u, zero = 0u;     // bit i: unit 10g+i is not certainly 1 / is certainly 0
@@ -329,7 +329,7 @@ __device__ __forceinline__ void sample_hidden(const float (&z)[C::KP], uint32_t 
     const uint32_t amb = not_one & ~zero;   // units of this group that need the fine field
     if constexpr (DEFER) pending[g] = amb;
     if (!DEFER && __any(amb != 0u)) {
-      const Philox4 rf = philox4x32(n, s, rng_word2(kind, strand, 1, (uint32_t)g), step, rng.seed_lo, rng.seed_hi);
+      const Philox4 rf = philox4x32(n, s, rng_word2(kind, strand, 1, group0 + (uint32_t)g), step, rng.seed_lo, rng.seed_hi);
       auto fix = [&](auto I) {
         constexpr int i = decltype(I)::value;
         const int k = 10 * g + i;
@@ -511,11 +511,11 @@ __device__ __forceinline__ void pooled_probs(ZFun zfun, int s, float (&p)[KP], f
 // sample_hidden does not apply)
 template <class C>
 __device__ __forceinline__ void hidden_uniforms24(uint32_t n, uint32_t s, uint32_t kind, uint32_t strand, const RngView& rng,
-                                                  uint32_t step, float (&u)[C::KP]) {
+                                                  uint32_t step, float (&u)[C::KP], uint32_t group0 = 0) {
 #pragma unroll
   for (int g = 0; g < C::NGRP; ++g) {
-    const Philox4 rc = philox4x32(n, s, rng_word2(kind, strand, 0, (uint32_t)g), step, rng.seed_lo, rng.seed_hi);
-    const Philox4 rf = philox4x32(n, s, rng_word2(kind, strand, 1, (uint32_t)g), step, rng.seed_lo, rng.seed_hi);
+    const Philox4 rc = philox4x32(n, s, rng_word2(kind, strand, 0, group0 + (uint32_t)g), step, rng.seed_lo, rng.seed_hi);
+    const Philox4 rf = philox4x32(n, s, rng_word2(kind, strand, 1, group0 + (uint32_t)g), step, rng.seed_lo, rng.seed_hi);
     auto unit = [&](auto I) {
       constexpr int i = decltype(I)::value;
       const int k = 10 * g + i;
@@ -677,6 +677,17 @@ struct HgvArgs {
   uint32_t kind;
 };
 
+// The kernel's model as a SLAB of a larger one (crbm_api.hip, slab_launch_hgv: h|v of a chain on the generic path): the
+// sampled units go, as bits [k0, k0 + K) and below Kfull, into the larger model's mask rows (OR: the rows start at zero and
+// slabs may overlap); group0 = k0 / 10 keeps every unit on its own counter (units draw in groups of ten).  Units below
+// kskip are not counted in `ones`.  (A struct of its own: HgvArgs, and with it crbm_hgv, stay what they were.)
+struct HgvMasksArgs {
+  HgvArgs g;                  // act, prob, sample unused
+  uint32_t* masks;            // [n][Lh][NWfull]
+  int32_t NWfull, k0, Kfull, kskip;
+  uint32_t group0;
+};
+
 template <class C>
 __device__ void hgv_body(const HgvArgs& a) {
   constexpr int KP = C::KP, K = C::K, M = C::M;
@@ -731,6 +742,69 @@ __device__ void hgv_body(const HgvArgs& a) {
           if (a.sample) a.sample[idx] = (float)hb;
           cnt += hb;
         }
+      }
+    }
+  }
+  if (a.ones && cnt) atomicAdd(a.ones, cnt);
+}
+
+// The same pass for a SLAB of a larger model's chain (HgvArgs::masks; crbm_api.hip, slab_launch_hgv): the sample only, as bits
+// of the larger model's mask rows.  A kernel of its own so that crbm_hgv stays the code it was (its register and scratch
+// budget at 256 motifs is tight); compiled for models of up to 64 motifs only (crbm_jit.h).
+template <class C>
+__device__ void hgv_masks_body(const HgvMasksArgs& ma) {
+  const HgvArgs& a = ma.g;
+  constexpr int KP = C::KP, K = C::K, M = C::M;
+  HIP_DYNAMIC_SHARED(float, smem);
+  float* T0 = smem;
+  copy_tables<C::TAB>(T0, a.tables + C::OFF_TF);
+  __syncthreads();
+  const uint32_t strand = a.mode == 1 ? 1u : 0u;
+  unsigned long long cnt = 0;
+  const int ntiles = (a.n + a.TS - 1) / a.TS;
+  const int w0 = ma.k0 >> 5, sh = ma.k0 & 31;
+  const int kend = min(K, ma.Kfull - ma.k0);          // local units that exist in the larger model
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int n0 = tile * a.TS;
+    const int ns = min(a.TS, a.n - n0);
+    const uint32_t items = (uint32_t)ns * (uint32_t)a.Lh;
+    for (uint32_t i = threadIdx.x; i < items; i += blockDim.x) {
+      const uint32_t nl = fastdiv(i, a.divLh);
+      const int s = (int)(i - nl * (uint32_t)a.Lh);
+      const int nn = n0 + (int)nl;
+      const uint32_t* lrow = a.letters + (size_t)nn * a.LW;
+      auto zfun = [&](int pos, float (&z)[KP]) {
+        const LetterWin<M> w = letter_window<M>(lrow, pos);
+        conv_gather<C>(T0, a.mode == 1 ? revcomp_window<M>(w) : w, z);
+      };
+      float x[KP];
+      zfun(s, x);
+      uint32_t mask[C::NW];
+      float p[KP];
+      if constexpr (C::POOL > 1) {
+        float cb[KP], S[KP], u[KP];
+        pooled_probs<C::POOL, KP>(zfun, s, p, cb, S);
+        hidden_uniforms24<C>(a.rng.seq_offset + (uint32_t)nn, (uint32_t)(s - s % C::POOL), a.kind, strand, a.rng, a.rng.step, u, ma.group0);
+        pooled_sample<C>(p, cb, u, mask);
+      } else {
+        sample_hidden<C, 0>(x, a.rng.seq_offset + (uint32_t)nn, (uint32_t)s, a.kind, strand, a.rng, a.rng.step, mask, p, nullptr, ma.group0);
+      }
+      // bits [k0, k0 + K) of the row's NWfull words, cut at Kfull (the last slab of a model may reach past its end);
+      // units below kskip belong to the neighbouring slab as well and are counted there
+      uint32_t* wp = ma.masks + ((size_t)nn * a.Lh + s) * ma.NWfull;
+#pragma unroll
+      for (int w = 0; w < C::NW; ++w) {
+        const int lo = min(32, max(0, ma.kskip - 32 * w)), hi = min(32, max(0, kend - 32 * w));
+        const uint32_t keep = hi >= 32 ? 0xFFFFFFFFu : (1u << hi) - 1u;
+        const uint32_t counted = keep & (lo >= 32 ? 0u : ~((1u << lo) - 1u));
+        mask[w] &= keep;
+        cnt += (unsigned)__popc(mask[w] & counted);
+      }
+#pragma unroll
+      for (int w = 0; w <= C::NW; ++w) {
+        const uint32_t cur = w < C::NW ? mask[w < C::NW ? w : 0] : 0u, prev = w > 0 ? mask[w - 1] : 0u;
+        const uint32_t bits = sh ? (cur << sh) | (prev >> (32 - sh)) : cur;
+        if (bits && w0 + w < ma.NWfull) wp[w0 + w] |= bits;
       }
     }
   }

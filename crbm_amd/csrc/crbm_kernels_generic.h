@@ -740,7 +740,8 @@ __global__ void __launch_bounds__(256) big_eval_kernel(BigEvalArgs a) {
 // statistics kernel (stats_mfma_body, compiled for a slab of <= 64 motifs) once per slab on the slab's own gather table,
 // and this kernel reduces the slab's partial rows column by column -- like reduce_partials_body -- straight into the
 // slab's columns of the full model's sums ([vh K*4*M][vh' K*4*M][h K][h' K][sw K*4*M][sb K][v 4] n, the model half
-// without sw, sb).  The letter counts and n do not depend on the motifs: every slab writes the same values.
+// without sw, sb).  The letter counts and n do not depend on the motifs: every slab writes the same values.  Slabs may
+// overlap (the same sums twice) and the last one may reach past motif K (zero padding of W and b: those columns are dropped).
 struct SlabReduceArgs {
   const float* partials;   // [nrows][row] partial rows of the slab model
   float* sums;             // the full model's sums of this half (d_sums + data_off or model_off)
@@ -760,13 +761,15 @@ __global__ void __launch_bounds__(1024) slab_reduce_kernel(SlabReduceArgs a) {
   int dst = -1;          // column of the full row
   bool valid = false;
   if (r < a.row) {
-    if (r < KAMs) { dst = a.k0 * a.M4 + r; valid = true; }
-    else if (r < 2 * KAMs) { dst = KAM + a.k0 * a.M4 + (r - KAMs); valid = a.ds != 0; }
-    else if (r < 2 * KAMs + Ks) { dst = 2 * KAM + a.k0 + (r - 2 * KAMs); valid = true; }
-    else if (r < 2 * KAMs + 2 * Ks) { dst = 2 * KAM + K + a.k0 + (r - 2 * KAMs - Ks); valid = a.ds != 0; }
-    else if (r < 3 * KAMs + 2 * Ks) { dst = 2 * KAM + 2 * K + a.k0 * a.M4 + (r - 2 * KAMs - 2 * Ks); valid = a.want_sparsity != 0; }
-    else if (r < 3 * KAMs + 3 * Ks) { dst = 3 * KAM + 2 * K + a.k0 + (r - 3 * KAMs - 2 * Ks); valid = a.want_sparsity != 0; }
-    else { dst = 3 * KAM + 3 * K + (r - 3 * KAMs - 3 * Ks); valid = true; }
+    int kk;              // motif of the slab this column belongs to (-1: none)
+    if (r < KAMs) { kk = r / a.M4; dst = a.k0 * a.M4 + r; valid = true; }
+    else if (r < 2 * KAMs) { kk = (r - KAMs) / a.M4; dst = KAM + a.k0 * a.M4 + (r - KAMs); valid = a.ds != 0; }
+    else if (r < 2 * KAMs + Ks) { kk = r - 2 * KAMs; dst = 2 * KAM + a.k0 + kk; valid = true; }
+    else if (r < 2 * KAMs + 2 * Ks) { kk = r - 2 * KAMs - Ks; dst = 2 * KAM + K + a.k0 + kk; valid = a.ds != 0; }
+    else if (r < 3 * KAMs + 2 * Ks) { kk = (r - 2 * KAMs - 2 * Ks) / a.M4; dst = 2 * KAM + 2 * K + a.k0 * a.M4 + (r - 2 * KAMs - 2 * Ks); valid = a.want_sparsity != 0; }
+    else if (r < 3 * KAMs + 3 * Ks) { kk = r - 3 * KAMs - 2 * Ks; dst = 3 * KAM + 2 * K + a.k0 + kk; valid = a.want_sparsity != 0; }
+    else { kk = -1; dst = 3 * KAM + 3 * K + (r - 3 * KAMs - 3 * Ks); valid = true; }
+    if (kk >= 0 && a.k0 + kk >= K) { dst = -1; valid = false; }      // the last slab may reach past the model's end (its padding)
   }
   float tsum = 0.f;
   if (valid) {      // eight rows in flight per thread, fixed order (reduce_partials_body)
