@@ -364,6 +364,37 @@ def cfg1_fit_gpu():
     return out
 
 
+def generic_model_timing(K=300, M=10, ds=False, chains=4096, L=200, steps=20, warmup=5):
+    """A model beyond the LDS-resident kernels (not a BASELINE configuration: reported beside them because the reference takes
+    any model size, convRBM.py:72-108): Gibbs steps and PCD-1 training steps of a DNA model whose statistics and h|v run on
+    the specialised kernels a slab of motifs at a time, v|h on the generic kernel (DESIGN.md section 5 "Slabs")."""
+    from crbm_amd._lib import fptr
+    cfg = dict(K=K, M=M, L=L, ds=ds, chains=chains, k=1)
+    model = build_model(cfg, 1, 0, 0)
+    model._h()
+    D = synthetic_onehot(chains, L, seed=1234)
+    model._call("crbm_dataset_upload", fptr(D), chains, L)
+    model._call("crbm_train_step_resident", 0, chains)
+    model.gibbsSteps(warmup)
+    model._call("crbm_sync")
+    t0 = time.perf_counter()
+    model.gibbsSteps(steps)
+    model._call("crbm_sync")
+    gibbs_ms = 1e3 * (time.perf_counter() - t0) / steps
+    for _ in range(warmup):
+        model._call("crbm_train_step_resident", 0, chains)
+    model._call("crbm_sync")
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        model._call("crbm_train_step_resident", 0, chains)
+    model._call("crbm_sync")
+    train_ms = 1e3 * (time.perf_counter() - t0) / steps
+    del model
+    return {"workload": "%d motifs len %d%s, %d chains x 4x%d, PCD-1 (beyond the LDS-resident kernels)" % (K, M, ", doublestranded" if ds else "", chains, L),
+            "ms_per_gibbs_step": gibbs_ms, "ms_per_train_step": train_ms, "steps": steps, "warmup_steps": warmup, "clock": "host",
+            "kernels": "statistics and h|v: the specialised kernels per slab of <= 60 motifs; v|h: generic kernel"}
+
+
 PMC_PASSES = (("valu", "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_TRANS_F32 SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT"),
               ("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE"))
 N_SIMD = 256 * 4          # MI355X: 256 CUs x 4 SIMDs
@@ -660,6 +691,10 @@ def main():
                     out["other_configs"]["cfg1"] = cfg1_fit_gpu()
                 except Exception as e:
                     out["other_configs"]["cfg1"] = {"error": str(e)[:300]}
+                try:
+                    out["other_configs"]["generic_300x10"] = generic_model_timing()
+                except Exception as e:
+                    out["other_configs"]["generic_300x10"] = {"error": str(e)[:300]}
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(cfg)
             print(json.dumps(out), flush=True)

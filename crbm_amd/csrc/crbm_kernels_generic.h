@@ -239,16 +239,26 @@ __global__ void __launch_bounds__(256) big_vgh_kernel(BigVghArgs a) {
   float4* Wt = reinterpret_cast<float4*>(smem);                       // [JS][32]: W[k, 0..3, j] of the slab
   unsigned char* lb = reinterpret_cast<unsigned char*>(Wt + (size_t)JS * 32);   // [BIG_VR * blockDim] letters of a chunk
   const int CH = BIG_VR * (int)blockDim.x;
+  // mask word w of the hidden positions a chunk's visible positions meet (s = p - j: CH + M - 1 of them), both strands: read
+  // from global memory once per (chunk, word) instead of once per (position, filter column, word)
+  const int HSW = CH + M - 1;
+  uint32_t* hs = reinterpret_cast<uint32_t*>(lb + (size_t)CH);         // [2][HSW]
   for (int chain = blockIdx.x; chain < a.nchains; chain += gridDim.x) {
     const uint32_t gn = a.rng.seq_offset + (uint32_t)chain;
     for (int c0 = 0; c0 < a.Lv; c0 += CH) {
       float y[BIG_VR][4];
 #pragma unroll
       for (int r = 0; r < BIG_VR; ++r) { y[r][0] = a.m.c[0]; y[r][1] = a.m.c[1]; y[r][2] = a.m.c[2]; y[r][3] = a.m.c[3]; }
+      const int sbase = max(0, c0 - (M - 1)), send = min(a.Lf, c0 + CH);      // hidden positions [sbase, send) matter to this chunk
       for (int w = 0; w < NW; ++w)
         for (int j0 = 0; j0 < M; j0 += JS) {
           const int jc = min(JS, M - j0), kc = min(32, K - 32 * w);
           __syncthreads();
+          if (j0 == 0)
+            for (int i = threadIdx.x; i < send - sbase; i += blockDim.x) {
+              hs[i] = a.hm[((size_t)chain * a.Lf + sbase + i) * NW + w];
+              if (a.hmp) hs[HSW + i] = a.hmp[((size_t)chain * a.Lf + sbase + i) * NW + w];
+            }
           for (int i = threadIdx.x; i < jc * 32; i += blockDim.x) {
             const int j = i >> 5, k = i & 31;
             float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -264,13 +274,13 @@ __global__ void __launch_bounds__(256) big_vgh_kernel(BigVghArgs a) {
             const int p = c0 + (int)threadIdx.x + r * (int)blockDim.x;
             if (p < a.Lv)
               for (int strand = 0; strand <= (a.hmp ? 1 : 0); ++strand) {
-                const uint32_t* hrow = (strand ? a.hmp : a.hm) + (size_t)chain * a.Lf * NW + w;
+                const uint32_t* hrow = hs + (strand ? HSW : 0) - sbase;
                 // forward strand: column j of the filter meets hidden position p - j; rc strand: rc(W)[k,a,j] = W[k,3-a,M-1-j]
                 for (int j = 0; j < jc; ++j) {
                   const int jj = j0 + j;                       // column of W that is staged at row j
                   const int s = strand ? p - (M - 1 - jj) : p - jj;
                   if (s < 0 || s >= a.Lf) continue;
-                  uint32_t bits = hrow[(size_t)s * NW];
+                  uint32_t bits = hrow[s];
                   while (bits) {
                     const int k = __ffs(bits) - 1;
                     bits &= bits - 1u;
