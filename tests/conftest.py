@@ -20,6 +20,12 @@ def pytest_collection_modifyitems(config, items):
     """GPU tests are selected with ``-m gpu``; when no GPU device node exists
     they are skipped rather than failed (the CPU container has no /dev/kfd)."""
     if _gpu_present():
+        # a launch that never comes back fails its test with a stack dump (pytest-timeout, thread method: the main thread
+        # sits in a ctypes call) instead of stalling the whole run until the box gives up on it
+        if config.pluginmanager.hasplugin("timeout"):
+            for item in items:
+                if "gpu" in item.keywords and item.get_closest_marker("timeout") is None:
+                    item.add_marker(pytest.mark.timeout(300, method="thread"))
         return
     skip = pytest.mark.skip(reason="no GPU (/dev/kfd absent)")
     for item in items:

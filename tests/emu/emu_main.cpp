@@ -163,6 +163,33 @@ int emu_hgv(int id, const float* tables, const uint32_t* letters, int n, int L, 
   return 0;
 }
 
+// h | v of a SLAB of a larger model's chain (crbm_api.hip, slab_launch_hgv): the sample as bits of the larger model's mask rows
+int emu_hgv_masks(int id, const float* tables, const uint32_t* letters, int n, int L, int mode, uint32_t* masks, int NWfull,
+                  int k0, int Kfull, int kskip, unsigned long long* ones, uint64_t seed, uint32_t step, uint32_t off,
+                  uint32_t kind, int TS, int grid, int threads) {
+  HgvMasksArgs ma;
+  HgvArgs& a = ma.g;
+  a.tables = tables; a.letters = letters; a.n = n; a.L = L; a.LW = letter_words(L);
+  a.TS = TS; a.mode = mode;
+  a.act = nullptr; a.prob = nullptr; a.sample = nullptr; a.ones = ones;
+  a.rng = make_rng(seed, step, off); a.kind = kind;
+  ma.masks = masks; ma.NWfull = NWfull; ma.k0 = k0; ma.Kfull = Kfull; ma.kskip = kskip; ma.group0 = (uint32_t)(k0 / 10);
+  CFG_DISPATCH(id, (a.Lh = L - C::M + 1, a.divLh = make_fastdiv((uint32_t)a.Lh),
+                    emu::launch([&] { hgv_masks_body<C>(ma); }, dim3(grid), dim3(threads), (size_t)C::TAB * 4)));
+  return 0;
+}
+
+// column reduction of a slab's partial rows into its columns of the larger model's sums (slab_reduce_kernel)
+int emu_slab_reduce(const float* partials, float* sums, int nrows, int row, int Ks, int k0, int K, int M4, int ds,
+                    int want_sparsity, int skip_begin, int skip_len, float n_value, int threads) {
+  SlabReduceArgs a;
+  a.partials = partials; a.sums = sums; a.nrows = nrows; a.row = row;
+  a.Ks = Ks; a.k0 = k0; a.K = K; a.M4 = M4; a.ds = ds; a.want_sparsity = want_sparsity;
+  a.skip_begin = skip_begin; a.skip_len = skip_len; a.n_value = n_value;
+  emu::launch([&] { slab_reduce_kernel(a); }, dim3((row + 31) / 32), dim3(threads), 0);
+  return 0;
+}
+
 int emu_vgh(const float* W, const float* c, int K, int M, const float* hid, const float* hidp,
             int n, int Lh, float* act, float* prob, float* sample, uint64_t seed, uint32_t step, uint32_t off,
             int TS, int grid, int threads) {

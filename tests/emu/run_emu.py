@@ -928,6 +928,71 @@ def test_big():
         print("big kernels ok", (K, M, ds, pool, A))
 
 
+def test_slabs():
+    """A model larger than a compiled case as a row of slabs of that case (crbm_api.hip, slab_launch_hgv / slab_launch_stats):
+    h|v of every slab into the model's mask rows -- units on the counters they have in the whole model, the last slab moved
+    to a multiple of ten (it overlaps its neighbour and reaches past motif K into zero padding) -- against the oracle of the
+    WHOLE model, sample for sample; and the column reduction of a slab's partial rows into the model's sums."""
+    for cid, K, pool in ((4, 47, 1), (0, 25, 1), (10, 20, 3)):
+        info = case_info(cid)
+        Ks, M, ds = info["K"], info["M"], info["ds"]
+        Lf = 12 * pool
+        o = make_oracle(K, M, ds, seed=K, Lf=Lf, pooling=pool) if pool > 1 else make_oracle(K, M, ds, seed=K, Lf=Lf)
+        W, b, c = model_arrays(o)
+        Wp = np.concatenate([W, np.zeros((10, 4, M), np.float32)])
+        bp = np.concatenate([b, np.zeros(10, np.float32)])
+        n, L = 4, Lf + M - 1
+        d = synthetic_onehot(n, L, seed=K + 1)
+        letters, _ = encode(d)
+        Lh, NW = L - M + 1, (K + 31) // 32
+        nslab = (K + Ks - 1) // Ks
+        origins = [i * Ks if (i + 1) * Ks <= K else (K - Ks + 9) // 10 * 10 for i in range(nslab)]
+        for strand in range(2 if ds else 1):
+            masks = np.zeros((n, Lh, NW), dtype=np.uint32)
+            ones = ctypes.c_ulonglong(0)
+            covered = 0
+            for k0 in origins:
+                t = np.zeros(info["TABLES"], dtype=np.float32)
+                assert lib.emu_tables(cid, fp(np.ascontiguousarray(Wp[k0:k0 + Ks])), fp(np.ascontiguousarray(bp[k0:k0 + Ks])), fp(c), fp(t)) == 0
+                assert lib.emu_hgv_masks(cid, fp(t), up(letters), n, L, strand, up(masks), NW, k0, K, max(0, covered - k0),
+                                         ctypes.byref(ones), ctypes.c_uint64(91), 4, 2, KIND_CHAIN_H, 2, 2, 128) == 0
+                covered = k0 + Ks
+            smp = unpack_hidden(masks, K).astype(np.float32).reshape(n, K, 1, Lh)
+            assert ones.value == int(smp.sum()) and smp.sum() > 0
+            x = o._bottomUpActivity(d, strand == 1)
+            if pool > 1:
+                prob = o._bottomUpProbability(x)
+                u = hidden_uniforms(91, 4, np.arange(n) + 2, K, Lh, strand, KIND_CHAIN_H)
+                check_pooled_samples("slab hgv", smp, prob, u, pool)
+            else:
+                u = hidden_uniforms(91, 4, np.arange(n) + 2, K, Lh, strand, KIND_CHAIN_H)
+                check_samples("slab hgv", smp, 1 / (1 + np.exp(-x)), u)
+        print("slab hgv ok", cid, (K, Ks, M, ds, pool), origins)
+    # slab_reduce_kernel: data half (everything carried) and model half (sw, sb dropped), a slab that reaches past motif K
+    rng = np.random.default_rng(5)
+    K, Ks, M, k0 = 47, 20, 3, 30
+    M4, KAM, KAMs = 4 * M, K * 4 * M, Ks * 4 * M
+    row, full = 3 * KAMs + 3 * Ks + 4, 3 * KAM + 3 * K + 4
+    nrows = 11
+    part = rng.standard_normal((nrows, row)).astype(np.float32)
+    col = part.astype(np.float64).sum(axis=0)
+    for dsf, sp, skip_begin, skip_len in ((1, 1, full, 0), (0, 0, 2 * KAM + 2 * K, KAM + K), (1, 0, 2 * KAM + 2 * K, KAM + K)):
+        sums = np.full(full + 1 - skip_len, -7.0, dtype=np.float32)
+        assert lib.emu_slab_reduce(fp(part), fp(sums), nrows, row, Ks, k0, K, M4, dsf, sp, skip_begin, skip_len, ctypes.c_float(13.0), 64) == 0
+        want = np.full(full + 1, -7.0)
+        kk = K - k0                                     # motifs of the slab that exist
+        def put(dst, src, per, valid):
+            want[dst + k0 * per:dst + (k0 + kk) * per] = col[src:src + kk * per] if valid else 0.0
+        put(0, 0, M4, True); put(KAM, KAMs, M4, dsf)
+        put(2 * KAM, 2 * KAMs, 1, True); put(2 * KAM + K, 2 * KAMs + Ks, 1, dsf)
+        put(2 * KAM + 2 * K, 2 * KAMs + 2 * Ks, M4, sp); put(3 * KAM + 2 * K, 3 * KAMs + 2 * Ks, 1, sp)
+        want[3 * KAM + 3 * K:3 * KAM + 3 * K + 4] = col[3 * KAMs + 3 * Ks:]
+        want[full] = 13.0
+        want = np.delete(want, np.arange(skip_begin, skip_begin + skip_len)) if skip_len else want
+        np.testing.assert_allclose(sums, want, rtol=1e-5, atol=1e-5)
+    print("slab reduce ok")
+
+
 def test_large_models():
     """Models beyond 64 motifs (masks of more than two words) and beyond 32-letter motifs (two-word letter
     windows, 128-bit statistics windows): every kernel of a training step, the free energy and the chain."""
@@ -940,7 +1005,7 @@ def test_large_models():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["encode_pack", "hgv", "vgh", "gibbs", "stats_mfma", "train_step", "two_ranks", "pooling",
-                             "free_energy", "hit_summary", "big"]
+                             "free_energy", "hit_summary", "big", "slabs"]
     for w in which:
         globals()["test_" + w]()
     print("EMU ALL OK")

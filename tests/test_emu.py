@@ -34,7 +34,7 @@ def emu_env():
 
 
 CASES = ["encode_pack", "hgv", "vgh", "gibbs", "stats_mfma", "train_step", "two_ranks", "pooling",
-         "free_energy", "hit_summary", "large_models", "big"]
+         "free_energy", "hit_summary", "large_models", "big", "slabs"]
 
 
 @pytest.fixture(scope="module")
