@@ -1101,6 +1101,10 @@ int launch_reduce_pair(crbm_handle* h, ReducePair pair, bool publish) {
 int train_local_dev(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool publish = false) {
   int rc = ensure_tables(h);
   if (rc) return rc;
+  if (h->slab) {      // the slab tables too, on the main stream: both halves read them (CRBM_OVERLAP: from two streams)
+    rc = slab_ensure_tables(h, h->stream);
+    if (rc) return rc;
+  }
   hipStream_t sm = h->overlap ? h->stream2 : h->stream;
   if (h->overlap) {
     HIPCHK(hipEventRecord(h->ev_fork, h->stream));          // tables ready, earlier work on the chains done
