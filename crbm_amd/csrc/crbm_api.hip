@@ -313,9 +313,16 @@ int slab_launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, b
 // h | v on packed rows: dense outputs (API), a count of sampled ones (evaluateData) or the masks of one strand (chain)
 int big_launch_hgv(crbm_handle* h, const uint32_t* d_letters, int n, int L, int mode, float* act, float* prob, float* sample,
                    unsigned long long* ones, uint32_t* masks, uint32_t kind, uint32_t step, uint32_t seq_offset, hipStream_t st) {
-  if (h->slab && h->slab_hgv && masks && !act && !prob && !sample) {      // the chain's h|v: the specialised kernel, slab by slab
-    const int rc = slab_launch_hgv(h, d_letters, n, L, mode, ones, masks, kind, step, seq_offset, st);
-    if (rc != SLAB_FALLBACK) return rc;
+  if (h->slab && h->slab_hgv && (masks || ones) && !act && !prob && !sample) {
+    // the chain's h|v, or the count of a sample (evaluateData, the per-epoch evaluation: into scratch masks): the
+    // specialised kernel, slab by slab
+    uint32_t* out = masks;
+    if (!out) {
+      HIPCHK(h->masks_tmp.ensure((size_t)n * (L - h->M + 1) * h->NW));
+      out = h->masks_tmp.p;
+    }
+    const int rc = slab_launch_hgv(h, d_letters, n, L, mode, ones, out, kind, step, seq_offset, st);
+    if (rc != SLAB_FALLBACK) return rc;      // (a fallback comes before anything is launched)
   }
   BigHgvArgs a;
   a.m = big_model(h);

@@ -1082,6 +1082,9 @@ def test_slabbed_statistics_of_generic_models(K, M, ds, pool, monkeypatch):
     for a, b in zip(m1.get_fantasy(), m0.get_fantasy()):
         if a is not None:
             np.testing.assert_array_equal(a, b)                 # the chain does not depend on the statistics path
+    # evaluateData (convRBM.py:517-522): the sampled activity is counted by the slabbed h|v too
+    e1, e0 = m1._evaluateData(D), m0._evaluateData(D)
+    assert abs(e1[0] - e0[0]) <= 1e-5 * abs(e0[0]) and abs(e1[1] - e0[1]) <= 2.0 / (n * K * (L - M + 1)) and e1[1] > 0
     got, ref = _unpack_sums(with_slabs, K, M), _unpack_sums(plain, K, M)
     for key in ref:
         scale = float(np.abs(ref[key]).max()) if np.size(ref[key]) else 0.0
