@@ -834,57 +834,63 @@ int slab_origin(const crbm_handle* h, int i) {
   return h->slab_hgv ? ((h->K - Ks + 9) / 10) * 10 : h->K - Ks;
 }
 
+SlabPlan slab_plan(const crbm_handle* h) {
+  SlabPlan p;
+  p.Ks = h->slab->K; p.K = h->K; p.last_k0 = slab_origin(h, h->slab_n - 1);
+  return p;
+}
+
+// one launch builds the table images of all slabs (blockIdx.y = slab: slab_tables_body)
 int slab_ensure_tables(crbm_handle* h, hipStream_t st) {
   crbm_handle* s = h->slab;
   if (h->slab_tables_version == h->params_version) return CRBM_OK;
-  for (int i = 0; i < h->slab_n; ++i) {
-    const int k0 = slab_origin(h, i);
-    TablesArgs t;
-    t.W = h->dW + (size_t)k0 * 4 * h->M; t.b = h->db + k0; t.c = h->dc;
-    t.out = h->d_slab_tables + (size_t)i * s->ms.TABLES_ALL;
-    const unsigned grid = (unsigned)std::max(1, std::min((s->ms.TABLES_ALL + 255) / 256, h->num_cu * 4));
-    HIPCHK(jit_launch(s->jk.build_tables, t, grid, 1, 256, 0, st));
-  }
+  SlabTablesArgs a;
+  a.t.W = h->dW; a.t.b = h->db; a.t.c = h->dc; a.t.out = h->d_slab_tables;
+  a.plan = slab_plan(h);
+  a.stride = s->ms.TABLES_ALL;
+  const unsigned grid = (unsigned)std::max(1, std::min((s->ms.TABLES_ALL + 255) / 256, h->num_cu * 4));
+  HIPCHK(jit_launch(s->jk.slab_tables, a, grid, (unsigned)h->slab_n, 256, 0, st));
   h->slab_tables_version = h->params_version;
   return CRBM_OK;
 }
 
-// h | v of a chain of a generic DNA model: the specialised h|v kernel of the slab model (hgv_body: gather table in LDS, all
-// of the slab's units of a position in one lane, sign-word sampling), once per slab; every unit draws from the counter it has
-// in the whole model (HgvMasksArgs::group0) and lands in its bit of the model's mask rows (HgvMasksArgs::masks).
+// h | v of a chain of a generic DNA model: the specialised h|v pass of the slab model (hgv_masks_body: gather table in LDS,
+// all of the slab's units of a position in one lane, sign-word sampling), all slabs in one launch (blockIdx.y = slab); every
+// unit draws from the counter it has in the whole model (HgvMasksArgs::group0) and lands in its bit of the model's mask rows
+// (HgvMasksArgs::masks, atomicOr: neighbouring slabs share words).
 int slab_launch_hgv(crbm_handle* h, const uint32_t* d_letters, int n, int L, int mode, unsigned long long* ones, uint32_t* masks,
                     uint32_t kind, uint32_t step, uint32_t seq_offset, hipStream_t st) {
   crbm_handle* s = h->slab;
-  const int Ks = s->K, Lh = L - h->M + 1;
+  const int Lh = L - h->M + 1;
   if (tab_bytes(s) > 160 * 1024) return SLAB_FALLBACK;
   int rc = slab_ensure_tables(h, st);
   if (rc) return rc;
   HIPCHK(hipMemsetAsync(masks, 0, (size_t)n * Lh * h->NW * sizeof(uint32_t), st));
-  int covered = 0;                      // motifs [0, covered) have been sampled by the slabs so far
-  for (int i = 0; i < h->slab_n; ++i) {
-    const int k0 = slab_origin(h, i);
-    HgvMasksArgs ma;
-    HgvArgs& a = ma.g;
-    a.tables = h->d_slab_tables + (size_t)i * s->ms.TABLES_ALL;
-    a.letters = d_letters;
-    a.n = n; a.L = L; a.Lh = Lh; a.LW = lw(h, L);
-    // rows per tile: ~4096 positions, fewer for small batches (enough tiles to cover the chip a few times over)
-    a.TS = std::max(1, std::min(tile_seqs(a.Lh, 4096), (n + 4 * h->num_cu - 1) / (4 * h->num_cu)));
-    a.divLh = make_fastdiv((uint32_t)a.Lh);
-    a.mode = mode;
-    a.act = nullptr; a.prob = nullptr; a.sample = nullptr; a.ones = ones;
-    a.rng = rng_view(h, step, seq_offset);
-    a.kind = kind;
-    ma.masks = masks; ma.NWfull = h->NW; ma.k0 = k0; ma.Kfull = h->K; ma.kskip = std::max(0, covered - k0);
-    ma.group0 = (uint32_t)(k0 / 10);
-    const int ntiles = (n + a.TS - 1) / a.TS;
-    const unsigned gx = (unsigned)std::max(1, std::min(ntiles, h->num_cu * 8));
-    HIPCHK(jit_launch(s->jk.hgv_masks, ma, gx, 1, 256, (unsigned)tab_bytes(s), st));
-    covered = k0 + Ks;
-  }
+  SlabHgvArgs sa;
+  HgvArgs& a = sa.m.g;
+  a.tables = h->d_slab_tables;
+  a.letters = d_letters;
+  a.n = n; a.L = L; a.Lh = Lh; a.LW = lw(h, L);
+  // rows per tile: ~4096 positions, fewer for small batches (enough blocks, with the slabs, to cover the chip a few times over)
+  a.TS = std::max(1, std::min(tile_seqs(a.Lh, 4096), (n * h->slab_n + 4 * h->num_cu - 1) / (4 * h->num_cu)));
+  a.divLh = make_fastdiv((uint32_t)a.Lh);
+  a.mode = mode;
+  a.act = nullptr; a.prob = nullptr; a.sample = nullptr; a.ones = ones;
+  a.rng = rng_view(h, step, seq_offset);
+  a.kind = kind;
+  sa.m.masks = masks; sa.m.NWfull = h->NW; sa.m.Kfull = h->K;
+  sa.m.k0 = 0; sa.m.kskip = 0; sa.m.group0 = 0;          // per slab: slab_hgv_body
+  sa.plan = slab_plan(h);
+  sa.table_stride = s->ms.TABLES_ALL;
+  const int ntiles = (n + a.TS - 1) / a.TS;
+  const unsigned gx = (unsigned)std::max(1, std::min(ntiles, h->num_cu * 8));
+  HIPCHK(jit_launch(s->jk.slab_hgv, sa, gx, (unsigned)h->slab_n, 256, (unsigned)tab_bytes(s), st));
   return CRBM_OK;
 }
 
+// The statistics of a generic DNA model: the specialised statistics kernel of the slab model, all slabs in one launch
+// (blockIdx.y = slab: its table image, its partial rows), then slab_reduce_kernel -- one launch too -- reduces every slab's
+// partial rows into the slab's columns of the model's sums.
 int slab_launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool data_half, hipStream_t st, ReduceArgs* reduce) {
   crbm_handle* s = h->slab;
   const int Ks = s->K, M = h->M;
@@ -893,32 +899,34 @@ int slab_launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, b
     const int trc = slab_ensure_tables(h, st);
     if (trc) return trc;
   }
-  for (int i = 0; i < h->slab_n; ++i) {
-    const int k0 = slab_origin(h, i);
-    s->d_tables = h->d_slab_tables + (size_t)i * s->ms.TABLES_ALL;
-    StatsMfmaArgs a;
-    ReduceArgs r;
-    int lds = 0, gx = 0, block = 0;
-    const int rc = prepare_stats(s, d_letters, n, L, data_half, 0, &a, &lds, &gx, &block, &r);
-    if (rc) {
-      if (i == 0 && rc == CRBM_ERR_INVALID) return SLAB_FALLBACK;   // (a data set whose rows the slab kernel's LDS does not take)
-      return fail(h, rc, "slabbed statistics: " + s->err);
-    }
-    if (jit_launch(data_half ? s->jk.stats_mfma_data : s->jk.stats_mfma_model, a, (unsigned)gx, 1, (unsigned)block, (unsigned)lds, st) != hipSuccess)
-      return fail(h, CRBM_ERR_HIP, "launch of the slab statistics kernel failed");
-    SlabReduceArgs ra;
-    ra.partials = r.partials;
-    ra.sums = h->d_sums + (data_half ? h->sl.data_off : h->sl.model_off);
-    ra.nrows = r.nrows; ra.row = r.row;
-    ra.Ks = Ks; ra.k0 = k0; ra.K = h->K; ra.M4 = 4 * M;
-    ra.ds = h->ds; ra.want_sparsity = data_half ? 1 : 0;
-    const int full_row = 3 * h->KAM + 3 * h->K + 4;
-    ra.skip_begin = data_half ? full_row : h->sl.model_skip_begin;
-    ra.skip_len = data_half ? 0 : h->sl.model_skip_len;
-    ra.n_value = (float)n;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((ra.row + 31) / 32), dim3(1024), 0, st, ra);
-    HIPCHK(hipGetLastError());
-  }
+  s->d_tables = h->d_slab_tables;
+  SlabStatsArgs sa;
+  ReduceArgs r;
+  int lds = 0, gx = 0, block = 0;
+  const int rc = prepare_stats(s, d_letters, n, L, data_half, 0, &sa.a, &lds, &gx, &block, &r);
+  if (rc == CRBM_ERR_INVALID) return SLAB_FALLBACK;      // (a data set whose rows the slab kernel's LDS does not take)
+  if (rc) return fail(h, rc, "slabbed statistics: " + s->err);
+  DevBuf<float>& pbuf = data_half ? s->partials : s->partials2;
+  const size_t per_slab = (size_t)r.nrows * r.row;
+  HIPCHK(pbuf.ensure(per_slab * h->slab_n));
+  sa.a.sg.partials = pbuf.p;
+  sa.table_stride = s->ms.TABLES_ALL; sa.pad_ = 0;
+  sa.partial_stride = (long long)per_slab;
+  if (jit_launch(data_half ? s->jk.slab_stats_data : s->jk.slab_stats_model, sa, (unsigned)gx, (unsigned)h->slab_n, (unsigned)block, (unsigned)lds, st) != hipSuccess)
+    return fail(h, CRBM_ERR_HIP, "launch of the slab statistics kernel failed");
+  SlabReduceArgs ra;
+  ra.partials = pbuf.p;
+  ra.sums = h->d_sums + (data_half ? h->sl.data_off : h->sl.model_off);
+  ra.nrows = r.nrows; ra.row = r.row;
+  ra.Ks = Ks; ra.k0 = slab_origin(h, h->slab_n - 1); ra.K = h->K; ra.M4 = 4 * M;
+  ra.partial_stride = (long long)per_slab;
+  ra.ds = h->ds; ra.want_sparsity = data_half ? 1 : 0;
+  const int full_row = 3 * h->KAM + 3 * h->K + 4;
+  ra.skip_begin = data_half ? full_row : h->sl.model_skip_begin;
+  ra.skip_len = data_half ? 0 : h->sl.model_skip_len;
+  ra.n_value = (float)n;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((ra.row + 31) / 32, h->slab_n), dim3(1024), 0, st, ra);
+  HIPCHK(hipGetLastError());
   *reduce = ReduceArgs();
   reduce->nrows = 0; reduce->row = 0;     // nothing left for the caller's column reduction
   return CRBM_OK;
@@ -931,7 +939,7 @@ int slab_setup(crbm_handle* h) {
   if (env_int("CRBM_SLAB_STATS", 1) == 0) { h->slab_note = "CRBM_SLAB_STATS=0"; return CRBM_OK; }
   if (h->A != 4 || h->M > MAX_MOTIF_LENGTH) { h->slab_note = "other alphabet, or motifs beyond 64 letters"; return CRBM_OK; }
   // a model of up to `want` motifs is one slab; a larger one takes slabs of a multiple of ten motifs (the sampler's groups)
-  const int want = std::max(10, std::min(env_int("CRBM_SLAB_MOTIFS", 60), MAX_MOTIFS));
+  const int want = std::max(10, std::min(env_int("CRBM_SLAB_MOTIFS", 60), 64));      // (the slab kernels are compiled for models of up to 64 motifs: crbm_jit.h)
   int Ks = 0, G = 0;
   ModelShape ms;
   const int first = h->K <= want ? h->K : want / 10 * 10;
@@ -974,7 +982,7 @@ int slab_setup(crbm_handle* h) {
   s->sl = sums_layout(Ks, h->M);
   s->stats_rows = h->stats_rows;
   h->slab_n = (h->K + Ks - 1) / Ks;
-  h->slab_hgv = (h->slab_n == 1 || Ks % 10 == 0) && Ks <= 64 && env_int("CRBM_SLAB_HGV", 1) != 0;   // (crbm_hgv_masks: compiled up to 64 motifs)
+  h->slab_hgv = (h->slab_n == 1 || Ks % 10 == 0) && env_int("CRBM_SLAB_HGV", 1) != 0;
   if (hipMalloc((void**)&s->d_sums, (size_t)s->sl.count * 4) != hipSuccess ||
       hipMalloc((void**)&h->d_slab_tables, (size_t)h->slab_n * ms.TABLES_ALL * 4) != hipSuccess) {
     (void)hipGetLastError();

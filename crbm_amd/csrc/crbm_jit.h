@@ -29,7 +29,7 @@ namespace crbm {
 struct JitKernels {
   hipModule_t module = nullptr;
   hipFunction_t build_tables = nullptr, update_tables = nullptr, update_tables_ipc = nullptr, hgv = nullptr, gibbs = nullptr /* dense top-down; null if the model has none */,
-                build_gather_solo = nullptr /* gather table of the solo letter grouping */, hgv_masks = nullptr /* empty beyond 64 motifs */,
+                build_gather_solo = nullptr /* gather table of the solo letter grouping */, slab_hgv = nullptr, slab_tables = nullptr, slab_stats_data = nullptr, slab_stats_model = nullptr /* the model as a slab of a larger one: empty beyond 64 motifs */,
                 gibbs_sparse = nullptr, gibbs_sparse_stats = nullptr /* empty unless Cfg::FUSE_STATS */, train_local = nullptr /* ditto */, stats_mfma_data = nullptr, stats_mfma_model = nullptr,
                 free_energy = nullptr, hit_summary = nullptr;
   bool from_cache = false;
@@ -93,7 +93,8 @@ inline std::string jit_stub(int K, int M, int DS, int G, int GS, int POOL, int g
            "extern \"C\" __global__ void __launch_bounds__(1024) crbm_update_tables(crbm::UpdateTablesArgs a) { crbm::update_tables_body<ModelCfg>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(1024) crbm_update_tables_ipc(crbm::UpdateIpcArgs a) { crbm::update_tables_ipc_body<ModelCfg>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_hgv(crbm::HgvArgs a) { crbm::hgv_body<ModelCfg>(a); }\n"
-           "extern \"C\" __global__ void __launch_bounds__(256) crbm_hgv_masks(crbm::HgvMasksArgs a) { if constexpr (ModelCfg::K <= 64) crbm::hgv_masks_body<ModelCfg>(a); }\n"
+           "extern \"C\" __global__ void __launch_bounds__(256) crbm_slab_hgv(crbm::SlabHgvArgs a) { if constexpr (ModelCfg::K <= 64) crbm::slab_hgv_body<ModelCfg>(a); }\n"
+           "extern \"C\" __global__ void __launch_bounds__(256) crbm_slab_tables(crbm::SlabTablesArgs a) { if constexpr (ModelCfg::K <= 64) crbm::slab_tables_body<ModelCfg>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(%d) CRBM_GIBBS_ATTR crbm_gibbs_sparse(crbm::GibbsArgs a) { crbm::gibbs_body<SoloCfg, true>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(CRBM_FUSED_TB) CRBM_GIBBS_STATS_ATTR crbm_gibbs_sparse_stats(crbm::GibbsArgs a) { if constexpr (ModelCfg::FUSE_STATS) crbm::gibbs_body<ModelCfg, true, true>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(CRBM_FUSED_TB) CRBM_GIBBS_STATS_ATTR crbm_train_local(crbm::TrainLocalArgs a) { crbm::train_local_body<ModelCfg>(a); }\n"
@@ -101,6 +102,8 @@ inline std::string jit_stub(int K, int M, int DS, int G, int GS, int POOL, int g
            "using RoleData = crbm::StatsRole<ModelCfg, true>;\nusing RoleModel = crbm::StatsRole<ModelCfg, false>;\n"
            "extern \"C\" __global__ void __launch_bounds__(RoleData::THREADS) crbm_stats_mfma_data(crbm::StatsMfmaArgs a) { crbm::stats_mfma_body<ModelCfg, true, CRBM_STATS_BYTE_LUT>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(RoleModel::THREADS) crbm_stats_mfma_model(crbm::StatsMfmaArgs a) { crbm::stats_mfma_body<ModelCfg, false, CRBM_STATS_BYTE_LUT>(a); }\n"
+           "extern \"C\" __global__ void __launch_bounds__(RoleData::THREADS) crbm_slab_stats_data(crbm::SlabStatsArgs a) { if constexpr (ModelCfg::K <= 64) crbm::slab_stats_body<ModelCfg, true, CRBM_STATS_BYTE_LUT>(a); }\n"
+           "extern \"C\" __global__ void __launch_bounds__(RoleModel::THREADS) crbm_slab_stats_model(crbm::SlabStatsArgs a) { if constexpr (ModelCfg::K <= 64) crbm::slab_stats_body<ModelCfg, false, CRBM_STATS_BYTE_LUT>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_free_energy(crbm::FeArgs a) { crbm::free_energy_body<ModelCfg>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_hit_summary(crbm::HitArgs a) { crbm::hit_summary_body<ModelCfg>(a); }\n",
            attr, sattr, K, M, DS, G, POOL, K, M, DS, GS, POOL, gibbs_tb, gibbs_tb);
@@ -190,7 +193,7 @@ inline int jit_load(int K, int M, int DS, int G, int GS, int POOL, int gibbs_wpe
     return -1;
   }
   struct { const char* name; hipFunction_t* f; } syms[] = {
-      {"crbm_build_tables", &out->build_tables}, {"crbm_build_gather_solo", &out->build_gather_solo}, {"crbm_update_tables", &out->update_tables}, {"crbm_update_tables_ipc", &out->update_tables_ipc}, {"crbm_hgv", &out->hgv}, {"crbm_hgv_masks", &out->hgv_masks}, {"crbm_gibbs", &out->gibbs},
+      {"crbm_build_tables", &out->build_tables}, {"crbm_build_gather_solo", &out->build_gather_solo}, {"crbm_update_tables", &out->update_tables}, {"crbm_update_tables_ipc", &out->update_tables_ipc}, {"crbm_hgv", &out->hgv}, {"crbm_slab_hgv", &out->slab_hgv}, {"crbm_slab_tables", &out->slab_tables}, {"crbm_slab_stats_data", &out->slab_stats_data}, {"crbm_slab_stats_model", &out->slab_stats_model}, {"crbm_gibbs", &out->gibbs},
       {"crbm_gibbs_sparse", &out->gibbs_sparse}, {"crbm_gibbs_sparse_stats", &out->gibbs_sparse_stats}, {"crbm_train_local", &out->train_local},
       {"crbm_stats_mfma_data", &out->stats_mfma_data},
       {"crbm_stats_mfma_model", &out->stats_mfma_model}, {"crbm_free_energy", &out->free_energy},

@@ -804,7 +804,7 @@ __device__ void hgv_masks_body(const HgvMasksArgs& ma) {
       for (int w = 0; w <= C::NW; ++w) {
         const uint32_t cur = w < C::NW ? mask[w < C::NW ? w : 0] : 0u, prev = w > 0 ? mask[w - 1] : 0u;
         const uint32_t bits = sh ? (cur << sh) | (prev >> (32 - sh)) : cur;
-        if (bits && w0 + w < ma.NWfull) wp[w0 + w] |= bits;
+        if (bits && w0 + w < ma.NWfull) atomicOr(&wp[w0 + w], bits);      // (the slabs of a launch share words: slab_hgv_body)
       }
     }
   }
@@ -2328,6 +2328,62 @@ __device__ __forceinline__ void reduce_partials_body(const ReduceArgs& a, const 
 struct ReducePair {
   ReduceArgs half[2];
 };
+
+// ===========================================================================
+// A model as a row of SLABS of the kernels' model (crbm_api.hip: slab_launch_stats, slab_launch_hgv -- generic DNA
+// models take their statistics and the h|v of their chains from the specialised kernels, Ks motifs at a time).  One launch
+// serves all slabs: blockIdx.y is the slab, whose table image, partial rows and first motif follow from it; the bodies
+// above run unchanged (they look at blockIdx.x only).
+// ===========================================================================
+struct SlabPlan {
+  int32_t Ks, K, last_k0;     // motifs per slab, motifs of the model, first motif of the last slab (it may overlap its neighbour)
+};
+__device__ __forceinline__ int slab_k0(const SlabPlan& p, int y) { return (y + 1) * p.Ks <= p.K ? y * p.Ks : p.last_k0; }
+
+struct SlabTablesArgs {
+  TablesArgs t;               // W, b of the whole model; out: the first slab's image
+  SlabPlan plan;
+  int32_t stride;             // floats between the images of consecutive slabs
+};
+template <class C>
+__device__ void slab_tables_body(const SlabTablesArgs& s) {
+  TablesArgs a = s.t;
+  const int k0 = slab_k0(s.plan, (int)blockIdx.y);
+  a.W += (size_t)k0 * 4 * C::M;
+  a.b += k0;
+  a.out += (size_t)blockIdx.y * s.stride;
+  build_tables_body<C>(a);
+}
+
+struct SlabStatsArgs {
+  StatsMfmaArgs a;            // tables, partial rows: the first slab's
+  int32_t table_stride;       // floats
+  int32_t pad_;
+  long long partial_stride;   // floats between the partial rows of consecutive slabs
+};
+template <class C, bool SP, bool BYTE_LUT>
+__device__ void slab_stats_body(const SlabStatsArgs& s) {
+  StatsMfmaArgs a = s.a;
+  a.tables += (size_t)blockIdx.y * s.table_stride;
+  a.sg.partials += (size_t)blockIdx.y * s.partial_stride;
+  stats_mfma_body<C, SP, BYTE_LUT>(a);
+}
+
+struct SlabHgvArgs {
+  HgvMasksArgs m;             // k0, kskip, group0 are filled in per slab
+  SlabPlan plan;
+  int32_t table_stride;       // floats
+};
+template <class C>
+__device__ void slab_hgv_body(const SlabHgvArgs& s) {
+  HgvMasksArgs ma = s.m;
+  const int y = (int)blockIdx.y, k0 = slab_k0(s.plan, y);
+  ma.g.tables += (size_t)y * s.table_stride;
+  ma.k0 = k0;
+  ma.group0 = (uint32_t)(k0 / 10);
+  ma.kskip = y > 0 ? max(0, slab_k0(s.plan, y - 1) + s.plan.Ks - k0) : 0;     // units the neighbouring slab counts
+  hgv_masks_body<C>(ma);
+}
 
 #ifdef CRBM_DEFINE_MISC_KERNELS
 // ===========================================================================

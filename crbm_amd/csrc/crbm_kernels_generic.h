@@ -756,7 +756,8 @@ struct SlabReduceArgs {
   const float* partials;   // [nrows][row] partial rows of the slab model
   float* sums;             // the full model's sums of this half (d_sums + data_off or model_off)
   int32_t nrows, row;      // row = 3 Ks 4M + 3 Ks + 4
-  int32_t Ks, k0, K, M4;   // motifs of the slab, its first motif, motifs of the model, 4 * motif_length
+  int32_t Ks, k0, K, M4;   // motifs of the slab, first motif of the last slab (slab_k0: blockIdx.y is the slab), motifs of the model, 4 * motif_length
+  long long partial_stride;   // floats between the partial rows of consecutive slabs
   int32_t ds, want_sparsity;
   int32_t skip_begin, skip_len;   // columns of the FULL row that are not carried (model half: sw, sb)
   float n_value;
@@ -768,31 +769,34 @@ __global__ void __launch_bounds__(1024) slab_reduce_kernel(SlabReduceArgs a) {
   const int ngrp = (int)(blockDim.x >> 5);
   const int r = blockIdx.x * 32 + col;
   const int Ks = a.Ks, K = a.K, KAMs = a.Ks * a.M4, KAM = a.K * a.M4;
+  const SlabPlan plan = {a.Ks, a.K, a.k0};
+  const int k0 = slab_k0(plan, (int)blockIdx.y);
+  const float* partials = a.partials + (size_t)blockIdx.y * a.partial_stride;
   int dst = -1;          // column of the full row
   bool valid = false;
   if (r < a.row) {
     int kk;              // motif of the slab this column belongs to (-1: none)
-    if (r < KAMs) { kk = r / a.M4; dst = a.k0 * a.M4 + r; valid = true; }
-    else if (r < 2 * KAMs) { kk = (r - KAMs) / a.M4; dst = KAM + a.k0 * a.M4 + (r - KAMs); valid = a.ds != 0; }
-    else if (r < 2 * KAMs + Ks) { kk = r - 2 * KAMs; dst = 2 * KAM + a.k0 + kk; valid = true; }
-    else if (r < 2 * KAMs + 2 * Ks) { kk = r - 2 * KAMs - Ks; dst = 2 * KAM + K + a.k0 + kk; valid = a.ds != 0; }
-    else if (r < 3 * KAMs + 2 * Ks) { kk = (r - 2 * KAMs - 2 * Ks) / a.M4; dst = 2 * KAM + 2 * K + a.k0 * a.M4 + (r - 2 * KAMs - 2 * Ks); valid = a.want_sparsity != 0; }
-    else if (r < 3 * KAMs + 3 * Ks) { kk = r - 3 * KAMs - 2 * Ks; dst = 3 * KAM + 2 * K + a.k0 + kk; valid = a.want_sparsity != 0; }
+    if (r < KAMs) { kk = r / a.M4; dst = k0 * a.M4 + r; valid = true; }
+    else if (r < 2 * KAMs) { kk = (r - KAMs) / a.M4; dst = KAM + k0 * a.M4 + (r - KAMs); valid = a.ds != 0; }
+    else if (r < 2 * KAMs + Ks) { kk = r - 2 * KAMs; dst = 2 * KAM + k0 + kk; valid = true; }
+    else if (r < 2 * KAMs + 2 * Ks) { kk = r - 2 * KAMs - Ks; dst = 2 * KAM + K + k0 + kk; valid = a.ds != 0; }
+    else if (r < 3 * KAMs + 2 * Ks) { kk = (r - 2 * KAMs - 2 * Ks) / a.M4; dst = 2 * KAM + 2 * K + k0 * a.M4 + (r - 2 * KAMs - 2 * Ks); valid = a.want_sparsity != 0; }
+    else if (r < 3 * KAMs + 3 * Ks) { kk = r - 3 * KAMs - 2 * Ks; dst = 3 * KAM + 2 * K + k0 + kk; valid = a.want_sparsity != 0; }
     else { kk = -1; dst = 3 * KAM + 3 * K + (r - 3 * KAMs - 3 * Ks); valid = true; }
-    if (kk >= 0 && a.k0 + kk >= K) { dst = -1; valid = false; }      // the last slab may reach past the model's end (its padding)
+    if (kk >= 0 && k0 + kk >= K) { dst = -1; valid = false; }      // the last slab may reach past the model's end (its padding)
   }
   float tsum = 0.f;
   if (valid) {      // eight rows in flight per thread, fixed order (reduce_partials_body)
     float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f, t4 = 0.f, t5 = 0.f, t6 = 0.f, t7 = 0.f;
     int i = grp;
     for (; i + 7 * ngrp < a.nrows; i += 8 * ngrp) {
-      const float v0 = a.partials[(size_t)i * a.row + r], v1 = a.partials[(size_t)(i + ngrp) * a.row + r];
-      const float v2 = a.partials[(size_t)(i + 2 * ngrp) * a.row + r], v3 = a.partials[(size_t)(i + 3 * ngrp) * a.row + r];
-      const float v4 = a.partials[(size_t)(i + 4 * ngrp) * a.row + r], v5 = a.partials[(size_t)(i + 5 * ngrp) * a.row + r];
-      const float v6 = a.partials[(size_t)(i + 6 * ngrp) * a.row + r], v7 = a.partials[(size_t)(i + 7 * ngrp) * a.row + r];
+      const float v0 = partials[(size_t)i * a.row + r], v1 = partials[(size_t)(i + ngrp) * a.row + r];
+      const float v2 = partials[(size_t)(i + 2 * ngrp) * a.row + r], v3 = partials[(size_t)(i + 3 * ngrp) * a.row + r];
+      const float v4 = partials[(size_t)(i + 4 * ngrp) * a.row + r], v5 = partials[(size_t)(i + 5 * ngrp) * a.row + r];
+      const float v6 = partials[(size_t)(i + 6 * ngrp) * a.row + r], v7 = partials[(size_t)(i + 7 * ngrp) * a.row + r];
       t0 += v0; t1 += v1; t2 += v2; t3 += v3; t4 += v4; t5 += v5; t6 += v6; t7 += v7;
     }
-    for (; i < a.nrows; i += ngrp) t0 += a.partials[(size_t)i * a.row + r];
+    for (; i < a.nrows; i += ngrp) t0 += partials[(size_t)i * a.row + r];
     tsum = ((t0 + t1) + (t2 + t3)) + ((t4 + t5) + (t6 + t7));
   }
   part[grp][col] = tsum;
@@ -805,5 +809,5 @@ __global__ void __launch_bounds__(1024) slab_reduce_kernel(SlabReduceArgs a) {
       a.sums[dst < a.skip_begin ? dst : dst - a.skip_len] = s;     // (columns of a kind the model does not have: zero, as the plain reduction writes them)
     }
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) a.sums[(3 * KAM + 3 * K + 4) - a.skip_len] = a.n_value;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.sums[(3 * KAM + 3 * K + 4) - a.skip_len] = a.n_value;
 }

@@ -163,30 +163,42 @@ int emu_hgv(int id, const float* tables, const uint32_t* letters, int n, int L, 
   return 0;
 }
 
-// h | v of a SLAB of a larger model's chain (crbm_api.hip, slab_launch_hgv): the sample as bits of the larger model's mask rows
-int emu_hgv_masks(int id, const float* tables, const uint32_t* letters, int n, int L, int mode, uint32_t* masks, int NWfull,
-                  int k0, int Kfull, int kskip, unsigned long long* ones, uint64_t seed, uint32_t step, uint32_t off,
-                  uint32_t kind, int TS, int grid, int threads) {
-  HgvMasksArgs ma;
-  HgvArgs& a = ma.g;
+// the table images of all slabs of a larger model in one launch (slab_tables_body; blockIdx.y = slab)
+int emu_slab_tables(int id, const float* W, const float* b, const float* c, float* out, int K, int last_k0, int nslab) {
+  SlabTablesArgs a;
+  a.t.W = W; a.t.b = b; a.t.c = c; a.t.out = out;
+  CFG_DISPATCH(id, (a.plan.Ks = C::K, a.plan.K = K, a.plan.last_k0 = last_k0, a.stride = C::TABLES_ALL,
+                    emu::launch([&] { slab_tables_body<C>(a); }, dim3(2, nslab), dim3(64), 0)));
+  return 0;
+}
+
+// h | v of a larger model's chain, all slabs in one launch (crbm_api.hip, slab_launch_hgv): the sample as bits of the larger
+// model's mask rows
+int emu_slab_hgv(int id, const float* tables, const uint32_t* letters, int n, int L, int mode, uint32_t* masks, int NWfull,
+                 int Kfull, int last_k0, int nslab, unsigned long long* ones, uint64_t seed, uint32_t step, uint32_t off,
+                 uint32_t kind, int TS, int grid, int threads) {
+  SlabHgvArgs sa;
+  HgvArgs& a = sa.m.g;
   a.tables = tables; a.letters = letters; a.n = n; a.L = L; a.LW = letter_words(L);
   a.TS = TS; a.mode = mode;
   a.act = nullptr; a.prob = nullptr; a.sample = nullptr; a.ones = ones;
   a.rng = make_rng(seed, step, off); a.kind = kind;
-  ma.masks = masks; ma.NWfull = NWfull; ma.k0 = k0; ma.Kfull = Kfull; ma.kskip = kskip; ma.group0 = (uint32_t)(k0 / 10);
+  sa.m.masks = masks; sa.m.NWfull = NWfull; sa.m.Kfull = Kfull; sa.m.k0 = 0; sa.m.kskip = 0; sa.m.group0 = 0;
   CFG_DISPATCH(id, (a.Lh = L - C::M + 1, a.divLh = make_fastdiv((uint32_t)a.Lh),
-                    emu::launch([&] { hgv_masks_body<C>(ma); }, dim3(grid), dim3(threads), (size_t)C::TAB * 4)));
+                    sa.plan.Ks = C::K, sa.plan.K = Kfull, sa.plan.last_k0 = last_k0, sa.table_stride = C::TABLES_ALL,
+                    emu::launch([&] { slab_hgv_body<C>(sa); }, dim3(grid, nslab), dim3(threads), (size_t)C::TAB * 4)));
   return 0;
 }
 
-// column reduction of a slab's partial rows into its columns of the larger model's sums (slab_reduce_kernel)
-int emu_slab_reduce(const float* partials, float* sums, int nrows, int row, int Ks, int k0, int K, int M4, int ds,
+// column reduction of all slabs' partial rows into their columns of the larger model's sums (slab_reduce_kernel)
+int emu_slab_reduce(const float* partials, float* sums, int nrows, int row, int Ks, int last_k0, int nslab, int K, int M4, int ds,
                     int want_sparsity, int skip_begin, int skip_len, float n_value, int threads) {
   SlabReduceArgs a;
   a.partials = partials; a.sums = sums; a.nrows = nrows; a.row = row;
-  a.Ks = Ks; a.k0 = k0; a.K = K; a.M4 = M4; a.ds = ds; a.want_sparsity = want_sparsity;
+  a.Ks = Ks; a.k0 = last_k0; a.K = K; a.M4 = M4; a.ds = ds; a.want_sparsity = want_sparsity;
+  a.partial_stride = (long long)nrows * row;
   a.skip_begin = skip_begin; a.skip_len = skip_len; a.n_value = n_value;
-  emu::launch([&] { slab_reduce_kernel(a); }, dim3((row + 31) / 32), dim3(threads), 0);
+  emu::launch([&] { slab_reduce_kernel(a); }, dim3((row + 31) / 32, nslab), dim3(threads), 0);
   return 0;
 }
 

@@ -947,16 +947,17 @@ def test_slabs():
         Lh, NW = L - M + 1, (K + 31) // 32
         nslab = (K + Ks - 1) // Ks
         origins = [i * Ks if (i + 1) * Ks <= K else (K - Ks + 9) // 10 * 10 for i in range(nslab)]
+        tabs = np.zeros(nslab * info["TABLES"], dtype=np.float32)
+        assert lib.emu_slab_tables(cid, fp(Wp), fp(bp), fp(c), fp(tabs), K, origins[-1], nslab) == 0
+        for i, k0 in enumerate(origins):                 # the image of every slab is the image of that slab as a model
+            t = np.zeros(info["TABLES"], dtype=np.float32)
+            assert lib.emu_tables(cid, fp(np.ascontiguousarray(Wp[k0:k0 + Ks])), fp(np.ascontiguousarray(bp[k0:k0 + Ks])), fp(c), fp(t)) == 0
+            np.testing.assert_array_equal(tabs[i * info["TABLES"]:(i + 1) * info["TABLES"]], t)
         for strand in range(2 if ds else 1):
             masks = np.zeros((n, Lh, NW), dtype=np.uint32)
             ones = ctypes.c_ulonglong(0)
-            covered = 0
-            for k0 in origins:
-                t = np.zeros(info["TABLES"], dtype=np.float32)
-                assert lib.emu_tables(cid, fp(np.ascontiguousarray(Wp[k0:k0 + Ks])), fp(np.ascontiguousarray(bp[k0:k0 + Ks])), fp(c), fp(t)) == 0
-                assert lib.emu_hgv_masks(cid, fp(t), up(letters), n, L, strand, up(masks), NW, k0, K, max(0, covered - k0),
-                                         ctypes.byref(ones), ctypes.c_uint64(91), 4, 2, KIND_CHAIN_H, 2, 2, 128) == 0
-                covered = k0 + Ks
+            assert lib.emu_slab_hgv(cid, fp(tabs), up(letters), n, L, strand, up(masks), NW, K, origins[-1], nslab,
+                                    ctypes.byref(ones), ctypes.c_uint64(91), 4, 2, KIND_CHAIN_H, 2, 2, 128) == 0
             smp = unpack_hidden(masks, K).astype(np.float32).reshape(n, K, 1, Lh)
             assert ones.value == int(smp.sum()) and smp.sum() > 0
             x = o._bottomUpActivity(d, strand == 1)
@@ -968,25 +969,31 @@ def test_slabs():
                 u = hidden_uniforms(91, 4, np.arange(n) + 2, K, Lh, strand, KIND_CHAIN_H)
                 check_samples("slab hgv", smp, 1 / (1 + np.exp(-x)), u)
         print("slab hgv ok", cid, (K, Ks, M, ds, pool), origins)
-    # slab_reduce_kernel: data half (everything carried) and model half (sw, sb dropped), a slab that reaches past motif K
+    # slab_reduce_kernel, all slabs in one launch: data half (everything carried) and model half (sw, sb dropped); the last slab
+    # overlaps its neighbour (the same sums twice, as the kernels produce them) and reaches past motif K (dropped)
     rng = np.random.default_rng(5)
-    K, Ks, M, k0 = 47, 20, 3, 30
+    K, Ks, M = 47, 20, 3
+    origins, nslab = [0, 20, 30], 3
     M4, KAM, KAMs = 4 * M, K * 4 * M, Ks * 4 * M
     row, full = 3 * KAMs + 3 * Ks + 4, 3 * KAM + 3 * K + 4
     nrows = 11
-    part = rng.standard_normal((nrows, row)).astype(np.float32)
-    col = part.astype(np.float64).sum(axis=0)
+    part = rng.standard_normal((nslab, nrows, row)).astype(np.float32)
+    classes = [(0, 0, M4), (KAM, KAMs, M4), (2 * KAM, 2 * KAMs, 1), (2 * KAM + K, 2 * KAMs + Ks, 1),
+               (2 * KAM + 2 * K, 2 * KAMs + 2 * Ks, M4), (3 * KAM + 2 * K, 3 * KAMs + 2 * Ks, 1)]     # (column in the full row, in the slab row, per motif)
+    for dst, src, per in classes:                         # motifs 30..39: slab 2's columns are slab 1's
+        part[2, :, src:src + 10 * per] = part[1, :, src + 10 * per:src + 20 * per]
+    part[2, :, 3 * KAMs + 3 * Ks:] = part[1, :, 3 * KAMs + 3 * Ks:] = part[0, :, 3 * KAMs + 3 * Ks:]      # letter counts: the same in every slab
+    col = part.astype(np.float64).sum(axis=1)
     for dsf, sp, skip_begin, skip_len in ((1, 1, full, 0), (0, 0, 2 * KAM + 2 * K, KAM + K), (1, 0, 2 * KAM + 2 * K, KAM + K)):
         sums = np.full(full + 1 - skip_len, -7.0, dtype=np.float32)
-        assert lib.emu_slab_reduce(fp(part), fp(sums), nrows, row, Ks, k0, K, M4, dsf, sp, skip_begin, skip_len, ctypes.c_float(13.0), 64) == 0
+        assert lib.emu_slab_reduce(fp(part), fp(sums), nrows, row, Ks, origins[-1], nslab, K, M4, dsf, sp, skip_begin, skip_len, ctypes.c_float(13.0), 64) == 0
         want = np.full(full + 1, -7.0)
-        kk = K - k0                                     # motifs of the slab that exist
-        def put(dst, src, per, valid):
-            want[dst + k0 * per:dst + (k0 + kk) * per] = col[src:src + kk * per] if valid else 0.0
-        put(0, 0, M4, True); put(KAM, KAMs, M4, dsf)
-        put(2 * KAM, 2 * KAMs, 1, True); put(2 * KAM + K, 2 * KAMs + Ks, 1, dsf)
-        put(2 * KAM + 2 * K, 2 * KAMs + 2 * Ks, M4, sp); put(3 * KAM + 2 * K, 3 * KAMs + 2 * Ks, 1, sp)
-        want[3 * KAM + 3 * K:3 * KAM + 3 * K + 4] = col[3 * KAMs + 3 * Ks:]
+        valid = [True, dsf, True, dsf, sp, sp]
+        for (dst, src, per), ok in zip(classes, valid):
+            for i, k0 in enumerate(origins):
+                kk = min(Ks, K - k0)                      # motifs of the slab that exist
+                want[dst + k0 * per:dst + (k0 + kk) * per] = col[i, src:src + kk * per] if ok else 0.0
+        want[3 * KAM + 3 * K:3 * KAM + 3 * K + 4] = col[0, 3 * KAMs + 3 * Ks:]
         want[full] = 13.0
         want = np.delete(want, np.arange(skip_begin, skip_begin + skip_len)) if skip_len else want
         np.testing.assert_allclose(sums, want, rtol=1e-5, atol=1e-5)
