@@ -309,6 +309,7 @@ constexpr int SLAB_FALLBACK = -1000;     // slab_launch_stats / slab_launch_hgv:
 int slab_launch_hgv(crbm_handle* h, const uint32_t* d_letters, int n, int L, int mode, unsigned long long* ones, uint32_t* masks,
                     uint32_t kind, uint32_t step, uint32_t seq_offset, hipStream_t st);
 int slab_launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bool data_half, hipStream_t st, ReduceArgs* reduce);
+int slab_launch_fe(crbm_handle* h, const uint32_t* rows, int n, int L, float* fe, float* fem, hipStream_t st);
 
 // h | v on packed rows: dense outputs (API), a count of sampled ones (evaluateData) or the masks of one strand (chain)
 int big_launch_hgv(crbm_handle* h, const uint32_t* d_letters, int n, int L, int mode, float* act, float* prob, float* sample,
@@ -428,6 +429,10 @@ int big_launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, bo
 // free energies (hits = 0) or motif-hit summaries (hits = 1) of n packed rows
 int big_launch_eval(crbm_handle* h, const uint32_t* rows, int n, int L, int hits, float* fe, float* fem, float* hmax, float* hmean,
                     unsigned long long* pos_fx, hipStream_t st) {
+  if (h->slab && !hits && env_int("CRBM_SLAB_FE", 1) != 0) {       // free energies: the specialised kernel, slab by slab
+    const int rc = slab_launch_fe(h, rows, n, L, fe, fem, st);
+    if (rc != SLAB_FALLBACK) return rc;
+  }
   BigEvalArgs a;
   a.m = big_model(h);
   a.letters = rows;
@@ -932,6 +937,37 @@ int slab_launch_stats(crbm_handle* h, const uint32_t* d_letters, int n, int L, b
   return CRBM_OK;
 }
 
+// Free energies of a generic DNA model (freeEnergy, evaluateData, the per-epoch evaluation of fit(): convRBM.py:657-697, :517-522):
+// the slab model's free-energy kernel leaves every slab's per-motif terms in a scratch (one launch, blockIdx.y = slab),
+// slab_fe_combine_kernel adds them up per sequence.
+int slab_launch_fe(crbm_handle* h, const uint32_t* rows, int n, int L, float* fe, float* fem, hipStream_t st) {
+  crbm_handle* s = h->slab;
+  if (tab_bytes(s) > 160 * 1024) return SLAB_FALLBACK;
+  int rc = slab_ensure_tables(h, st);
+  if (rc) return rc;
+  const size_t per_slab = (size_t)n * s->K;
+  HIPCHK(s->out_b.ensure(per_slab * h->slab_n));
+  SlabFeArgs sa;
+  sa.a.tables = h->d_slab_tables;
+  sa.a.letters = rows;
+  sa.a.n = n; sa.a.L = L; sa.a.Lh = L - h->M + 1; sa.a.LW = lw(h, L);
+  sa.a.fe = nullptr; sa.a.fem = s->out_b.p;
+  sa.table_stride = s->ms.TABLES_ALL; sa.pad_ = 0;
+  sa.fem_stride = (long long)per_slab;
+  const unsigned gx = (unsigned)std::max(1, std::min((n + 3) / 4, h->num_cu * 8));
+  HIPCHK(jit_launch(s->jk.slab_fe, sa, gx, (unsigned)h->slab_n, 256, (unsigned)tab_bytes(s), st));
+  SlabFeCombineArgs ca;
+  ca.scratch = s->out_b.p;
+  ca.c_log2e = h->d_slab_tables + s->ms.OFF_C;
+  ca.letters = rows;
+  ca.n = n; ca.L = L; ca.LW = lw(h, L);
+  ca.Ks = s->K; ca.K = h->K; ca.last_k0 = slab_origin(h, h->slab_n - 1); ca.nslab = h->slab_n;
+  ca.fe = fe; ca.fem = fem;
+  hipLaunchKernelGGL(slab_fe_combine_kernel, dim3(gx), dim3(256), 0, st, ca);
+  HIPCHK(hipGetLastError());
+  return CRBM_OK;
+}
+
 // The shadow handle of the slab model of a generic handle (crbm_create); leaves h->slab null, with the reason in
 // h->slab_note, when the model is not one for slabs.  CRBM_SLAB_STATS=0 switches them off (A/B runs, tests).
 int slab_setup(crbm_handle* h) {
@@ -1000,7 +1036,7 @@ int slab_setup(crbm_handle* h) {
 void slab_destroy(crbm_handle* h) {
   if (crbm_handle* s = h->slab) {
     if (s->d_sums) (void)hipFree(s->d_sums);
-    s->partials.release(); s->partials2.release();
+    s->partials.release(); s->partials2.release(); s->out_b.release();
     if (s->jk.module) (void)hipModuleUnload(s->jk.module);
     delete s;
     h->slab = nullptr;

@@ -29,7 +29,7 @@ namespace crbm {
 struct JitKernels {
   hipModule_t module = nullptr;
   hipFunction_t build_tables = nullptr, update_tables = nullptr, update_tables_ipc = nullptr, hgv = nullptr, gibbs = nullptr /* dense top-down; null if the model has none */,
-                build_gather_solo = nullptr /* gather table of the solo letter grouping */, slab_hgv = nullptr, slab_tables = nullptr, slab_stats_data = nullptr, slab_stats_model = nullptr /* the model as a slab of a larger one: empty beyond 64 motifs */,
+                build_gather_solo = nullptr /* gather table of the solo letter grouping */, slab_hgv = nullptr, slab_tables = nullptr, slab_stats_data = nullptr, slab_stats_model = nullptr, slab_fe = nullptr /* the model as a slab of a larger one: empty beyond 64 motifs */,
                 gibbs_sparse = nullptr, gibbs_sparse_stats = nullptr /* empty unless Cfg::FUSE_STATS */, train_local = nullptr /* ditto */, stats_mfma_data = nullptr, stats_mfma_model = nullptr,
                 free_energy = nullptr, hit_summary = nullptr;
   bool from_cache = false;
@@ -105,6 +105,7 @@ inline std::string jit_stub(int K, int M, int DS, int G, int GS, int POOL, int g
            "extern \"C\" __global__ void __launch_bounds__(RoleData::THREADS) crbm_slab_stats_data(crbm::SlabStatsArgs a) { if constexpr (ModelCfg::K <= 64) crbm::slab_stats_body<ModelCfg, true, CRBM_STATS_BYTE_LUT>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(RoleModel::THREADS) crbm_slab_stats_model(crbm::SlabStatsArgs a) { if constexpr (ModelCfg::K <= 64) crbm::slab_stats_body<ModelCfg, false, CRBM_STATS_BYTE_LUT>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_free_energy(crbm::FeArgs a) { crbm::free_energy_body<ModelCfg>(a); }\n"
+           "extern \"C\" __global__ void __launch_bounds__(256) crbm_slab_fe(crbm::SlabFeArgs a) { if constexpr (ModelCfg::K <= 64) crbm::slab_fe_body<ModelCfg>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_hit_summary(crbm::HitArgs a) { crbm::hit_summary_body<ModelCfg>(a); }\n",
            attr, sattr, K, M, DS, G, POOL, K, M, DS, GS, POOL, gibbs_tb, gibbs_tb);
   return buf;
@@ -193,7 +194,7 @@ inline int jit_load(int K, int M, int DS, int G, int GS, int POOL, int gibbs_wpe
     return -1;
   }
   struct { const char* name; hipFunction_t* f; } syms[] = {
-      {"crbm_build_tables", &out->build_tables}, {"crbm_build_gather_solo", &out->build_gather_solo}, {"crbm_update_tables", &out->update_tables}, {"crbm_update_tables_ipc", &out->update_tables_ipc}, {"crbm_hgv", &out->hgv}, {"crbm_slab_hgv", &out->slab_hgv}, {"crbm_slab_tables", &out->slab_tables}, {"crbm_slab_stats_data", &out->slab_stats_data}, {"crbm_slab_stats_model", &out->slab_stats_model}, {"crbm_gibbs", &out->gibbs},
+      {"crbm_build_tables", &out->build_tables}, {"crbm_build_gather_solo", &out->build_gather_solo}, {"crbm_update_tables", &out->update_tables}, {"crbm_update_tables_ipc", &out->update_tables_ipc}, {"crbm_hgv", &out->hgv}, {"crbm_slab_hgv", &out->slab_hgv}, {"crbm_slab_tables", &out->slab_tables}, {"crbm_slab_stats_data", &out->slab_stats_data}, {"crbm_slab_stats_model", &out->slab_stats_model}, {"crbm_slab_fe", &out->slab_fe}, {"crbm_gibbs", &out->gibbs},
       {"crbm_gibbs_sparse", &out->gibbs_sparse}, {"crbm_gibbs_sparse_stats", &out->gibbs_sparse_stats}, {"crbm_train_local", &out->train_local},
       {"crbm_stats_mfma_data", &out->stats_mfma_data},
       {"crbm_stats_mfma_model", &out->stats_mfma_model}, {"crbm_free_energy", &out->free_energy},

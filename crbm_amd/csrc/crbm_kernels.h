@@ -2385,6 +2385,23 @@ __device__ void slab_hgv_body(const SlabHgvArgs& s) {
   hgv_masks_body<C>(ma);
 }
 
+// free energy: the per-motif terms -v_k - cs of every slab (free_energy_body's `fem`) into a scratch [slab][n][Ks];
+// slab_fe_combine_kernel (crbm_kernels_generic.h) puts them together
+struct SlabFeArgs {
+  FeArgs a;                   // fe unused; fem: the first slab's scratch
+  int32_t table_stride;       // floats
+  int32_t pad_;
+  long long fem_stride;       // floats between the scratch of consecutive slabs
+};
+template <class C>
+__device__ void slab_fe_body(const SlabFeArgs& s) {
+  FeArgs a = s.a;
+  a.tables += (size_t)blockIdx.y * s.table_stride;
+  a.fem += (size_t)blockIdx.y * s.fem_stride;
+  a.fe = nullptr;
+  free_energy_body<C>(a);
+}
+
 #ifdef CRBM_DEFINE_MISC_KERNELS
 // ===========================================================================
 // Model-independent kernels, compiled ahead of time into libcrbm_hip.so.

@@ -811,3 +811,41 @@ __global__ void __launch_bounds__(1024) slab_reduce_kernel(SlabReduceArgs a) {
   }
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.sums[(3 * KAM + 3 * K + 4) - a.skip_len] = a.n_value;
 }
+
+// Free energy of a model evaluated slab by slab (slab_fe_body: every slab leaves fem[n][kk] = -v_k - cs, v_k = sum over positions
+// and strands of softplus(x_k), cs = sum_p c[letter(p)] -- free_energy_body).  One wave per sequence: cs exactly as
+// free_energy_body forms it (same terms, same order), then -v_k = fem + cs motif by motif, F = (-sum_k v_k - cs) / L
+// (convRBM.py:657-697) and, where asked for, the per-motif free energies in the model's own (n, K) layout.
+struct SlabFeCombineArgs {
+  const float* scratch;       // [nslab][n][Ks]
+  const float* c_log2e;       // log2(e) * c as the slab tables hold it (C::OFF_C of any slab image)
+  const uint32_t* letters;
+  int32_t n, L, LW;
+  int32_t Ks, K, last_k0, nslab;
+  float* fe;                  // (n), may be null
+  float* fem;                 // (n, K), may be null
+};
+
+__global__ void __launch_bounds__(256) slab_fe_combine_kernel(SlabFeCombineArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const float c0 = LN2 * a.c_log2e[0], c1 = LN2 * a.c_log2e[1], c2 = LN2 * a.c_log2e[2], c3 = LN2 * a.c_log2e[3];
+  for (int nn = blockIdx.x * nwaves + wave; nn < a.n; nn += gridDim.x * nwaves) {
+    const uint32_t* row = a.letters + (size_t)nn * a.LW;
+    float cs = 0.f;
+    for (int p = lane; p < a.L; p += 64) {
+      const uint32_t l = (row[p >> 4] >> (2 * (p & 15))) & 3u;
+      cs += l == 0u ? c0 : l == 1u ? c1 : l == 2u ? c2 : c3;
+    }
+    cs = wave_sum(cs);
+    float part = 0.f;            // - sum of v_k over this lane's motifs
+    for (int k = lane; k < a.K; k += 64) {
+      const int y = k >= a.last_k0 ? a.nslab - 1 : k / a.Ks;        // (the last slab owns everything from its first motif on)
+      const int k0 = y == a.nslab - 1 ? a.last_k0 : y * a.Ks;
+      const float f = a.scratch[((size_t)y * a.n + nn) * a.Ks + (k - k0)];
+      if (a.fem) a.fem[(size_t)nn * a.K + k] = f;
+      part += f + cs;
+    }
+    const float tot = wave_sum(part);
+    if (lane == 0 && a.fe) a.fe[nn] = (tot - cs) / (float)a.L;
+  }
+}

@@ -190,6 +190,22 @@ int emu_slab_hgv(int id, const float* tables, const uint32_t* letters, int n, in
   return 0;
 }
 
+// free energy of a larger model slab by slab (slab_fe_body, blockIdx.y = slab) and the combine (slab_fe_combine_kernel)
+int emu_slab_fe(int id, const float* tables, const uint32_t* letters, int n, int L, float* scratch, int K, int last_k0, int nslab,
+                float* fe, float* fem, int grid, int threads) {
+  SlabFeArgs sa;
+  sa.a.tables = tables; sa.a.letters = letters; sa.a.n = n; sa.a.L = L; sa.a.LW = letter_words(L);
+  sa.a.fe = nullptr; sa.a.fem = scratch; sa.pad_ = 0;
+  SlabFeCombineArgs ca;
+  ca.scratch = scratch; ca.letters = letters; ca.n = n; ca.L = L; ca.LW = letter_words(L);
+  ca.K = K; ca.last_k0 = last_k0; ca.nslab = nslab; ca.fe = fe; ca.fem = fem;
+  CFG_DISPATCH(id, (sa.a.Lh = L - C::M + 1, sa.table_stride = C::TABLES_ALL, sa.fem_stride = (long long)n * C::K,
+                    ca.Ks = C::K, ca.c_log2e = tables + C::OFF_C,
+                    emu::launch([&] { slab_fe_body<C>(sa); }, dim3(grid, nslab), dim3(threads), (size_t)C::TAB * 4)));
+  emu::launch([&] { slab_fe_combine_kernel(ca); }, dim3(grid), dim3(threads), 0);
+  return 0;
+}
+
 // column reduction of all slabs' partial rows into their columns of the larger model's sums (slab_reduce_kernel)
 int emu_slab_reduce(const float* partials, float* sums, int nrows, int row, int Ks, int last_k0, int nslab, int K, int M4, int ds,
                     int want_sparsity, int skip_begin, int skip_len, float n_value, int threads) {

@@ -953,6 +953,13 @@ def test_slabs():
             t = np.zeros(info["TABLES"], dtype=np.float32)
             assert lib.emu_tables(cid, fp(np.ascontiguousarray(Wp[k0:k0 + Ks])), fp(np.ascontiguousarray(bp[k0:k0 + Ks])), fp(c), fp(t)) == 0
             np.testing.assert_array_equal(tabs[i * info["TABLES"]:(i + 1) * info["TABLES"]], t)
+        # free energies slab by slab (per sequence and per motif) against the oracle of the whole model
+        scratch = np.zeros(nslab * n * Ks, dtype=np.float32)
+        fe = np.zeros(n, dtype=np.float32)
+        fem = np.zeros((n, K), dtype=np.float32)
+        assert lib.emu_slab_fe(cid, fp(tabs), up(letters), n, L, fp(scratch), K, origins[-1], nslab, fp(fe), fp(fem), 2, 128) == 0
+        np.testing.assert_allclose(fe, o.freeEnergy(d), rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(fem, o.freeEnergy(d, True), rtol=2e-5, atol=2e-5)
         for strand in range(2 if ds else 1):
             masks = np.zeros((n, Lh, NW), dtype=np.uint32)
             ones = ctypes.c_ulonglong(0)

@@ -1082,6 +1082,9 @@ def test_slabbed_statistics_of_generic_models(K, M, ds, pool, monkeypatch):
     for a, b in zip(m1.get_fantasy(), m0.get_fantasy()):
         if a is not None:
             np.testing.assert_array_equal(a, b)                 # the chain does not depend on the statistics path
+    # free energies (convRBM.py:657-697) slab by slab: per sequence and per motif against the generic kernel and the oracle
+    np.testing.assert_allclose(m1.freeEnergy(D), m0.freeEnergy(D), rtol=RTOL, atol=1e-6)
+    np.testing.assert_allclose(m1.freeEnergy(D, True), m0.freeEnergy(D, True), rtol=RTOL, atol=2e-5)
     # evaluateData (convRBM.py:517-522): the sampled activity is counted by the slabbed h|v too
     e1, e0 = m1._evaluateData(D), m0._evaluateData(D)
     assert abs(e1[0] - e0[0]) <= 1e-5 * abs(e0[0]) and abs(e1[1] - e0[1]) <= 2.0 / (n * K * (L - M + 1)) and e1[1] > 0
@@ -1095,6 +1098,8 @@ def test_slabbed_statistics_of_generic_models(K, M, ds, pool, monkeypatch):
     o.b = m1.bias.get_value().astype(np.float64)
     P_m, P_mp, v_m = o.gibbs_steps(2)
     h1, h1p = m1.get_fantasy()
+    np.testing.assert_allclose(m1.freeEnergy(D), o.freeEnergy(D), rtol=RTOL, atol=1e-6)
+    np.testing.assert_allclose(m1.freeEnergy(D, True), o.freeEnergy(D, True), rtol=RTOL, atol=2e-5)
     if np.array_equal(h1, o.fantasy_h) and (not ds or np.array_equal(h1p, o.fantasy_h_prime)):
         want = o.local_sums(D, P_m, P_mp, v_m)
         for key in ("vh_d", "h_d", "sw", "sb", "v_d", "vh_m", "h_m", "v_m") + (("vh_dp", "h_dp", "vh_mp", "h_mp") if ds else ()):
