@@ -1002,7 +1002,7 @@ int slab_setup(crbm_handle* h) {
   if (!Ks) { h->slab_note = "no slab of this motif length fits the LDS"; return CRBM_OK; }
   crbm_handle* s = new crbm_handle();
   std::string err;
-  if (jit_load(Ks, h->M, h->ds, G, G, ms.POOL, 0, 256, &s->jk, &err) != 0) {
+  if (jit_load(Ks, h->M, h->ds, G, G, ms.POOL, 0, 256, &s->jk, &err, true) != 0) {
     h->slab_note = "kernel specialisation of the slab failed: " + err;
     if (s->jk.module) (void)hipModuleUnload(s->jk.module);
     delete s;

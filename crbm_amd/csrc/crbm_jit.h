@@ -71,7 +71,9 @@ inline uint64_t jit_fnv1a(const std::string& s, uint64_t h = 1469598103934665603
 // the kernel for an occupancy it will never see; 0 = no hint.
 // gibbs_tb: block-size bound of the chain kernels (256, 512 or 1024: large models share one table copy per CU)
 // GS: letters per gather-table group of the plain chain kernel (crbm_gibbs_sparse), G of everything else
-inline std::string jit_stub(int K, int M, int DS, int G, int GS, int POOL, int gibbs_wpe, int gibbs_tb = 256) {
+// slab: the module also carries the kernels that run the model as a slab of a larger one (crbm_slab_*; models of up to 64 motifs):
+// compiled for the shadow handles of generic models only, so that an ordinary model does not pay for them at crbm_create
+inline std::string jit_stub(int K, int M, int DS, int G, int GS, int POOL, int gibbs_wpe, int gibbs_tb = 256, bool slab = false) {
   char attr[96] = "", sattr[96] = "";
   if (gibbs_wpe > 0) snprintf(attr, sizeof(attr), "__attribute__((amdgpu_waves_per_eu(1, %d)))", gibbs_wpe);
   else snprintf(attr, sizeof(attr), "__attribute__((amdgpu_waves_per_eu(4)))");   // 4 blocks of 4 waves per CU: at most 128 registers
@@ -81,6 +83,7 @@ inline std::string jit_stub(int K, int M, int DS, int G, int GS, int POOL, int g
   else snprintf(sattr, sizeof(sattr), "__attribute__((amdgpu_waves_per_eu(4)))");
   char buf[16384];
   snprintf(buf, sizeof(buf),
+           "#define CRBM_SLAB_KERNELS %d\n"
            "#include \"crbm_kernels.h\"\n"
            "#ifndef CRBM_GIBBS_ATTR\n#define CRBM_GIBBS_ATTR %s\n#endif\n"
            "#ifndef CRBM_GIBBS_STATS_ATTR\n#define CRBM_GIBBS_STATS_ATTR %s\n#endif\n"
@@ -93,8 +96,8 @@ inline std::string jit_stub(int K, int M, int DS, int G, int GS, int POOL, int g
            "extern \"C\" __global__ void __launch_bounds__(1024) crbm_update_tables(crbm::UpdateTablesArgs a) { crbm::update_tables_body<ModelCfg>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(1024) crbm_update_tables_ipc(crbm::UpdateIpcArgs a) { crbm::update_tables_ipc_body<ModelCfg>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_hgv(crbm::HgvArgs a) { crbm::hgv_body<ModelCfg>(a); }\n"
-           "extern \"C\" __global__ void __launch_bounds__(256) crbm_slab_hgv(crbm::SlabHgvArgs a) { if constexpr (ModelCfg::K <= 64) crbm::slab_hgv_body<ModelCfg>(a); }\n"
-           "extern \"C\" __global__ void __launch_bounds__(256) crbm_slab_tables(crbm::SlabTablesArgs a) { if constexpr (ModelCfg::K <= 64) crbm::slab_tables_body<ModelCfg>(a); }\n"
+           "extern \"C\" __global__ void __launch_bounds__(256) crbm_slab_hgv(crbm::SlabHgvArgs a) { if constexpr (CRBM_SLAB_KERNELS && ModelCfg::K <= 64) crbm::slab_hgv_body<ModelCfg>(a); }\n"
+           "extern \"C\" __global__ void __launch_bounds__(256) crbm_slab_tables(crbm::SlabTablesArgs a) { if constexpr (CRBM_SLAB_KERNELS && ModelCfg::K <= 64) crbm::slab_tables_body<ModelCfg>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(%d) CRBM_GIBBS_ATTR crbm_gibbs_sparse(crbm::GibbsArgs a) { crbm::gibbs_body<SoloCfg, true>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(CRBM_FUSED_TB) CRBM_GIBBS_STATS_ATTR crbm_gibbs_sparse_stats(crbm::GibbsArgs a) { if constexpr (ModelCfg::FUSE_STATS) crbm::gibbs_body<ModelCfg, true, true>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(CRBM_FUSED_TB) CRBM_GIBBS_STATS_ATTR crbm_train_local(crbm::TrainLocalArgs a) { crbm::train_local_body<ModelCfg>(a); }\n"
@@ -102,25 +105,25 @@ inline std::string jit_stub(int K, int M, int DS, int G, int GS, int POOL, int g
            "using RoleData = crbm::StatsRole<ModelCfg, true>;\nusing RoleModel = crbm::StatsRole<ModelCfg, false>;\n"
            "extern \"C\" __global__ void __launch_bounds__(RoleData::THREADS) crbm_stats_mfma_data(crbm::StatsMfmaArgs a) { crbm::stats_mfma_body<ModelCfg, true, CRBM_STATS_BYTE_LUT>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(RoleModel::THREADS) crbm_stats_mfma_model(crbm::StatsMfmaArgs a) { crbm::stats_mfma_body<ModelCfg, false, CRBM_STATS_BYTE_LUT>(a); }\n"
-           "extern \"C\" __global__ void __launch_bounds__(RoleData::THREADS) crbm_slab_stats_data(crbm::SlabStatsArgs a) { if constexpr (ModelCfg::K <= 64) crbm::slab_stats_body<ModelCfg, true, CRBM_STATS_BYTE_LUT>(a); }\n"
-           "extern \"C\" __global__ void __launch_bounds__(RoleModel::THREADS) crbm_slab_stats_model(crbm::SlabStatsArgs a) { if constexpr (ModelCfg::K <= 64) crbm::slab_stats_body<ModelCfg, false, CRBM_STATS_BYTE_LUT>(a); }\n"
+           "extern \"C\" __global__ void __launch_bounds__(RoleData::THREADS) crbm_slab_stats_data(crbm::SlabStatsArgs a) { if constexpr (CRBM_SLAB_KERNELS && ModelCfg::K <= 64) crbm::slab_stats_body<ModelCfg, true, CRBM_STATS_BYTE_LUT>(a); }\n"
+           "extern \"C\" __global__ void __launch_bounds__(RoleModel::THREADS) crbm_slab_stats_model(crbm::SlabStatsArgs a) { if constexpr (CRBM_SLAB_KERNELS && ModelCfg::K <= 64) crbm::slab_stats_body<ModelCfg, false, CRBM_STATS_BYTE_LUT>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_free_energy(crbm::FeArgs a) { crbm::free_energy_body<ModelCfg>(a); }\n"
-           "extern \"C\" __global__ void __launch_bounds__(256) crbm_slab_fe(crbm::SlabFeArgs a) { if constexpr (ModelCfg::K <= 64) crbm::slab_fe_body<ModelCfg>(a); }\n"
+           "extern \"C\" __global__ void __launch_bounds__(256) crbm_slab_fe(crbm::SlabFeArgs a) { if constexpr (CRBM_SLAB_KERNELS && ModelCfg::K <= 64) crbm::slab_fe_body<ModelCfg>(a); }\n"
            "extern \"C\" __global__ void __launch_bounds__(256) crbm_hit_summary(crbm::HitArgs a) { crbm::hit_summary_body<ModelCfg>(a); }\n",
-           attr, sattr, K, M, DS, G, POOL, K, M, DS, GS, POOL, gibbs_tb, gibbs_tb);
+           slab ? 1 : 0, attr, sattr, K, M, DS, G, POOL, K, M, DS, GS, POOL, gibbs_tb, gibbs_tb);
   return buf;
 }
 
 // Compile (or fetch from the cache) the code object; no device needed.
 inline int jit_compile(int K, int M, int DS, int G, int GS, int POOL, int gibbs_wpe, int gibbs_tb, std::vector<char>* code, bool* from_cache,
-                       std::string* cache_file, std::string* err) {
+                       std::string* cache_file, std::string* err, bool slab = false) {
   const std::string dir = jit_source_dir();
   std::string kernels, layout;
   if (!jit_read_file(dir + "/crbm_kernels.h", &kernels) || !jit_read_file(dir + "/crbm_layout.h", &layout)) {
     *err = "kernel sources not found in " + dir + " (set CRBM_KERNEL_SRC_DIR)";
     return -1;
   }
-  const std::string stub = jit_stub(K, M, DS, G, GS, POOL, gibbs_wpe, gibbs_tb);
+  const std::string stub = jit_stub(K, M, DS, G, GS, POOL, gibbs_wpe, gibbs_tb, slab);
   std::vector<std::string> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
                                    "-I" + dir, "-I/opt/rocm/include"};
   if (const char* e = getenv("CRBM_JIT_DEFINES")) {   // tuning knobs, e.g. "-DCRBM_STATS_MAX_TILES=16"
@@ -185,9 +188,9 @@ inline int jit_compile(int K, int M, int DS, int G, int GS, int POOL, int gibbs_
   return 0;
 }
 
-inline int jit_load(int K, int M, int DS, int G, int GS, int POOL, int gibbs_wpe, int gibbs_tb, JitKernels* out, std::string* err) {
+inline int jit_load(int K, int M, int DS, int G, int GS, int POOL, int gibbs_wpe, int gibbs_tb, JitKernels* out, std::string* err, bool slab = false) {
   std::vector<char> code;
-  if (jit_compile(K, M, DS, G, GS, POOL, gibbs_wpe, gibbs_tb, &code, &out->from_cache, &out->cache_file, err) != 0) return -1;
+  if (jit_compile(K, M, DS, G, GS, POOL, gibbs_wpe, gibbs_tb, &code, &out->from_cache, &out->cache_file, err, slab) != 0) return -1;
   hipError_t e = hipModuleLoadData(&out->module, code.data());
   if (e != hipSuccess) {
     *err = std::string("hipModuleLoadData: ") + hipGetErrorString(e);
