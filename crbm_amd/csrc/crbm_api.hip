@@ -362,7 +362,7 @@ int big_launch_gibbs(crbm_handle* h, int steps, hipStream_t st) {
   v.nchains = h->B; v.Lf = h->Lf; v.Lv = h->Lv; v.LWs = h->gl.LWs;
   v.JS = std::max(1, std::min(h->M, (64 * 1024) / (32 * 4 * h->A)));
   // DNA: activations in registers; any other alphabet: one position per thread, activations in LDS (big_vgh_any_kernel)
-  const size_t lds = h->A == 4 ? (size_t)v.JS * 32 * 16 + (size_t)BIG_VR * 256 + (size_t)2 * (BIG_VR * 256 + h->M - 1) * 4   // (+ one mask word of both strands for a chunk)
+  const size_t lds = h->A == 4 ? (size_t)v.JS * 32 * 16 + (size_t)BIG_VR * 256 + (size_t)2 * (std::min(BIG_VR * 256, h->Lv) + h->M - 1) * 4   // (+ one mask word of both strands for a chunk)
                                : ((size_t)v.JS * 32 * h->A + (size_t)h->A * 256) * 4 + 256;
   HIPCHK(hipMemsetAsync(h->d_ones, 0, sizeof(unsigned long long), st));
   for (int t = 0; t < steps; ++t) {

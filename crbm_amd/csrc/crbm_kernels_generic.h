@@ -241,7 +241,7 @@ __global__ void __launch_bounds__(256) big_vgh_kernel(BigVghArgs a) {
   const int CH = BIG_VR * (int)blockDim.x;
   // mask word w of the hidden positions a chunk's visible positions meet (s = p - j: CH + M - 1 of them), both strands: read
   // from global memory once per (chunk, word) instead of once per (position, filter column, word)
-  const int HSW = CH + M - 1;
+  const int HSW = min(CH, a.Lv) + M - 1;              // (a chain shorter than a chunk needs no more than its own length)
   uint32_t* hs = reinterpret_cast<uint32_t*>(lb + (size_t)CH);         // [2][HSW]
   for (int chain = blockIdx.x; chain < a.nchains; chain += gridDim.x) {
     const uint32_t gn = a.rng.seq_offset + (uint32_t)chain;

@@ -562,7 +562,7 @@ int emu_big_gibbs_step(const float* W, const float* b, const float* c, int K, in
   v.hm = hm; v.hmp = ds ? hmp : nullptr; v.vout = vout;
   v.nchains = nchains; v.Lf = Lf; v.Lv = Lv; v.LWs = LWs; v.JS = JS;
   v.rng = make_rng(seed, step, off);
-  if (A == 4) emu::launch([&] { big_vgh_kernel(v); }, dim3(grid), dim3(threads), (size_t)JS * 32 * 16 + (size_t)BIG_VR * threads + (size_t)2 * (BIG_VR * threads + M - 1) * 4);
+  if (A == 4) emu::launch([&] { big_vgh_kernel(v); }, dim3(grid), dim3(threads), (size_t)JS * 32 * 16 + (size_t)BIG_VR * threads + (size_t)2 * (std::min(BIG_VR * threads, Lv) + M - 1) * 4);
   else emu::launch([&] { big_vgh_any_kernel(v); }, dim3(grid), dim3(threads), ((size_t)JS * 32 * A + (size_t)A * threads) * 4 + threads);
   for (int strand = 0; strand <= ds; ++strand)
     emu_big_hgv(W, b, c, K, M, ds, vout, nchains, Lv, strand, nullptr, nullptr, nullptr, nullptr, strand ? hmp : hm, seed, step, off,
