@@ -968,37 +968,43 @@ int slab_launch_fe(crbm_handle* h, const uint32_t* rows, int n, int L, float* fe
   return CRBM_OK;
 }
 
+// The slab model of a generic DNA model: up to `want` motifs are one slab, a larger model takes slabs of a multiple of ten
+// motifs (the sampler's groups); the largest candidate whose statistics kernel fits the LDS.  Returns 0 motifs when none does.
+int slab_choose(int K, int M, int ds, int pool, int Lf, int* G_out, ModelShape* ms_out) {
+  const int want = std::max(10, std::min(env_int("CRBM_SLAB_MOTIFS", 60), 64));      // (the slab kernels are compiled for models of up to 64 motifs: crbm_jit.h)
+  const int first = K <= want ? K : want / 10 * 10;
+  for (int cand : {first, 40, 30, 20, 10}) {
+    if (cand > K || (cand != first && cand >= first)) continue;
+    int G = env_int("CRBM_SLAB_GROUP", 0);
+    if (G < 1 || G > 4) {
+      // the table budget of the specialised kernels; long motifs that it leaves with single letters take pairs where those fit
+      // twice 48 KB (60 x 40 double-stranded: 77 KB, training step 1.55 -> 1.19 ms at 2048 chains; a larger budget for ALL slabs
+      // costs the statistics kernel waves: 256 x 4 double-stranded 1.72 -> 1.99 ms)
+      const int budget = env_int("CRBM_SLAB_TABLE_BUDGET", 26 * 1024);
+      G = choose_group(cand, M, ds, budget);
+      if (G == 1) G = choose_group(cand, M, ds, std::max(budget, 48 * 1024));
+    }
+    const ModelShape ms = model_shape(cand, M, ds, G, pool);
+    bool fit = true;
+    for (int want_sp = 0; want_sp <= 1 && fit; ++want_sp) {
+      const int tabs = ms.TAB * 4;
+      const StatsMfmaLayout st = stats_mfma_layout(ms, want_sp, Lf, 0, tabs, true);
+      if (st.threads > 1024 || std::max(st.region_floats * 4 + tabs, st.combine_bytes) > 160 * 1024) fit = false;
+    }
+    if (fit) { *G_out = G; *ms_out = ms; return cand; }
+  }
+  return 0;
+}
+
 // The shadow handle of the slab model of a generic handle (crbm_create); leaves h->slab null, with the reason in
 // h->slab_note, when the model is not one for slabs.  CRBM_SLAB_STATS=0 switches them off (A/B runs, tests).
 int slab_setup(crbm_handle* h) {
   if (!h->big) return CRBM_OK;
   if (env_int("CRBM_SLAB_STATS", 1) == 0) { h->slab_note = "CRBM_SLAB_STATS=0"; return CRBM_OK; }
   if (h->A != 4 || h->M > MAX_MOTIF_LENGTH) { h->slab_note = "other alphabet, or motifs beyond 64 letters"; return CRBM_OK; }
-  // a model of up to `want` motifs is one slab; a larger one takes slabs of a multiple of ten motifs (the sampler's groups)
-  const int want = std::max(10, std::min(env_int("CRBM_SLAB_MOTIFS", 60), 64));      // (the slab kernels are compiled for models of up to 64 motifs: crbm_jit.h)
-  int Ks = 0, G = 0;
+  int G = 0;
   ModelShape ms;
-  const int first = h->K <= want ? h->K : want / 10 * 10;
-  for (int cand : {first, 40, 30, 20, 10}) {
-    if (cand > h->K || (cand != first && cand >= first)) continue;
-    G = env_int("CRBM_SLAB_GROUP", 0);
-    if (G < 1 || G > 4) {
-      // the table budget of the specialised kernels; long motifs that it leaves with single letters take pairs where those fit
-      // twice 48 KB (60 x 40 double-stranded: 77 KB, training step 1.55 -> 1.19 ms at 2048 chains; a larger budget for ALL slabs
-      // costs the statistics kernel waves: 256 x 4 double-stranded 1.72 -> 1.99 ms)
-      const int budget = env_int("CRBM_SLAB_TABLE_BUDGET", 26 * 1024);
-      G = choose_group(cand, h->M, h->ds, budget);
-      if (G == 1) G = choose_group(cand, h->M, h->ds, std::max(budget, 48 * 1024));
-    }
-    ms = model_shape(cand, h->M, h->ds, G, h->ms.POOL);
-    bool fit = true;
-    for (int want_sp = 0; want_sp <= 1 && fit; ++want_sp) {
-      const int tabs = ms.TAB * 4;
-      const StatsMfmaLayout st = stats_mfma_layout(ms, want_sp, h->Lf, 0, tabs, true);
-      if (st.threads > 1024 || std::max(st.region_floats * 4 + tabs, st.combine_bytes) > 160 * 1024) fit = false;
-    }
-    if (fit) { Ks = cand; break; }
-  }
+  const int Ks = slab_choose(h->K, h->M, h->ds, h->ms.POOL, h->Lf, &G, &ms);
   if (!Ks) { h->slab_note = "no slab of this motif length fits the LDS"; return CRBM_OK; }
   crbm_handle* s = new crbm_handle();
   std::string err;
@@ -1510,8 +1516,20 @@ int crbm_precompile(const crbm_config* cfg) {
   std::string file, err;
   const int Lf_pc = cfg->fantasy_hidden_len > 0 ? cfg->fantasy_hidden_len : 200;
   const int ncu = env_int("CRBM_NUM_CU", 256);
-  if (cfg->num_motifs > MAX_MOTIFS || cfg->motif_length > MAX_MOTIF_LENGTH || cfg->input_dims != 4 || model_needs_big(ms, Lf_pc, cfg->batchsize, ncu))
-    return CRBM_OK;     // the generic kernels are compiled ahead of time: nothing to specialise
+  if (cfg->num_motifs > MAX_MOTIFS || cfg->motif_length > MAX_MOTIF_LENGTH || cfg->input_dims != 4 || model_needs_big(ms, Lf_pc, cfg->batchsize, ncu)) {
+    // the generic kernels are compiled ahead of time; a DNA model with motifs of up to 64 letters also takes the kernels of
+    // its slab model (slab_setup): those are specialised
+    if (cfg->input_dims == 4 && cfg->motif_length <= MAX_MOTIF_LENGTH && env_int("CRBM_SLAB_STATS", 1) != 0) {
+      int Gs = 0;
+      ModelShape mss;
+      const int Ks = slab_choose(cfg->num_motifs, cfg->motif_length, ds, cfg->pooling, Lf_pc, &Gs, &mss);
+      if (Ks > 0 && jit_compile(Ks, cfg->motif_length, ds, Gs, Gs, mss.POOL, 0, 256, &code, &cached, &file, &err, true) != 0) {
+        g_create_error = err;
+        return CRBM_ERR_HIP;
+      }
+    }
+    return CRBM_OK;
+  }
   const GibbsGeom gs = choose_gibbs_geometry(ms, Lf_pc, cfg->batchsize, ncu, true);
   int tb = gs.threads;
   if (ms.DENSE) tb = std::max(tb, choose_gibbs_geometry(ms, Lf_pc, cfg->batchsize, ncu, false).threads);
